@@ -1,0 +1,716 @@
+// fem_hip.hip — host side of libfemhip.so: the C ABI declared in include/fem_hip.h.
+// Owns device memory, streams, pinned result buffers and the launch logic of the
+// kernels in fem_kernels.hip.h.  No CPU fallback: every entry point needs a GPU.
+#include "../../include/fem_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fem_index_build.hip.h"
+#include "fem_kernels.hip.h"
+
+namespace {
+
+constexpr int kSlots = 4;
+constexpr uint32_t kMaxReadLen = 1024;
+constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;
+
+struct TimedLaunch {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  // inputs
+  uint8_t *d_bases = nullptr;
+  size_t bases_cap = 0;
+  uint64_t *d_off = nullptr;
+  size_t off_cap = 0;
+  uint64_t n_reads = 0;
+  uint64_t n_bases = 0;
+  uint32_t max_len = 0;
+  bool staged = false;
+  // outputs on the device
+  uint64_t *d_cand = nullptr;
+  uint32_t *d_meta = nullptr;
+  uint8_t *d_ed = nullptr;
+  int16_t *d_end = nullptr;
+  uint32_t cand_cap = 0;
+  uint32_t *d_begin = nullptr, *d_count = nullptr, *d_nmap = nullptr;
+  size_t per_read_cap = 0;
+  // counters: ctr[4] (u32) | arena_ctr[2] (u64) | stats[4] (u64)
+  uint8_t *d_ctl = nullptr;
+  uint8_t *h_ctl = nullptr;  // pinned mirror
+  uint64_t *d_arena = nullptr;
+  uint64_t arena_cap = 0;
+  // pinned host results
+  uint32_t *h_begin = nullptr, *h_count = nullptr;
+  size_t h_per_read_cap = 0;
+  uint64_t *h_cand = nullptr;
+  uint8_t *h_ed = nullptr;
+  int16_t *h_end = nullptr;
+  size_t h_cand_cap = 0;
+  // state of the last launch
+  fem_params params{};
+  bool mapped = false, synced = false;
+  uint64_t stats[5] = {0, 0, 0, 0, 0};
+  uint32_t n_cand = 0;
+  std::vector<TimedLaunch> pending;
+};
+
+constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
+
+}  // namespace
+
+struct fem_dev {
+  int device = 0;
+  int n_cu = 256;
+  std::string err;
+  // index
+  uint32_t *d_lookup = nullptr;
+  uint64_t n_lookup = 0;
+  uint64_t *d_occ = nullptr;
+  uint64_t n_occ = 0;
+  int32_t k = 0, step = 0;
+  // reference
+  uint8_t *d_ref = nullptr;  // base codes
+  uint64_t ref_bytes = 0;
+  uint64_t *d_seq_off = nullptr;
+  uint32_t *d_seq_len = nullptr;
+  uint32_t n_seq = 0;
+  std::vector<uint64_t> seq_off;
+  std::vector<uint32_t> seq_len;
+  Slot slot[kSlots];
+  bool timing = false;
+  double t_ms[2] = {0, 0};
+  uint64_t t_n[2] = {0, 0};
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(fem_dev *h, int rc, const std::string &msg) {
+  if (h) h->err = msg;
+  return rc;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(h, e_ == hipErrorOutOfMemory ? FEM_ERR_NOMEM : FEM_ERR_HIP,                     \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+  } while (0)
+
+template <typename T>
+int dev_realloc(fem_dev *h, T **p, size_t *cap, size_t want, bool keep = false) {
+  if (want <= *cap && *p) return FEM_OK;
+  size_t n = std::max(want, *cap + *cap / 2);
+  T *q = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&q, std::max<size_t>(n, 1) * sizeof(T)));
+  if (keep && *p && *cap) HIP_TRY(h, hipMemcpy(q, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice));
+  if (*p) (void)hipFree(*p);
+  *p = q;
+  *cap = n;
+  return FEM_OK;
+}
+
+template <typename T>
+int pinned_realloc(fem_dev *h, T **p, size_t *cap, size_t want) {
+  if (want <= *cap && *p) return FEM_OK;
+  size_t n = std::max(want, *cap + *cap / 2);
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  HIP_TRY(h, hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+  *cap = n;
+  return FEM_OK;
+}
+
+bool params_ok(const fem_params *p) {
+  return p && p->k >= 1 && p->k <= 16 && p->step >= 1 && p->step <= 16 && p->e >= 0 && p->e <= 7 && p->a >= 0 &&
+         p->a <= 2;
+}
+
+// LDS carve-up of one wave for reads up to max_len (see femk::SeedLayout)
+femk::SeedLayout make_layout(const fem_params &p, uint32_t max_len) {
+  femk::SeedLayout l{};
+  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
+  const uint32_t lg = (uint32_t)(p.k / p.step + (p.k % p.step ? 1 : 0));
+  const uint32_t n_groups = 2u * (uint32_t)p.step;
+  uint32_t smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
+  int c = (int)(smax / (uint32_t)p.step) - (int)(R * lg) + 2;
+  uint32_t cmax = (uint32_t)std::max(c, 2);
+  l.smax = smax;
+  l.cmax = cmax;
+  l.cw = (cmax + 31u) / 32u;
+  l.n_words = (max_len + 15u) / 16u + 2u;
+  l.xcap = kXcapSmall, l.fcap = kFcap, l.ccap = kCcap;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  l.pkw = take(l.n_words * 4u);
+  l.nkw = take(l.n_words * 4u);
+  l.sf = take(2u * smax * 8u);
+  l.dp_rows = take(n_groups * 2u * cmax * 4u);
+  l.dp_bits = take(n_groups * R * l.cw * 4u);
+  l.picked = take(n_groups * R * 16u);
+  l.rb = take(2u * (R + 1u) * 4u);
+  l.X = take(l.xcap * 8u);
+  l.F = take(l.fcap * 8u);
+  l.A = take(l.ccap * 8u);
+  l.B = take(l.ccap * 8u);
+  l.wave_bytes = o;
+  return l;
+}
+
+hipEvent_t get_event(fem_dev *h) {
+  if (!h->event_pool.empty()) {
+    hipEvent_t e = h->event_pool.back();
+    h->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void drain_timing(fem_dev *h, Slot &s) {
+  for (auto &t : s.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      h->t_ms[t.kernel] += ms;
+      h->t_n[t.kernel] += 1;
+    }
+    h->event_pool.push_back(t.start);
+    h->event_pool.push_back(t.stop);
+  }
+  s.pending.clear();
+}
+
+int ensure_outputs(fem_dev *h, Slot &s) {
+  size_t want_reads = (size_t)s.n_reads;
+  if (want_reads > s.per_read_cap || !s.d_begin) {
+    size_t cap = std::max<size_t>(want_reads, 1);
+    if (s.d_begin) (void)hipFree(s.d_begin);
+    if (s.d_count) (void)hipFree(s.d_count);
+    if (s.d_nmap) (void)hipFree(s.d_nmap);
+    s.d_begin = s.d_count = s.d_nmap = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&s.d_begin, cap * 2 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void **)&s.d_count, cap * 2 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void **)&s.d_nmap, cap * sizeof(uint32_t)));
+    s.per_read_cap = cap;
+  }
+  if (!s.d_cand) {
+    uint64_t want = std::max<uint64_t>(1u << 20, 2 * s.n_reads + (1u << 16));
+    want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
+    s.cand_cap = 0;
+    size_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int rc;
+    if ((rc = dev_realloc(h, &s.d_cand, &c0, want))) return rc;
+    if ((rc = dev_realloc(h, &s.d_meta, &c1, want))) return rc;
+    if ((rc = dev_realloc(h, &s.d_ed, &c2, want))) return rc;
+    if ((rc = dev_realloc(h, &s.d_end, &c3, want))) return rc;
+    s.cand_cap = (uint32_t)want;
+  }
+  if (!s.d_ctl) {
+    HIP_TRY(h, hipMalloc((void **)&s.d_ctl, kCtlBytes));
+    HIP_TRY(h, hipHostMalloc((void **)&s.h_ctl, kCtlBytes, hipHostMallocDefault));
+  }
+  if (!s.d_arena) {
+    s.arena_cap = 4u << 20;  // entries (32 MiB); grown on demand
+    HIP_TRY(h, hipMalloc((void **)&s.d_arena, s.arena_cap * sizeof(uint64_t)));
+  }
+  return FEM_OK;
+}
+
+int grow_candidates(fem_dev *h, Slot &s, uint64_t want) {
+  if (want > 0xFFFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^32 candidates in one batch; split the batch");
+  for (void *p : {(void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed, (void *)s.d_end})
+    if (p) (void)hipFree(p);
+  s.d_cand = nullptr, s.d_meta = nullptr, s.d_ed = nullptr, s.d_end = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&s.d_cand, want * sizeof(uint64_t)));
+  HIP_TRY(h, hipMalloc((void **)&s.d_meta, want * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&s.d_ed, want * sizeof(uint8_t)));
+  HIP_TRY(h, hipMalloc((void **)&s.d_end, want * sizeof(int16_t)));
+  s.cand_cap = (uint32_t)want;
+  return FEM_OK;
+}
+
+// Enqueue the two kernels of one batch on the slot's stream (asynchronous).
+int launch_batch(fem_dev *h, Slot &s) {
+  const fem_params &p = s.params;
+  uint32_t *d_ctr = (uint32_t *)s.d_ctl;
+  unsigned long long *d_arena_ctr = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t));
+  unsigned long long *d_stats = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
+  HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlBytes, s.stream));
+  if (s.n_reads) HIP_TRY(h, hipMemsetAsync(s.d_nmap, 0, s.n_reads * sizeof(uint32_t), s.stream));
+
+  femk::SeedParams sp{};
+  sp.bases = s.d_bases;
+  sp.read_off = s.d_off;
+  sp.n_reads = (uint32_t)s.n_reads;
+  sp.lookup = h->d_lookup;
+  sp.occ = h->d_occ;
+  sp.inf32 = (uint32_t)h->n_occ;
+  sp.seq_len = h->d_seq_len;
+  sp.e = p.e, sp.a = p.a, sp.R = p.e + 1 + p.a, sp.k = p.k, sp.step = p.step;
+  sp.lg = p.k / p.step + (p.k % p.step ? 1 : 0);
+  sp.cand = s.d_cand, sp.cand_meta = s.d_meta, sp.cand_cap = s.cand_cap;
+  sp.cand_begin = s.d_begin, sp.cand_count = s.d_count;
+  sp.ctr = d_ctr;
+  sp.stats = d_stats;
+  sp.arena = s.d_arena, sp.arena_cap = s.arena_cap, sp.arena_ctr = d_arena_ctr;
+  sp.lay = make_layout(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
+
+  uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / sp.lay.wave_bytes));
+  if (sp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
+  uint32_t lds_bytes = wpb * sp.lay.wave_bytes;
+  uint32_t waves_per_cu = std::min<uint32_t>(32u, (160u * 1024u / lds_bytes) * wpb);
+  uint64_t blocks_wanted = (s.n_reads + wpb - 1) / wpb;
+  uint64_t blocks_resident = (uint64_t)h->n_cu * std::max<uint32_t>(1u, waves_per_cu / wpb);
+  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks_wanted, blocks_resident * 4));
+
+  TimedLaunch t0{0, nullptr, nullptr}, t1{1, nullptr, nullptr};
+  if (s.n_reads) {
+    if (h->timing) {
+      t0.start = get_event(h), t0.stop = get_event(h);
+      HIP_TRY(h, hipEventRecord(t0.start, s.stream));
+    }
+    hipLaunchKernelGGL(femk::seed_filter_kernel, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, sp);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) {
+      HIP_TRY(h, hipEventRecord(t0.stop, s.stream));
+      s.pending.push_back(t0);
+    }
+
+    femk::VerifyParams vp{};
+    vp.bases = s.d_bases, vp.read_off = s.d_off;
+    vp.ref_codes = h->d_ref, vp.seq_off = h->d_seq_off;
+    vp.cand = s.d_cand, vp.cand_meta = s.d_meta, vp.cand_begin = s.d_begin, vp.cand_count = s.d_count;
+    vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
+    vp.ed = s.d_ed, vp.end = s.d_end, vp.n_map = s.d_nmap, vp.stats = d_stats;
+    uint32_t vgrid = (uint32_t)h->n_cu * 8u;
+    if (h->timing) {
+      t1.start = get_event(h), t1.stop = get_event(h);
+      HIP_TRY(h, hipEventRecord(t1.start, s.stream));
+    }
+    hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) {
+      HIP_TRY(h, hipEventRecord(t1.stop, s.stream));
+      s.pending.push_back(t1);
+    }
+  }
+  HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
+  s.mapped = true;
+  s.synced = false;
+  return FEM_OK;
+}
+
+int check_slot(fem_dev *h, int slot) {
+  if (!h) return FEM_ERR_INVALID;
+  if (slot < 0 || slot >= kSlots) return fail(h, FEM_ERR_INVALID, "slot out of range");
+  return FEM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fem_strerror(int rc) {
+  switch (rc) {
+    case FEM_OK: return "ok";
+    case FEM_ERR_INVALID: return "invalid argument";
+    case FEM_ERR_HIP: return "HIP runtime error";
+    case FEM_ERR_NOMEM: return "out of memory";
+    case FEM_ERR_STATE: return "call order violated";
+    case FEM_ERR_UNSUPPORTED: return "input not supported by the device path";
+    case FEM_ERR_RCCL: return "RCCL error";
+    default: return "unknown error";
+  }
+}
+
+const char *fem_dev_last_error(const fem_dev *h) { return h ? h->err.c_str() : "null handle"; }
+
+int fem_dev_open(int device, fem_dev **out) {
+  if (!out) return FEM_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FEM_ERR_HIP;  // no GPU: fail loudly, no fallback
+  if (device < 0 || device >= n) return FEM_ERR_INVALID;
+  fem_dev *h = new (std::nothrow) fem_dev();
+  if (!h) return FEM_ERR_NOMEM;
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete h;
+    return FEM_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+  for (int i = 0; i < kSlots; ++i) {
+    if (hipStreamCreateWithFlags(&h->slot[i].stream, hipStreamNonBlocking) != hipSuccess) {
+      delete h;
+      return FEM_ERR_HIP;
+    }
+  }
+  *out = h;
+  return FEM_OK;
+}
+
+int fem_dev_close(fem_dev *h) {
+  if (!h) return FEM_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (auto &s : h->slot) {
+    drain_timing(h, s);
+    for (void *p : {(void *)s.d_bases, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
+                    (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
+                    (void *)s.d_arena})
+      if (p) (void)hipFree(p);
+    for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
+                    (void *)s.h_end})
+      if (p) (void)hipHostFree(p);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len})
+    if (p) (void)hipFree(p);
+  delete h;
+  return FEM_OK;
+}
+
+int fem_dev_limits(const fem_dev *h, uint32_t *max_read_len, int32_t *n_slots) {
+  if (!h) return FEM_ERR_INVALID;
+  if (max_read_len) *max_read_len = kMaxReadLen;
+  if (n_slots) *n_slots = kSlots;
+  return FEM_OK;
+}
+
+int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lookup, uint64_t n_lookup,
+                         const uint64_t *occ, uint64_t n_occ) {
+  if (!h || !lookup || (!occ && n_occ)) return FEM_ERR_INVALID;
+  if (k < 1 || k > 16 || step < 1) return fail(h, FEM_ERR_INVALID, "k must be 1..16 and step >= 1");
+  if (n_lookup != (1ull << (2 * k)) + 1) return fail(h, FEM_ERR_INVALID, "lookup table must have 4^k + 1 entries");
+  if (n_occ > 0xFFFFFFFFull) return fail(h, FEM_ERR_INVALID, "occurrence table larger than its uint32 prefix sums");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->d_lookup) (void)hipFree(h->d_lookup);
+  if (h->d_occ) (void)hipFree(h->d_occ);
+  h->d_lookup = nullptr, h->d_occ = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&h->d_lookup, n_lookup * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_occ, std::max<uint64_t>(n_occ, 1) * sizeof(uint64_t)));
+  HIP_TRY(h, hipMemcpy(h->d_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (n_occ) HIP_TRY(h, hipMemcpy(h->d_occ, occ, n_occ * sizeof(uint64_t), hipMemcpyHostToDevice));
+  h->n_lookup = n_lookup, h->n_occ = n_occ, h->k = k, h->step = step;
+  return FEM_OK;
+}
+
+int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len) {
+  if (!h || !seq || !seq_len || n_seq == 0) return FEM_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  h->seq_off.assign(n_seq, 0);
+  h->seq_len.assign(seq_len, seq_len + n_seq);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_seq; ++i) {
+    h->seq_off[i] = total;
+    total += seq_len[i];
+  }
+  for (void *p : {(void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len})
+    if (p) (void)hipFree(p);
+  h->d_ref = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
+  // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 64));
+  HIP_TRY(h, hipMalloc((void **)&h->d_seq_off, n_seq * sizeof(uint64_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_seq_len, n_seq * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemset(h->d_ref + total, 4, 64));
+  for (uint32_t i = 0; i < n_seq; ++i)
+    if (seq_len[i]) HIP_TRY(h, hipMemcpy(h->d_ref + h->seq_off[i], seq[i], seq_len[i], hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_seq_off, h->seq_off.data(), n_seq * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_seq_len, h->seq_len.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (total) {
+    hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, total);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+  }
+  h->ref_bytes = total, h->n_seq = n_seq;
+  return FEM_OK;
+}
+
+int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_out, uint64_t *occ_out, uint64_t occ_cap,
+                        uint64_t *n_occ_out) {
+  if (!h) return FEM_ERR_INVALID;
+  if (!h->d_ref) return fail(h, FEM_ERR_STATE, "upload the reference before building the index");
+  if (k < 1 || k > 16 || step < 1) return fail(h, FEM_ERR_INVALID, "k must be 1..16 and step >= 1");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->d_lookup) (void)hipFree(h->d_lookup);
+  if (h->d_occ) (void)hipFree(h->d_occ);
+  h->d_lookup = nullptr, h->d_occ = nullptr;
+  uint64_t n_occ = 0;
+  std::string err;
+  int rc = femix::build_index(h->d_ref, h->seq_off, h->seq_len, k, step, h->n_cu, &h->d_lookup, &h->d_occ, &n_occ, &err);
+  if (rc != FEM_OK) return fail(h, rc, err);
+  h->n_lookup = (1ull << (2 * k)) + 1, h->n_occ = n_occ, h->k = k, h->step = step;
+  if (n_occ_out) *n_occ_out = n_occ;
+  if (lookup_out)
+    HIP_TRY(h, hipMemcpy(lookup_out, h->d_lookup, h->n_lookup * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (occ_out) {
+    if (occ_cap < n_occ) return fail(h, FEM_ERR_INVALID, "occ_out too small");
+    if (n_occ) HIP_TRY(h, hipMemcpy(occ_out, h->d_occ, n_occ * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return FEM_OK;
+}
+
+int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  if (!reads || (reads->n_reads && (!reads->bases || !reads->offsets))) return fail(h, FEM_ERR_INVALID, "null read batch");
+  if (reads->n_reads > 0x7FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
+  Slot &s = h->slot[slot];
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(s.stream));
+  drain_timing(h, s);
+  const uint64_t n = reads->n_reads;
+  const uint64_t base0 = n ? reads->offsets[0] : 0;
+  const uint64_t n_bases = n ? reads->offsets[n] - base0 : 0;
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t len = reads->offsets[i + 1] - reads->offsets[i];
+    if (reads->offsets[i + 1] < reads->offsets[i]) return fail(h, FEM_ERR_INVALID, "read offsets must be ascending");
+    if (len > kMaxReadLen)
+      return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
+    max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+  }
+  if ((rc = dev_realloc(h, &s.d_bases, &s.bases_cap, (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
+  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_bases, reads->bases + base0, n_bases, hipMemcpyHostToDevice, s.stream));
+  if (base0 == 0) {
+    HIP_TRY(h, hipMemcpyAsync(s.d_off, reads->offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+  } else {
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[i] = reads->offsets[i] - base0;
+    HIP_TRY(h, hipMemcpyAsync(s.d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+  }
+  s.n_reads = n, s.n_bases = n_bases, s.max_len = max_len;
+  s.staged = true, s.mapped = false, s.synced = false;
+  return FEM_OK;
+}
+
+int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  if (!params_ok(p)) return fail(h, FEM_ERR_INVALID, "parameters out of range (k 1..16, step 1..16, e 0..7, a 0..2)");
+  if (!h->d_lookup || !h->d_ref) return fail(h, FEM_ERR_STATE, "index and reference must be uploaded first");
+  if (p->k != h->k) return fail(h, FEM_ERR_INVALID, "k differs from the uploaded index");
+  Slot &s = h->slot[slot];
+  if (!s.staged) return fail(h, FEM_ERR_STATE, "no reads staged in this slot");
+  HIP_TRY(h, hipSetDevice(h->device));
+  s.params = *p;
+  if ((rc = ensure_outputs(h, s))) return rc;
+  return launch_batch(h, s);
+}
+
+int fem_dev_sync(fem_dev *h, int slot) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!s.mapped) return fail(h, FEM_ERR_STATE, "nothing was mapped in this slot");
+  if (s.synced) return FEM_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    drain_timing(h, s);
+    const uint32_t *ctr = (const uint32_t *)s.h_ctl;
+    const uint64_t *arena_ctr = (const uint64_t *)(s.h_ctl + 4 * sizeof(uint32_t));
+    const uint64_t *st = (const uint64_t *)(s.h_ctl + 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
+    uint32_t flags = ctr[1];
+    if (flags & femk::kFlagTooLarge)
+      return fail(h, FEM_ERR_UNSUPPORTED, "a read selects more than 2^31 occurrence entries in one seed group");
+    if (flags == 0) {
+      s.n_cand = ctr[0];
+      s.stats[0] = s.n_reads;
+      s.stats[1] = st[3];
+      s.stats[2] = st[0];
+      s.stats[3] = st[1];
+      s.stats[4] = st[2];
+      s.synced = true;
+      return FEM_OK;
+    }
+    // scratch too small: grow exactly what was asked for and run the batch again
+    if (flags & femk::kFlagCandOverflow) {
+      uint64_t want = (uint64_t)ctr[0] + ctr[0] / 8 + 1024;
+      if ((rc = grow_candidates(h, s, std::min<uint64_t>(want, 0xFFFFFFF0ull)))) return rc;
+    }
+    if (flags & femk::kFlagArenaOverflow) {
+      uint64_t want = arena_ctr[1] + arena_ctr[1] / 8 + 1024;
+      (void)hipFree(s.d_arena);
+      s.d_arena = nullptr;
+      hipError_t e = hipMalloc((void **)&s.d_arena, want * sizeof(uint64_t));
+      if (e != hipSuccess) {
+        s.arena_cap = 0;
+        return fail(h, FEM_ERR_NOMEM, "scratch arena for oversized seed lists does not fit in device memory; use smaller batches");
+      }
+      s.arena_cap = want;
+    }
+    if ((rc = launch_batch(h, s))) return rc;
+  }
+  return fail(h, FEM_ERR_HIP, "batch kept overflowing its scratch buffers");
+}
+
+int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]) {
+  int rc = fem_dev_sync(h, slot);
+  if (rc) return rc;
+  if (stats) memcpy(stats, h->slot[slot].stats, sizeof(uint64_t) * 5);
+  return FEM_OK;
+}
+
+int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
+  int rc = fem_dev_sync(h, slot);
+  if (rc) return rc;
+  if (!out) return fail(h, FEM_ERR_INVALID, "null result");
+  Slot &s = h->slot[slot];
+  const size_t n2 = (size_t)s.n_reads * 2, nc = s.n_cand;
+  if (n2 > s.h_per_read_cap || !s.h_begin) {
+    size_t c0 = 0, c1 = 0;
+    if (s.h_begin) (void)hipHostFree(s.h_begin);
+    if (s.h_count) (void)hipHostFree(s.h_count);
+    s.h_begin = s.h_count = nullptr;
+    if ((rc = pinned_realloc(h, &s.h_begin, &c0, std::max<size_t>(n2, 2)))) return rc;
+    if ((rc = pinned_realloc(h, &s.h_count, &c1, std::max<size_t>(n2, 2)))) return rc;
+    s.h_per_read_cap = c0;
+  }
+  if (nc > s.h_cand_cap || !s.h_cand) {
+    size_t c0 = 0, c1 = 0, c2 = 0;
+    for (void *p : {(void *)s.h_cand, (void *)s.h_ed, (void *)s.h_end})
+      if (p) (void)hipHostFree(p);
+    s.h_cand = nullptr, s.h_ed = nullptr, s.h_end = nullptr;
+    size_t want = std::max<size_t>(nc + nc / 4, 1024);
+    if ((rc = pinned_realloc(h, &s.h_cand, &c0, want))) return rc;
+    if ((rc = pinned_realloc(h, &s.h_ed, &c1, want))) return rc;
+    if ((rc = pinned_realloc(h, &s.h_end, &c2, want))) return rc;
+    s.h_cand_cap = c0;
+  }
+  if (n2) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d_count, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  }
+  if (nc) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_cand, s.d_cand, nc * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_ed, s.d_ed, nc * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_end, s.d_end, nc * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(s.stream));
+  out->n_reads = s.n_reads;
+  out->n_candidates = nc;
+  out->cand_begin = s.h_begin, out->cand_count = s.h_count;
+  out->cand = s.h_cand, out->ed = s.h_ed, out->end = s.h_end;
+  memcpy(out->stats, s.stats, sizeof s.stats);
+  return FEM_OK;
+}
+
+int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fem_read_batch *reads) {
+  int rc = fem_dev_stage_reads(h, slot, reads);
+  if (rc) return rc;
+  return fem_dev_map_staged(h, slot, p);
+}
+
+int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out) { return fem_dev_fetch(h, slot, out); }
+
+int fem_dev_set_timing(fem_dev *h, int on) {
+  if (!h) return FEM_ERR_INVALID;
+  h->timing = on != 0;
+  return FEM_OK;
+}
+
+int fem_dev_reset_timing(fem_dev *h) {
+  if (!h) return FEM_ERR_INVALID;
+  h->t_ms[0] = h->t_ms[1] = 0;
+  h->t_n[0] = h->t_n[1] = 0;
+  return FEM_OK;
+}
+
+int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
+  if (!h || kernel < 0 || kernel > 1) return FEM_ERR_INVALID;
+  if (ms_total) *ms_total = h->t_ms[kernel];
+  if (launches) *launches = h->t_n[kernel];
+  return FEM_OK;
+}
+
+int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s) {
+  if (!h || !gb_per_s || bytes == 0 || iters <= 0) return FEM_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  void *a = nullptr, *b = nullptr;
+  HIP_TRY(h, hipMalloc(&a, bytes));
+  if (hipMalloc(&b, bytes) != hipSuccess) {
+    (void)hipFree(a);
+    return fail(h, FEM_ERR_NOMEM, "copy bandwidth probe: out of memory");
+  }
+  hipStream_t st = h->slot[0].stream;
+  hipEvent_t e0 = get_event(h), e1 = get_event(h);
+  (void)hipMemsetAsync(a, 1, bytes, st);
+  (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st);
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipStreamSynchronize(st);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  h->event_pool.push_back(e0);
+  h->event_pool.push_back(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (e != hipSuccess) return fail(h, FEM_ERR_HIP, hipGetErrorString(e));
+  *gb_per_s = ms > 0 ? (2.0 * (double)bytes * iters) / (ms * 1e6) : 0.0;  // read + write
+  return FEM_OK;
+}
+
+int fem_dev_allreduce_stats(fem_dev *const *hs, int n, uint64_t *stats) {
+  if (!hs || n <= 0 || !stats) return FEM_ERR_INVALID;
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!hs[i]) return FEM_ERR_INVALID;
+    devs[i] = hs[i]->device;
+  }
+  fem_dev *h0 = hs[0];
+  std::vector<ncclComm_t> comms(n);
+  if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return fail(h0, FEM_ERR_RCCL, "ncclCommInitAll failed");
+  std::vector<uint64_t *> bufs(n, nullptr);
+  int rc = FEM_OK;
+  for (int i = 0; i < n && rc == FEM_OK; ++i) {
+    if (hipSetDevice(devs[i]) != hipSuccess || hipMalloc((void **)&bufs[i], 5 * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(bufs[i], stats + 5 * i, 5 * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(h0, FEM_ERR_HIP, "allreduce: staging the counters failed");
+  }
+  if (rc == FEM_OK) {
+    ncclGroupStart();
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(devs[i]);
+      if (ncclAllReduce(bufs[i], bufs[i], 5, ncclUint64, ncclSum, comms[i], hs[i]->slot[0].stream) != ncclSuccess)
+        rc = fail(h0, FEM_ERR_RCCL, "ncclAllReduce failed");
+    }
+    if (ncclGroupEnd() != ncclSuccess) rc = fail(h0, FEM_ERR_RCCL, "ncclGroupEnd failed");
+  }
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(devs[i]);
+    if (rc == FEM_OK) {
+      if (hipStreamSynchronize(hs[i]->slot[0].stream) != hipSuccess ||
+          hipMemcpy(stats + 5 * i, bufs[i], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(h0, FEM_ERR_HIP, "allreduce: reading the counters back failed");
+    }
+    if (bufs[i]) (void)hipFree(bufs[i]);
+    ncclCommDestroy(comms[i]);
+  }
+  return rc;
+}
+
+}  // extern "C"

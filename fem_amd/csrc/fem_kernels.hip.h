@@ -1,0 +1,704 @@
+// fem_kernels.hip.h — gfx950 kernels of the FEM mapping hot path.
+//
+//   seed_filter_kernel : one wavefront per read.  Restates
+//       generate_group_seeding_candidates (reference src/filter.c:146-223) for both
+//       strands: 2-bit rolling hashes, CSR lookups, the seed-selection DP, the
+//       merge of the shifted occurrence lists, the additional-q-gram window filter,
+//       the staged greedy de-dup and the range clip.  Lists are staged in LDS;
+//       reads whose lists do not fit take the same code path over a global arena.
+//   verify_kernel      : one lane per candidate.  Restates banded_edit_distance /
+//       vectorized_banded_edit_distance (src/align.c:102-277) and the accept test
+//       of verify_candidates (src/align.c:22,40).
+//   ref_encode_kernel  : reference characters -> base codes (src/utils.h:72).
+//
+// Integer / bit-parallel work only: nothing here is GEMM shaped, so no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace femk {
+
+constexpr int kWave = 64;
+constexpr uint32_t kFlagCandOverflow = 1u;   // candidate output buffer too small
+constexpr uint32_t kFlagArenaOverflow = 2u;  // global arena too small
+constexpr uint32_t kFlagTooLarge = 4u;       // a single group exceeds 2^31 entries
+
+// Byte offsets (relative to a wave's LDS region) and capacities; filled by the host.
+struct SeedLayout {
+  uint32_t pkw, nkw;         // uint32[n_words]: 2-bit packed bases, and 2-bit N masks
+  uint32_t sf;               // uint2[2][smax]: (lookup[h], frequency) per strand and seed
+  uint32_t dp_rows;          // uint32[n_groups][2][cmax]
+  uint32_t dp_bits;          // uint32[n_groups][R][cw]
+  uint32_t picked;           // uint4[n_groups][R]: (start, lookup[h], frequency, -)
+  uint32_t rb;               // uint32[2][R+1]: run bounds of X and of F
+  uint32_t X, F, A, B;       // uint64 arrays
+  uint32_t xcap, fcap, ccap; // capacities (entries) of X, F, A/B
+  uint32_t smax, cmax, cw;
+  uint32_t n_words;
+  uint32_t wave_bytes;
+};
+
+struct SeedParams {
+  const uint8_t *bases;
+  const uint64_t *read_off;
+  uint32_t n_reads;
+  const uint32_t *lookup;
+  const uint64_t *occ;
+  uint32_t inf32;  // (uint32_t)occurrence_table_size, the DP's +inf (src/filter.c:9)
+  const uint32_t *seq_len;
+  int32_t e, a, R, k, step, lg;
+  uint64_t *cand;
+  uint32_t *cand_meta;  // read*2 + strand per candidate
+  uint32_t cand_cap;
+  uint32_t *cand_begin;  // [2*n_reads]
+  uint32_t *cand_count;  // [2*n_reads]
+  uint32_t *ctr;         // [0] candidate cursor, [1] flags
+  unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
+  uint64_t *arena;
+  unsigned long long arena_cap;   // entries
+  unsigned long long *arena_ctr;  // [0] cursor, [1] total entries wanted (for the retry)
+  SeedLayout lay;
+};
+
+struct Picked {
+  uint32_t start, lo, freq, pad;
+};
+
+struct Bufs {
+  uint64_t *X;
+  uint64_t *F;
+  uint64_t *A;
+  uint64_t *B;
+  uint32_t xcap, fcap, ccap;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Wave-synchronous ordering of LDS traffic: DS operations of one wave execute in
+// order, so only the compiler has to be kept from moving them.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Same for the global arena: make this wave's stores visible to its own later loads.
+__device__ __forceinline__ void wave_sync_global() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool GLOBAL>
+__device__ __forceinline__ void wave_sync() {
+  if (GLOBAL)
+    wave_sync_global();
+  else
+    wave_sync_lds();
+}
+
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// char -> base code (src/utils.h:72): A/a 0, C/c 1, G/g 2, T/t 3, anything else 4
+__device__ __forceinline__ uint32_t base_code(uint32_t c) {
+  uint32_t x = (c >> 1) & 3u;           // A 0, C 1, G 3, T 2
+  uint32_t code = x ^ (x >> 1);         // A 0, C 1, G 2, T 3
+  uint32_t u = c & 0xDFu;               // upper case
+  bool acgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+  return acgt ? code : 4u;
+}
+
+// reverse the order of the 2-bit groups of a 2k-bit value
+__device__ __forceinline__ uint32_t reverse_pairs(uint32_t x, int k) {
+  uint32_t r = __brev(x) >> (32 - 2 * k);
+  return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t lower_bound_u64(const T *x, uint32_t lo, uint32_t hi, uint64_t key) {
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (x[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+template <typename T>
+__device__ __forceinline__ uint32_t upper_bound_u64(const T *x, uint32_t lo, uint32_t hi, uint64_t key) {
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (x[mid] <= key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------
+// One strand: the three phase groups of src/filter.c:190-213 followed by the
+// staged greedy de-dup.  Returns the number of entries left in the returned
+// list (sorted, before the range clip), or 0xFFFFFFFF if a buffer was too small.
+// All control flow is wave-uniform; lanes split the list entries.
+// ---------------------------------------------------------------------------
+template <bool GLOBAL>
+__device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [step][R] of this strand */,
+                                 uint32_t *rb, const Bufs &b, uint64_t **result) {
+  const uint32_t ln = lane_id();
+  const uint64_t lt_mask = (1ull << ln) - 1ull;
+  const int R = p.R;
+  const uint64_t e64 = (uint64_t)p.e;
+  uint32_t *fb = rb + (R + 1);
+  uint64_t *A = b.A, *B = b.B;
+  uint32_t nA = 0;
+
+  for (int si = 0; si < p.step; ++si) {
+    const Picked *pk = picked + si * R;
+    // ---- merge_candidate_locations (src/filter.c:80-116) as a set: stage the R shifted runs ----
+    uint32_t n = 0;
+    bool too_big = false;
+    for (int t = 0; t < R; ++t) {
+      const uint32_t start = pk[t].start, lo = pk[t].lo, freq = pk[t].freq;
+      uint64_t max_u = 0;
+      bool last = (t == R - 1);
+      if (last) {
+        // the last seed is merged only while the accumulated list has elements
+        // (src/filter.c:85): keep q <= max(U); nothing if U is empty.
+        if (n == 0) {
+          if (ln == 0) rb[t + 1] = n;
+          continue;
+        }
+        wave_sync<GLOBAL>();
+        for (int u = 0; u < R - 1; ++u) {
+          uint32_t hi_ = rb[u + 1], lo_ = rb[u];
+          if (hi_ > lo_ && hi_ <= b.xcap) {
+            uint64_t v = b.X[hi_ - 1];
+            max_u = v > max_u ? v : max_u;
+          }
+        }
+      }
+      for (uint32_t i0 = 0; i0 < freq; i0 += kWave) {
+        uint32_t i = i0 + ln;
+        bool ok = i < freq;
+        uint64_t v = 0;
+        if (ok) {
+          uint64_t o = p.occ[(uint64_t)lo + i];
+          ok = (uint32_t)o >= start;  // src/filter.c:89,106
+          v = o - start;
+          if (last) ok = ok && (v <= max_u);
+        }
+        uint64_t m = __ballot(ok);
+        uint32_t pos = n + __popcll(m & lt_mask);
+        if (ok && pos < b.xcap) b.X[pos] = v;
+        n += __popcll(m);
+        if (n > 0x7fffffffu) too_big = true;
+      }
+      if (ln == 0) rb[t + 1] = n;
+    }
+    if (ln == 0) rb[0] = 0;
+    if (too_big) return 0xFFFFFFFEu;
+    if (n > b.xcap) return 0xFFFFFFFFu;
+
+    // ---- additional_qgram_filter (src/filter.c:118-131): v survives iff at least a+1 staged values lie
+    //      in [v, v+e] (itself included); duplicates never survive the greedy pass below, so the set is enough.
+    uint32_t nF = 0;
+    if (n > (uint32_t)p.a) {
+      wave_sync<GLOBAL>();
+      const uint32_t need = (uint32_t)p.a + 1u;
+      for (int t = 0; t < R; ++t) {
+        uint32_t r_lo = rb[t], r_hi = rb[t + 1];
+        for (uint32_t i0 = r_lo; i0 < r_hi; i0 += kWave) {
+          uint32_t i = i0 + ln;
+          bool act = i < r_hi;
+          bool pass = false;
+          uint64_t v = 0;
+          if (act) {
+            v = b.X[i];
+            uint32_t cnt = 0;
+            for (int u = 0; u < R && cnt < need; ++u) {
+              uint32_t u_lo = rb[u], u_hi = rb[u + 1];
+              if (u_lo == u_hi) continue;
+              uint32_t j = (u == t) ? i : lower_bound_u64(b.X, u_lo, u_hi, v);
+              if (u == t) {
+                // own run: equal values before i also lie in [v, v+e]
+                uint32_t jj = i;
+                while (jj > u_lo && b.X[jj - 1] == v && cnt < need) {
+                  ++cnt;
+                  --jj;
+                }
+              }
+              while (j < u_hi && cnt < need && b.X[j] <= v + e64) {
+                ++cnt;
+                ++j;
+              }
+            }
+            pass = cnt >= need;
+          }
+          uint64_t m = __ballot(pass);
+          uint32_t pos = nF + __popcll(m & lt_mask);
+          if (pass && pos < b.fcap) b.F[pos] = v;
+          nF += __popcll(m);
+        }
+        if (ln == 0) fb[t + 1] = nF;
+      }
+      if (ln == 0) fb[0] = 0;
+      if (nF > b.fcap) return 0xFFFFFFFFu;
+    }
+
+    // ---- sort F (R sorted runs) into X by rank ----
+    if (nF > 0) {
+      wave_sync<GLOBAL>();
+      for (int t = 0; t < R; ++t) {
+        uint32_t r_lo = fb[t], r_hi = fb[t + 1];
+        for (uint32_t i0 = r_lo; i0 < r_hi; i0 += kWave) {
+          uint32_t i = i0 + ln;
+          if (i < r_hi) {
+            uint64_t v = b.F[i];
+            uint32_t rank = i - r_lo;
+            for (int u = 0; u < R; ++u) {
+              uint32_t u_lo = fb[u], u_hi = fb[u + 1];
+              if (u == t || u_lo == u_hi) continue;
+              uint32_t j = (u < t) ? upper_bound_u64(b.F, u_lo, u_hi, v) : lower_bound_u64(b.F, u_lo, u_hi, v);
+              rank += j - u_lo;
+            }
+            b.X[rank] = v;  // nF <= n <= xcap
+          }
+        }
+      }
+      wave_sync<GLOBAL>();
+      // ---- merge_kvec_t_uint64_t (src/filter.c:45-78): merge with the candidates so far, keep x iff
+      //      x > last kept + e.  Sequential by definition; one lane walks the two short lists.
+      uint32_t nB = 0;
+      if (ln == 0) {
+        uint32_t i = 0, j = 0;
+        uint64_t last_kept = 0;
+        while (i < nA || j < nF) {
+          uint64_t x;
+          if (i < nA && (j >= nF || A[i] < b.X[j]))
+            x = A[i++];
+          else
+            x = b.X[j++];
+          if (nB == 0 || x > last_kept + e64) {
+            if (nB < b.ccap) B[nB] = x;
+            ++nB;
+            last_kept = x;
+          }
+        }
+      }
+      nB = bcast0(nB);
+      if (nB > b.ccap) return 0xFFFFFFFFu;
+      uint64_t *tmp = A;
+      A = B;
+      B = tmp;
+      nA = nB;
+      wave_sync<GLOBAL>();
+    }
+    // nF == 0: greedy(merge(cand, {})) == cand, because cand already satisfies the gap rule
+  }
+  *result = A;
+  return nA;
+}
+
+// remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel
+template <bool GLOBAL>
+__device__ void clip_and_emit(const SeedParams &p, uint32_t read, uint32_t strand, uint32_t L, const uint64_t *list,
+                              uint32_t n, uint64_t *tmp, unsigned long long &cand_sum) {
+  const uint32_t ln = lane_id();
+  const uint64_t lt_mask = (1ull << ln) - 1ull;
+  uint32_t kept = 0;
+  for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+    uint32_t i = i0 + ln;
+    bool ok = false;
+    uint64_t x = 0;
+    if (i < n) {
+      x = list[i];
+      uint32_t seq = (uint32_t)(x >> 32), pos = (uint32_t)x;
+      uint32_t slen = p.seq_len[seq];
+      ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+    }
+    uint64_t m = __ballot(ok);
+    uint32_t pos = kept + __popcll(m & lt_mask);
+    if (ok) tmp[pos] = x - (uint64_t)p.e;  // kept <= n <= capacity of tmp
+    kept += __popcll(m);
+  }
+  uint32_t base = 0;
+  if (kept > 0) {
+    if (ln == 0) base = atomicAdd(&p.ctr[0], kept);
+    base = bcast0(base);
+    if ((unsigned long long)base + kept > p.cand_cap) {
+      if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+    } else {
+      wave_sync<GLOBAL>();
+      for (uint32_t i = ln; i < kept; i += kWave) {
+        p.cand[base + i] = tmp[i];
+        p.cand_meta[base + i] = read * 2u + strand;
+      }
+    }
+  }
+  if (ln == 0) {
+    p.cand_begin[read * 2u + strand] = base;
+    p.cand_count[read * 2u + strand] = kept;
+  }
+  cand_sum += kept;
+}
+
+// ---------------------------------------------------------------------------
+// seed + filter kernel: one wave per read, grid-stride over the batch
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t ln = lane_id();
+  const uint32_t wave_in_block = threadIdx.x >> 6;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
+  uint32_t *pkw = (uint32_t *)(wbase + p.lay.pkw);
+  uint32_t *nkw = (uint32_t *)(wbase + p.lay.nkw);
+  uint2 *sf = (uint2 *)(wbase + p.lay.sf);
+  uint32_t *dp_rows = (uint32_t *)(wbase + p.lay.dp_rows);
+  uint32_t *dp_bits = (uint32_t *)(wbase + p.lay.dp_bits);
+  Picked *picked = (Picked *)(wbase + p.lay.picked);
+  uint32_t *rb = (uint32_t *)(wbase + p.lay.rb);
+  Bufs lds;
+  lds.X = (uint64_t *)(wbase + p.lay.X);
+  lds.F = (uint64_t *)(wbase + p.lay.F);
+  lds.A = (uint64_t *)(wbase + p.lay.A);
+  lds.B = (uint64_t *)(wbase + p.lay.B);
+  lds.xcap = p.lay.xcap, lds.fcap = p.lay.fcap, lds.ccap = p.lay.ccap;
+
+  const int k = p.k, step = p.step, R = p.R, lg = p.lg;
+  const uint32_t hash_mask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+  const uint32_t smax = p.lay.smax, cmax = p.lay.cmax, cw = p.lay.cw;
+  unsigned long long pre_sum = 0, cand_sum = 0;
+
+  const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
+  const uint32_t n_waves = gridDim.x * waves_per_block;
+
+  for (uint32_t read = wave_global; read < p.n_reads; read += n_waves) {
+    const uint64_t off = p.read_off[read];
+    const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
+    const uint8_t *seq = p.bases + off;
+    const int S = (int)L - k + 1;  // num_seeds_in_read
+
+    // ---- gates (src/filter.c:161-172) + the (L,e,a) shapes on which the reference DP is undefined ----
+    bool shape_ok = S > 0 && R <= S / step;
+    if (shape_ok) {
+      int g_min = (S - (step - 1)) / step;
+      shape_ok = g_min - R * lg + 2 >= 2;
+    }
+    if (!shape_ok || (uint32_t)S > smax) {
+      // (S > smax cannot happen: the host sizes the layout from the longest read of the batch)
+      if (ln < 2) {
+        p.cand_begin[read * 2u + ln] = 0;
+        p.cand_count[read * 2u + ln] = 0;
+      }
+      continue;
+    }
+
+    // ---- encode: lane handles bases 4*lane.. (+256 per round); 2 bits per base, first base in the top bits ----
+    uint32_t n_fwd_amb = 0, n_rev_amb = 0;
+    {
+      const uint32_t n_words = (L + 15u) / 16u + 2u;
+      for (uint32_t w = ln; w < n_words; w += kWave) {
+        pkw[w] = 0;
+        nkw[w] = 0;
+      }
+      wave_sync_lds();
+      uint8_t *pkb = (uint8_t *)pkw, *nkb = (uint8_t *)nkw;
+      for (uint32_t b0 = 0; b0 < L; b0 += 256u) {
+        uint32_t idx = b0 + 4u * ln;
+        if (idx < L) {
+          uint32_t pv = 0, nv = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t c = 0, isn = 0;
+            if (idx + q < L) {
+              uint32_t code = base_code(seq[idx + q]);
+              isn = code >> 2;
+              c = code & 3u & (isn - 1u);  // N -> A (src/utils.h:92)
+              // hash_all_seeds_in_sequence counts ambiguous bases at offsets >= k only (src/utils.h:108-114);
+              // on the reverse strand offset L-1-i >= k
+              n_fwd_amb += isn & (uint32_t)(idx + q >= (uint32_t)k);
+              n_rev_amb += isn & (uint32_t)(L - 1u - (idx + q) >= (uint32_t)k);
+            }
+            pv = (pv << 2) | c;
+            nv = (nv << 2) | (isn * 3u);
+          }
+          uint32_t byte_addr = (idx >> 4) * 4u + (3u - ((idx >> 2) & 3u));  // big-endian inside each dword
+          pkb[byte_addr] = (uint8_t)pv;
+          nkb[byte_addr] = (uint8_t)nv;
+        }
+      }
+      if (__any(n_fwd_amb | n_rev_amb)) {
+        for (int d = 32; d >= 1; d >>= 1) {
+          n_fwd_amb += __shfl_xor(n_fwd_amb, d);
+          n_rev_amb += __shfl_xor(n_rev_amb, d);
+        }
+      }
+      wave_sync_lds();
+    }
+    const bool strand_ok[2] = {n_fwd_amb <= (uint32_t)p.e, n_rev_amb <= (uint32_t)p.e};  // src/filter.c:180-182
+
+    // ---- hashes + CSR lookups (src/utils.h:101-117, src/index.h:22-28); lane j owns seed j of the forward
+    //      strand and seed S-1-j of the reverse strand (the reverse complement of the same k-mer) ----
+    for (int j0 = 0; j0 < S; j0 += kWave) {
+      int j = j0 + (int)ln;
+      if (j < S) {
+        uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
+        uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
+        uint64_t nw = ((uint64_t)nkw[w] << 32) | nkw[w + 1];
+        uint32_t hf = (uint32_t)(pw >> (64 - 2 * k - sh)) & hash_mask;
+        uint32_t nm = (uint32_t)(nw >> (64 - 2 * k - sh)) & hash_mask;
+        uint32_t hr = reverse_pairs((~hf) & ~nm & hash_mask, k);
+        if (strand_ok[0]) {
+          uint32_t lo = p.lookup[hf], hi = p.lookup[hf + 1];
+          sf[j] = make_uint2(lo, hi - lo);
+        }
+        if (strand_ok[1]) {
+          uint32_t lo = p.lookup[hr], hi = p.lookup[hr + 1];
+          sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(lo, hi - lo);
+        }
+      }
+    }
+    wave_sync_lds();
+
+    // ---- seed selection DP (src/filter.c:3-43), one lane per (strand, phase group) ----
+    uint32_t pre_g = 0;
+    if (ln < 2u * (uint32_t)step && strand_ok[ln / (uint32_t)step]) {
+      const uint32_t strand = ln / (uint32_t)step, si = ln % (uint32_t)step;
+      const int G = (S - (int)si) / step;
+      const int C = G - R * lg + 2;  // num_columns
+      uint32_t *rows = dp_rows + (size_t)ln * 2u * cmax;
+      uint32_t *bits = dp_bits + (size_t)ln * (uint32_t)R * cw;
+      const uint2 *sfs = sf + strand * smax;
+      for (int c = 1; c < C; ++c) rows[c] = 0;  // M[0][c] = 0
+      uint32_t left = p.inf32;
+      for (int row = 1; row <= R; ++row) {
+        const uint32_t *prev = rows + (size_t)((row - 1) & 1) * cmax;
+        uint32_t *cur = rows + (size_t)(row & 1) * cmax;
+        left = p.inf32;  // M[row][0]
+        uint32_t acc = 0;
+        for (int col = 1; col < C; ++col) {
+          uint32_t pos = (uint32_t)(col + (row - 1) * lg - 1);
+          uint32_t with_new = prev[col] + sfs[si + (uint32_t)step * pos].y;
+          bool take = with_new < left;  // strict: ties go horizontal (src/filter.c:20)
+          left = take ? with_new : left;
+          cur[col] = left;
+          acc |= (uint32_t)take << (col & 31);
+          if ((col & 31) == 31 || col == C - 1) {
+            bits[(uint32_t)(row - 1) * cw + ((uint32_t)col >> 5)] = acc;
+            acc = 0;
+          }
+        }
+      }
+      pre_g = left;  // M[R][C-1]
+      // traceback, right to left (src/filter.c:30-41); seeds never reached stay all-zero (UB in reference)
+      Picked *out = picked + (size_t)ln * (uint32_t)R;
+      for (int t = 0; t < R; ++t) out[t] = Picked{0, 0, 0, 0};
+      int r = R, c = C - 1, n_out = 0;
+      while (r > 0 && c > 0) {
+        uint32_t bit = (bits[(uint32_t)(r - 1) * cw + ((uint32_t)c >> 5)] >> (c & 31)) & 1u;
+        if (bit) {
+          uint32_t sidx = si + (uint32_t)step * (uint32_t)(c + (r - 1) * lg - 1);
+          uint2 s = sfs[sidx];
+          out[n_out++] = Picked{sidx, s.x, s.y, 0};
+          --r;
+        } else {
+          --c;
+        }
+      }
+      // qsort(compare_seed) (src/filter.c:204): stable by ascending frequency
+      for (int i = 1; i < R; ++i) {
+        Picked t = out[i];
+        int j = i;
+        while (j > 0 && t.freq < out[j - 1].freq) {
+          out[j] = out[j - 1];
+          --j;
+        }
+        out[j] = t;
+      }
+    }
+    wave_sync_lds();
+
+    // ---- per strand: lists, filter, de-dup, clip, emit ----
+    for (uint32_t strand = 0; strand < 2; ++strand) {
+      if (!strand_ok[strand]) {
+        if (ln == 0) {
+          p.cand_begin[read * 2u + strand] = 0;
+          p.cand_count[read * 2u + strand] = 0;
+        }
+        continue;
+      }
+      // per-strand pre-filter count: uint32 sum of the groups' M[R][C-1] (src/filter.c:202)
+      uint32_t pre = 0, pre_max = 0;
+      unsigned long long pre_wide = 0;
+      for (int si = 0; si < step; ++si) {
+        uint32_t v = __shfl(pre_g, (int)(strand * (uint32_t)step) + si);
+        pre += v;
+        pre_wide += v;
+        pre_max = v > pre_max ? v : pre_max;
+      }
+      pre_sum += pre;
+      const Picked *pk = picked + (size_t)strand * (uint32_t)step * (uint32_t)R;
+      uint64_t *list = nullptr;
+      uint32_t n = strand_lists<false>(p, pk, rb, lds, &list);
+      if (n < 0xFFFFFFFEu) {
+        clip_and_emit<false>(p, read, strand, L, list, n, list == lds.A ? lds.B : lds.A, cand_sum);
+      } else if (n == 0xFFFFFFFEu) {
+        if (ln == 0) atomicOr(&p.ctr[1], kFlagTooLarge);
+      } else {
+        // lists do not fit in LDS: same code over a slice of the global arena.
+        // staged <= max group total, survivors <= staged, candidates <= sum of the groups
+        unsigned long long want = 2ull * pre_max + 2ull * pre_wide + 8ull;
+        unsigned long long base = 0;
+        if (ln == 0) {
+          base = atomicAdd(&p.arena_ctr[0], want);
+          atomicAdd(&p.arena_ctr[1], want);
+        }
+        base = ((unsigned long long)bcast0((uint32_t)(base >> 32)) << 32) | bcast0((uint32_t)base);
+        if (base + want > p.arena_cap) {
+          if (ln == 0) atomicOr(&p.ctr[1], kFlagArenaOverflow);
+          if (ln == 0) {
+            p.cand_begin[read * 2u + strand] = 0;
+            p.cand_count[read * 2u + strand] = 0;
+          }
+        } else {
+          Bufs g;
+          g.X = p.arena + base;
+          g.F = g.X + pre_max + 2;
+          g.A = g.F + pre_max + 2;
+          g.B = g.A + pre_wide + 2;
+          g.xcap = pre_max + 1u, g.fcap = pre_max + 1u;
+          g.ccap = pre_wide > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pre_wide + 1u;
+          uint32_t n2 = strand_lists<true>(p, pk, rb, g, &list);
+          if (n2 < 0xFFFFFFFEu) {
+            clip_and_emit<true>(p, read, strand, L, list, n2, list == g.A ? g.B : g.A, cand_sum);
+          } else {
+            if (ln == 0) atomicOr(&p.ctr[1], kFlagTooLarge);
+          }
+        }
+      }
+      wave_sync_lds();
+    }
+  }
+  if (ln == 0) {
+    if (pre_sum) atomicAdd(&p.stats[0], pre_sum);
+    if (cand_sum) atomicAdd(&p.stats[1], cand_sum);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// verification: one lane per candidate (src/align.c:4-51, 102-277)
+// ---------------------------------------------------------------------------
+struct VerifyParams {
+  const uint8_t *bases;
+  const uint64_t *read_off;
+  const uint8_t *ref_codes;  // base codes 0..4, all sequences concatenated
+  const uint64_t *seq_off;
+  const uint64_t *cand;
+  const uint32_t *cand_meta;
+  const uint32_t *cand_begin;
+  const uint32_t *cand_count;
+  const uint32_t *ctr;  // [0] = number of candidates produced by the seed kernel
+  uint32_t cand_cap;
+  int32_t e;
+  uint8_t *ed;
+  int16_t *end;
+  uint32_t *n_map;             // per read: accepted mappings
+  unsigned long long *stats;   // [2] mappings, [3] mapped reads
+};
+
+__global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
+  const uint32_t total = min(p.ctr[0], p.cand_cap);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const int e = p.e;
+  const uint32_t top = 1u << (2 * e);
+  const uint32_t band = (top << 1) - 1u;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < total; i0 += stride) {
+    uint32_t i = i0 + threadIdx.x;
+    bool active = i < total;
+    bool accepted = false, first_of_read = false;
+    if (active) {
+      const uint32_t meta = p.cand_meta[i];
+      const uint32_t read = meta >> 1, strand = meta & 1u;
+      const uint64_t c = p.cand[i];
+      const uint8_t *pat = p.ref_codes + p.seq_off[(uint32_t)(c >> 32)] + (uint32_t)c;
+      const uint64_t off = p.read_off[read];
+      const int L = (int)(p.read_off[read + 1] - off);
+      const uint8_t *rd = p.bases + off;
+      // verify_candidates sends full groups of 8 through the 16-bit SSE lanes and the remainder through the
+      // 32-bit scalar routine (src/align.c:12-13); the word width is the only difference between the two.
+      const uint32_t rank = i - p.cand_begin[meta];
+      const uint32_t n_here = p.cand_count[meta];
+      const uint32_t wm = rank < (n_here & ~7u) ? 0xFFFFu : 0xFFFFFFFFu;
+      // bit planes of the pattern window: bit j of Bq = bit q of code(pattern[i + j])
+      uint32_t B0 = 0, B1 = 0, B2 = 0;
+      for (int j = 0; j < 2 * e; ++j) {
+        uint32_t pc = pat[j];
+        B0 |= (pc & 1u) << j;
+        B1 |= ((pc >> 1) & 1u) << j;
+        B2 |= ((pc >> 2) & 1u) << j;
+      }
+      uint32_t VP = 0, VN = 0;
+      int score = 0;
+      bool rejected = false;
+      for (int col = 0; col < L; ++col) {
+        uint32_t pc = pat[col + 2 * e];
+        B0 |= (pc & 1u) << (2 * e);
+        B1 |= ((pc >> 1) & 1u) << (2 * e);
+        B2 |= ((pc >> 2) & 1u) << (2 * e);
+        uint32_t tc;
+        if (strand == 0) {
+          tc = base_code(rd[col]);
+        } else {  // prepare_negative_sequence_at (src/sequence_batch.h:90-98)
+          tc = base_code(rd[L - 1 - col]);
+          tc = tc < 4u ? 3u - tc : 4u;
+        }
+        uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
+        uint32_t eq = ~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)) & band;  // Peq[text[col]]
+        uint32_t X = eq | VN;
+        uint32_t D0 = ((((X & VP) + VP) ^ VP) | X) & wm;
+        uint32_t HN = VP & D0;
+        uint32_t HP = (VN | ~(VP | D0)) & wm;
+        X = D0 >> 1;
+        VN = X & HP;
+        VP = (HN | ~(X | HP)) & wm;
+        score += 1 - (int)(D0 & 1u);
+        if (score > 3 * e) {  // src/align.c:128-130; the SSE lanes run on but end up rejected as well
+          rejected = true;
+          break;
+        }
+        B0 >>= 1;
+        B1 >>= 1;
+        B2 >>= 1;
+      }
+      int best = score, endp = L - 1;
+      if (!rejected) {
+        for (int j = 0; j < 2 * e; ++j) {  // first strict minimum (src/align.c:135-146)
+          score += (int)((VP >> j) & 1u) - (int)((VN >> j) & 1u);
+          if (score < best) {
+            best = score;
+            endp = L + j;
+          }
+        }
+      }
+      accepted = !rejected && best <= e;
+      p.ed[i] = accepted ? (uint8_t)best : (uint8_t)0xFF;
+      p.end[i] = accepted ? (int16_t)endp : (int16_t)0;
+      if (accepted) first_of_read = atomicAdd(&p.n_map[read], 1u) == 0u;
+    }
+    uint64_t m_acc = __ballot(accepted), m_first = __ballot(first_of_read);
+    if (lane_id() == 0) {
+      if (m_acc) atomicAdd(&p.stats[2], (unsigned long long)__popcll(m_acc));
+      if (m_first) atomicAdd(&p.stats[3], (unsigned long long)__popcll(m_first));
+    }
+  }
+}
+
+// reference characters -> codes, in place (src/utils.h:72)
+__global__ void ref_encode_kernel(uint8_t *text, uint64_t n) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    text[i] = (uint8_t)base_code(text[i]);
+}
+
+}  // namespace femk

@@ -1,0 +1,225 @@
+"""ctypes binding of libfemhip.so (include/fem_hip.h).  One Device == one fem_dev handle == one GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HIP = None
+
+#: every symbol include/fem_hip.h declares
+ABI_SYMBOLS = [
+    "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
+    "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index",
+    "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
+    "fem_dev_stage_reads", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
+    "fem_dev_allreduce_stats",
+]
+
+
+class FemError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """fem_params == FEMArgs of the reference (src/utils.h:63-70); map always uses k=12, step=3."""
+    _fields_ = [("k", C.c_int32), ("step", C.c_int32), ("e", C.c_int32), ("a", C.c_int32)]
+
+
+class _ReadBatch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64)]
+
+
+class _BatchResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_candidates", C.c_uint64), ("cand_begin", C.c_void_p),
+                ("cand_count", C.c_void_p), ("cand", C.c_void_p), ("ed", C.c_void_p), ("end", C.c_void_p),
+                ("stats", C.c_uint64 * 5)]
+
+
+def hip_library_path():
+    return os.path.join(_HERE, "csrc", "libfemhip.so")
+
+
+def load_hip():
+    """Load libfemhip.so; raise loudly if it has not been built (no fallback of any kind)."""
+    global _HIP
+    if _HIP is not None:
+        return _HIP
+    path = hip_library_path()
+    if not os.path.exists(path):
+        raise FemError("libfemhip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C fem_amd/csrc`" % path)
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    L.fem_dev_open.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fem_dev_close.argtypes = [vp]
+    L.fem_strerror.restype = C.c_char_p
+    L.fem_strerror.argtypes = [C.c_int]
+    L.fem_dev_last_error.restype = C.c_char_p
+    L.fem_dev_last_error.argtypes = [vp]
+    L.fem_dev_limits.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
+    L.fem_dev_upload_index.argtypes = [vp, i32, i32, vp, u64, vp, u64]
+    L.fem_dev_upload_reference.argtypes = [vp, C.c_uint32, C.POINTER(vp), vp]
+    L.fem_dev_build_index.argtypes = [vp, i32, i32, vp, vp, u64, C.POINTER(u64)]
+    L.fem_dev_map_batch_submit.argtypes = [vp, C.c_int, C.POINTER(Params), C.POINTER(_ReadBatch)]
+    L.fem_dev_map_batch_wait.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
+    L.fem_dev_stage_reads.argtypes = [vp, C.c_int, C.POINTER(_ReadBatch)]
+    L.fem_dev_map_staged.argtypes = [vp, C.c_int, C.POINTER(Params)]
+    L.fem_dev_sync.argtypes = [vp, C.c_int]
+    L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
+    L.fem_dev_fetch.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
+    L.fem_dev_set_timing.argtypes = [vp, C.c_int]
+    L.fem_dev_reset_timing.argtypes = [vp]
+    L.fem_dev_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.fem_dev_copy_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
+    L.fem_dev_allreduce_stats.argtypes = [C.POINTER(vp), C.c_int, vp]
+    _HIP = L
+    return L
+
+
+def _copy(ptr, n, dtype):
+    n = int(n)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class BatchResult:
+    """Host copy of fem_batch_result."""
+
+    def __init__(self, r):
+        n2 = 2 * int(r.n_reads)
+        nc = int(r.n_candidates)
+        self.n_reads = int(r.n_reads)
+        self.cand_begin = _copy(r.cand_begin, n2, np.uint32)
+        self.cand_count = _copy(r.cand_count, n2, np.uint32)
+        self.cand = _copy(r.cand, nc, np.uint64)
+        self.ed = _copy(r.ed, nc, np.uint8)
+        self.end = _copy(r.end, nc, np.int16)
+        self.stats = np.array(list(r.stats), dtype=np.uint64)
+
+    def per_strand(self):
+        """Candidates regrouped in (read, strand) order: offsets[2n+1], cand, ed, end — the layout the oracle uses."""
+        cnt = self.cand_count.astype(np.int64)
+        off = np.zeros(len(cnt) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(cnt)
+        total = int(off[-1])
+        idx = np.zeros(total, dtype=np.int64)
+        if total:
+            starts = np.repeat(self.cand_begin.astype(np.int64) - off[:-1].astype(np.int64), cnt)
+            idx = np.arange(total, dtype=np.int64) + starts
+        return off, self.cand[idx], self.ed[idx], self.end[idx]
+
+
+class Device:
+    """One GPU: resident index + reference, batches mapped through slots."""
+
+    def __init__(self, device=0):
+        self._L = load_hip()
+        h = C.c_void_p()
+        rc = self._L.fem_dev_open(device, C.byref(h))
+        if rc != 0:
+            raise FemError("fem_dev_open(%d) failed: %s — the HIP path needs a GPU, there is no CPU fallback"
+                           % (device, self._L.fem_strerror(rc).decode()))
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._L.fem_dev_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FemError("%s: %s" % (self._L.fem_strerror(rc).decode(),
+                                       self._L.fem_dev_last_error(self._h).decode()))
+
+    def limits(self):
+        m, s = C.c_uint32(), C.c_int32()
+        self._check(self._L.fem_dev_limits(self._h, C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+    def upload_index(self, k, step, lookup, occ, n_occ=None):
+        lookup = np.ascontiguousarray(lookup, dtype=np.uint32)
+        occ = np.ascontiguousarray(occ, dtype=np.uint64)
+        n_occ = len(occ) if n_occ is None else n_occ
+        self._check(self._L.fem_dev_upload_index(self._h, k, step, lookup.ctypes.data, len(lookup), occ.ctypes.data,
+                                                 n_occ))
+
+    def upload_reference(self, seqs):
+        """seqs: list of bytes / uint8 arrays (raw FASTA characters)."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, np.uint8)
+                for s in seqs]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        lens = np.array([len(a) for a in arrs], dtype=np.uint32)
+        self._check(self._L.fem_dev_upload_reference(self._h, len(arrs), ptrs, lens.ctypes.data))
+
+    def build_index(self, k=12, step=3, fetch=True):
+        n = C.c_uint64()
+        self._check(self._L.fem_dev_build_index(self._h, k, step, None, None, 0, C.byref(n)))
+        if not fetch:
+            return int(n.value), None, None
+        lookup = np.zeros((1 << (2 * k)) + 1, dtype=np.uint32)
+        occ = np.zeros(max(int(n.value), 1), dtype=np.uint64)
+        self._check(self._L.fem_dev_build_index(self._h, k, step, lookup.ctypes.data, occ.ctypes.data, len(occ),
+                                                C.byref(n)))
+        return int(n.value), lookup, occ[:n.value]
+
+    @staticmethod
+    def _batch(bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return _ReadBatch(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), (bases, offsets)
+
+    def stage_reads(self, bases, offsets, slot=0):
+        b, keep = self._batch(bases, offsets)
+        self._check(self._L.fem_dev_stage_reads(self._h, slot, C.byref(b)))
+
+    def map_staged(self, e=3, a=1, k=12, step=3, slot=0):
+        p = Params(k, step, e, a)
+        self._check(self._L.fem_dev_map_staged(self._h, slot, C.byref(p)))
+
+    def sync(self, slot=0):
+        self._check(self._L.fem_dev_sync(self._h, slot))
+
+    def fetch_stats(self, slot=0):
+        st = np.zeros(5, dtype=np.uint64)
+        self._check(self._L.fem_dev_fetch_stats(self._h, slot, st.ctypes.data))
+        return st
+
+    def fetch(self, slot=0):
+        r = _BatchResult()
+        self._check(self._L.fem_dev_fetch(self._h, slot, C.byref(r)))
+        return BatchResult(r)
+
+    def map_batch(self, bases, offsets, e=3, a=1, k=12, step=3, slot=0):
+        b, keep = self._batch(bases, offsets)
+        p = Params(k, step, e, a)
+        self._check(self._L.fem_dev_map_batch_submit(self._h, slot, C.byref(p), C.byref(b)))
+        r = _BatchResult()
+        self._check(self._L.fem_dev_map_batch_wait(self._h, slot, C.byref(r)))
+        return BatchResult(r)
+
+    def set_timing(self, on=True):
+        self._check(self._L.fem_dev_set_timing(self._h, int(on)))
+
+    def reset_timing(self):
+        self._check(self._L.fem_dev_reset_timing(self._h))
+
+    def kernel_time(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._L.fem_dev_kernel_time(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        self._check(self._L.fem_dev_copy_bandwidth(self._h, nbytes, iters, C.byref(g)))
+        return g.value

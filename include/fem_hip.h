@@ -1,0 +1,138 @@
+/*
+ * fem_hip.h — C ABI of libfemhip.so: FEM's per-read mapping hot path on MI355X (gfx950).
+ *
+ * The reference (haowenz/FEM v0.2) has no plugin/FFI layer; the seam this
+ * library replaces is the per-read call sequence inside
+ * single_end_read_mapping_thread (src/map.c:27-55):
+ *
+ *     generate_group_seeding_candidates()   src/filter.h:9   (src/filter.c:146-223)
+ *     verify_candidates()                   src/align.h:13   (src/align.c:4-51)
+ *     MappingStats accumulation             src/map.c:25,32-33,37,43-44,48,51
+ *
+ * called once per read and strand.  Here the same work is done one BATCH at a
+ * time: the index (src/index.h:7-14) and the reference text are uploaded once
+ * and stay resident in HBM, reads are handed over as one contiguous byte
+ * array + offsets, and the per-candidate verification outcome comes back as
+ * flat arrays from which the host rebuilds the reference's Mapping lists
+ * (src/utils.h:44-49) in the reference's order.
+ *
+ * Plain C types only; no exits or aborts: every call returns 0 (FEM_OK) or a
+ * negative fem_status, and fem_dev_last_error() holds a message.
+ * A handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef FEM_HIP_H_
+#define FEM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum fem_status {
+  FEM_OK = 0,
+  FEM_ERR_INVALID = -1,     /* bad argument (NULL, out-of-range parameter, bad slot) */
+  FEM_ERR_HIP = -2,         /* a HIP runtime call failed; see fem_dev_last_error() */
+  FEM_ERR_NOMEM = -3,       /* host or device allocation failed */
+  FEM_ERR_STATE = -4,       /* call order violated (e.g. map before index upload) */
+  FEM_ERR_UNSUPPORTED = -5, /* input outside what the device path handles (see fem_dev_limits) */
+  FEM_ERR_RCCL = -6         /* an RCCL call failed */
+};
+
+/* FEMArgs (src/utils.h:63-70) minus threads/seeding_method.  `FEM map` always
+ * runs k=12, step=3 (src/FEM_map.c:67-68); 0<=e<=7, 0<=a<=2 (src/FEM_map.c:30,38). */
+typedef struct {
+  int32_t k;
+  int32_t step;
+  int32_t e; /* error_threshold */
+  int32_t a; /* num_additional_qgrams */
+} fem_params;
+
+/* One batch of reads: what a SequenceBatch (src/sequence_batch.h:15-24) holds
+ * for the hot path — the raw read characters, concatenated, and n_reads+1 offsets. */
+typedef struct {
+  const char *bases;
+  const uint64_t *offsets;
+  uint64_t n_reads;
+} fem_read_batch;
+
+/* Outcome of one batch.  Pointers refer to pinned host memory owned by the
+ * handle and stay valid until the slot is staged or mapped again.
+ * Slot 2*i+d describes strand d (0 = POSITIVE_DIRECTION, 1 = NEGATIVE_DIRECTION,
+ * src/utils.h:21-22) of read i: its candidates (src/filter.c:221-222, ascending,
+ * already shifted by -e) are cand[cand_begin[s] .. cand_begin[s]+cand_count[s]),
+ * and ed[]/end[] hold banded_edit_distance's result for each (src/align.c:102-147;
+ * ed == 0xFF when the candidate is rejected, i.e. the reference would not push
+ * a Mapping, src/align.c:22,40). */
+typedef struct {
+  uint64_t n_reads;
+  uint64_t n_candidates;
+  const uint32_t *cand_begin; /* 2*n_reads */
+  const uint32_t *cand_count; /* 2*n_reads */
+  const uint64_t *cand;       /* n_candidates: seq<<32 | (pos - e) */
+  const uint8_t *ed;          /* n_candidates */
+  const int16_t *end;         /* n_candidates: Mapping.end_position_offset */
+  /* MappingStats (src/utils.h:55-61): reads, mapped reads, candidates before the
+   * additional q-gram filter, candidates, mappings */
+  uint64_t stats[5];
+} fem_batch_result;
+
+typedef struct fem_dev fem_dev;
+
+/* ---- lifetime ---- */
+int fem_dev_open(int device, fem_dev **out);
+int fem_dev_close(fem_dev *h);
+const char *fem_strerror(int rc);
+const char *fem_dev_last_error(const fem_dev *h);
+/* Limits of the device path: max read length, number of batch slots. */
+int fem_dev_limits(const fem_dev *h, uint32_t *max_read_len, int32_t *n_slots);
+
+/* ---- resident data (replaces load_index / the reference SequenceBatch;
+ *      src/index.c:100-131, src/FEM_map.c:135-143) ---- */
+/* lookup: 4^k+1 prefix sums; occ: seq<<32|pos, ascending in each bucket — byte
+ * for byte the arrays of the index file (src/index.c:133-168). */
+int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lookup, uint64_t n_lookup,
+                         const uint64_t *occ, uint64_t n_occ);
+/* seq[i] points at seq_len[i] raw FASTA characters (any case; non-ACGT = N). */
+int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len);
+/* Build the index on the device from the uploaded reference (construct_index,
+ * src/index.c:57-98) and keep it resident.  If lookup_out/occ_out are non-NULL
+ * the arrays are also copied back (occ_cap entries available); *n_occ_out is
+ * always set.  The result is byte-identical to the reference's index arrays. */
+int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_out, uint64_t *occ_out,
+                        uint64_t occ_cap, uint64_t *n_occ_out);
+
+/* ---- mapping one batch (replaces the loop body src/map.c:27-49) ---- */
+/* submit = stage + map + start of the copy back; wait = finish + result.
+ * Two (or more) slots let the transfer of one batch overlap the kernels of another. */
+int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fem_read_batch *reads);
+int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out);
+
+/* The same in separate phases, for callers that keep reads resident in HBM
+ * (bench.py measures fem_dev_map_staged with the inputs already on the device). */
+int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads); /* host -> HBM */
+int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p);          /* kernels only, asynchronous */
+int fem_dev_sync(fem_dev *h, int slot);                                     /* wait; re-runs on scratch overflow */
+int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* sync + the five counters */
+int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);             /* sync + full result to the host */
+
+/* ---- measurement ---- */
+/* With timing on, every kernel launch is bracketed by HIP events on the stream
+ * it is launched on; fem_dev_kernel_time reports their sum and count since
+ * the last reset.  kernel: 0 = seed/filter kernel, 1 = verify kernel. */
+int fem_dev_set_timing(fem_dev *h, int on);
+int fem_dev_reset_timing(fem_dev *h);
+int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);
+/* Achieved device-to-device copy bandwidth in GB/s over `bytes` (roofline cross-check). */
+int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s);
+
+/* ---- multi-GPU (replaces the thread reduction src/FEM_map.c:200-212) ---- */
+/* Sums the five MappingStats counters of n handles (one per GPU of this
+ * process) with one RCCL all-reduce; stats is n x 5, reduced in place. */
+int fem_dev_allreduce_stats(fem_dev *const *h, int n, uint64_t *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEM_HIP_H_ */

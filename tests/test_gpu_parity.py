@@ -1,0 +1,97 @@
+"""HIP path vs the CPU oracle, bit for bit, through the C ABI (libfemhip.so).  Needs a GPU: -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from fem_amd import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def run_both(dev, seqs, reads, e, a=1, build_on_device=False):
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    batch = fo.ReadBatch(reads)
+    want = fo.map_reads(ref, idx, batch, e=e, a=a, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    dev.upload_reference(seqs)
+    if build_on_device:
+        n, lookup, occ = dev.build_index(12, 3)
+        assert n == idx.n_occ
+        assert np.array_equal(lookup, idx.lookup)
+        assert np.array_equal(occ, idx.occ[:n])
+    else:
+        dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    got = dev.map_batch(batch.bases, batch.off, e=e, a=a)
+    return want, got
+
+
+def assert_same(want, got):
+    off, cand, ed, end = got.per_strand()
+    assert np.array_equal(off, want.cand_off), "candidate counts per (read, strand)"
+    assert np.array_equal(cand, want.cands), "candidate locations"
+    assert np.array_equal(ed, want.v_ed), "edit distances / accept set"
+    assert np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF]), "end offsets"
+    assert np.array_equal(got.stats, want.stats), (got.stats, want.stats)
+
+
+def test_config1_random_reference(dev):
+    # BASELINE.json configs[0]: 1k synthetic 100 bp reads, e=3, 1 Mbp random reference, k=12 step=3
+    rng = np.random.default_rng(1)
+    seqs = [util.rand_seq(rng, 1_000_000)]
+    reads = util.make_reads(rng, seqs, 1000, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3, build_on_device=True)
+    assert want.stats[1] > 700
+    assert_same(want, got)
+
+
+@pytest.mark.parametrize("e,a,L", [(3, 1, 100), (7, 1, 150), (2, 1, 75), (0, 1, 64), (3, 2, 100), (3, 0, 100), (5, 1, 125)])
+def test_repeat_rich_multi_sequence(dev, e, a, L):
+    # many candidates per strand: full groups of 8 (16-bit Myers lanes), LDS overflow into the arena, N runs
+    rng = np.random.default_rng(10 * e + a + L)
+    seqs = util.repeat_rich_reference(rng, n_seq=3, unit_len=max(300, 2 * L), n_units=6, copies=60, spacer=200)
+    reads = util.make_reads(rng, seqs, 400, L, e, n_rate=0.003)
+    want, got = run_both(dev, seqs, reads, e=e, a=a, build_on_device=(e == 3 and a == 1))
+    assert_same(want, got)
+    if e > 0:
+        per_strand = np.diff(want.cand_off.astype(np.int64))
+        assert per_strand.max() >= 8, "fixture must reach the 8-lane path"
+
+
+def test_ragged_lengths_and_degenerate_reads(dev):
+    rng = np.random.default_rng(5)
+    seqs = [util.rand_seq(rng, 200_000), util.rand_seq(rng, 3000)]
+    reads = []
+    for L in (12, 20, 35, 59, 60, 61, 64, 99, 100, 101, 127, 128, 129, 200, 255, 256, 257, 300):
+        reads += util.make_reads(rng, seqs, 6, L, 2)
+    reads += [b"N" * 100, b"A" * 100, b"ACGT" * 25, b"acgt" * 25, reads[40].lower(), b"ACGTNNNN" * 12 + b"ACGT"]
+    # reads hanging over both ends of a sequence (range clip, src/filter.c:133-144)
+    reads += [seqs[1][:100], seqs[1][1:101], seqs[1][3:103], seqs[1][-100:], seqs[1][-103:-3], seqs[1][-104:-4]]
+    want, got = run_both(dev, seqs, reads, e=2)
+    assert_same(want, got)
+
+
+def test_empty_batch(dev):
+    rng = np.random.default_rng(6)
+    seqs = [util.rand_seq(rng, 5000)]
+    want, got = run_both(dev, seqs, [], e=3)
+    assert got.n_reads == 0 and len(got.cand) == 0
+    assert np.array_equal(got.stats, np.zeros(5, np.uint64))
+
+
+def test_poly_a_reads_take_the_arena_path(dev):
+    # one k-mer with a huge bucket: poly-A and N runs hash to 0 (src/utils.h:92)
+    rng = np.random.default_rng(8)
+    seqs = [util.rand_seq(rng, 3000) + b"A" * 9000 + util.rand_seq(rng, 3000) + b"N" * 3000 + util.rand_seq(rng, 2000)]
+    reads = [b"A" * 100, b"A" * 50 + util.rand_seq(rng, 50), seqs[0][2950:3050], seqs[0][11990:12090]]
+    reads += util.make_reads(rng, seqs, 50, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert_same(want, got)
+    assert np.diff(want.cand_off.astype(np.int64)).max() > 128
