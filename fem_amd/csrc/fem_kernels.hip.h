@@ -157,6 +157,7 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
     // ---- merge_candidate_locations (src/filter.c:80-116) as a set: stage the R shifted runs ----
     uint32_t n = 0;
     bool too_big = false;
+    if (ln == 0) rb[0] = 0, fb[0] = 0;
     for (int t = 0; t < R; ++t) {
       const uint32_t start = pk[t].start, lo = pk[t].lo, freq = pk[t].freq;
       uint64_t max_u = 0;
@@ -195,7 +196,6 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
       }
       if (ln == 0) rb[t + 1] = n;
     }
-    if (ln == 0) rb[0] = 0;
     if (too_big) return 0xFFFFFFFEu;
     if (n > b.xcap) return 0xFFFFFFFFu;
 
@@ -241,7 +241,6 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
         }
         if (ln == 0) fb[t + 1] = nF;
       }
-      if (ln == 0) fb[0] = 0;
       if (nF > b.fcap) return 0xFFFFFFFFu;
     }
 

@@ -86,12 +86,31 @@ def test_empty_batch(dev):
     assert np.array_equal(got.stats, np.zeros(5, np.uint64))
 
 
-def test_poly_a_reads_take_the_arena_path(dev):
-    # one k-mer with a huge bucket: poly-A and N runs hash to 0 (src/utils.h:92)
+def test_poly_a_and_n_runs(dev):
+    # one k-mer with a huge bucket: poly-A and N runs hash to 0 (src/utils.h:92).  With that bucket holding most
+    # of the index the DP runs into its +inf column (src/filter.c:9); both sides then pick the same (zeroed) seeds.
     rng = np.random.default_rng(8)
     seqs = [util.rand_seq(rng, 3000) + b"A" * 9000 + util.rand_seq(rng, 3000) + b"N" * 3000 + util.rand_seq(rng, 2000)]
     reads = [b"A" * 100, b"A" * 50 + util.rand_seq(rng, 50), seqs[0][2950:3050], seqs[0][11990:12090]]
     reads += util.make_reads(rng, seqs, 50, 100, 3)
     want, got = run_both(dev, seqs, reads, e=3)
     assert_same(want, got)
-    assert np.diff(want.cand_off.astype(np.int64)).max() > 128
+
+
+def test_high_copy_repeat_takes_the_arena_path(dev):
+    # a 150 bp unit present ~1500 times: thousands of staged occurrences and candidates per strand, far beyond
+    # the LDS staging capacity -> the same code runs over the global arena (and the buffers grow + re-run)
+    rng = np.random.default_rng(9)
+    unit = util.rand_seq(rng, 150)
+    parts = [util.rand_seq(rng, 100_000)]
+    for _ in range(1500):
+        parts.append(util.mutate(rng, unit, int(rng.integers(0, 2))))
+        parts.append(util.rand_seq(rng, int(rng.integers(10, 50))))
+    seqs = [b"".join(parts), util.rand_seq(rng, 50_000)]
+    reads = [util.mutate(rng, unit[s:s + 103], int(rng.integers(0, 4)))[:100] for s in rng.integers(0, 45, size=24)]
+    reads = [r if rng.random() < 0.5 else util.revcomp(r) for r in reads]
+    reads += util.make_reads(rng, seqs, 40, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert np.diff(want.cand_off.astype(np.int64)).max() > 600
+    assert want.pre.max() > 3 * 512
+    assert_same(want, got)
