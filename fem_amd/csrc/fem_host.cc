@@ -1,0 +1,875 @@
+// fem_host.cc — host side of the drop-in (see fem_host.h).  C++17, OpenMP for the per-read loops.
+#include "fem_host.h"
+
+#include <omp.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// encodings (reference src/utils.h:72-81)
+// ------------------------------------------------------------------------------------------------
+struct CodeTable {
+  uint8_t t[256];
+  constexpr CodeTable() : t() {
+    for (int i = 0; i < 256; ++i) t[i] = 4;
+    t['A'] = t['a'] = 0;
+    t['C'] = t['c'] = 1;
+    t['G'] = t['g'] = 2;
+    t['T'] = t['t'] = 3;
+  }
+};
+constexpr CodeTable kCode;
+inline uint8_t code_of(char c) { return kCode.t[(uint8_t)c]; }
+constexpr char kCodeChar[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
+
+template <typename T>
+T *dup_vec(const std::vector<T> &v) {
+  T *p = (T *)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequence files: a FASTA/FASTQ reader with kseq's record rules (reference src/kseq.h:185-226)
+// ------------------------------------------------------------------------------------------------
+class ByteStream {
+ public:
+  explicit ByteStream(gzFile f) : f_(f), buf_(1u << 20) {}
+  int get() {  // next byte, -1 at end of file, -3 on a read error
+    if (pos_ >= end_) {
+      if (eof_) return -1;
+      int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+      if (n < 0) {
+        eof_ = true;
+        return -3;
+      }
+      if (n == 0) {
+        eof_ = true;
+        return -1;
+      }
+      pos_ = 0;
+      end_ = (size_t)n;
+    }
+    return (unsigned char)buf_[pos_++];
+  }
+  // Append bytes up to (not including) the next delimiter; returns the delimiter, -1 at EOF (with or
+  // without bytes appended; *got tells), -3 on error.  line=true: delimiter '\n'; else any isspace().
+  int until(bool line, std::string *dst, bool *got) {
+    *got = false;
+    for (;;) {
+      if (pos_ >= end_) {
+        int c = get();
+        if (c < 0) return c;
+        --pos_;
+      }
+      size_t i = pos_;
+      if (line) {
+        const char *nl = (const char *)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+        i = nl ? (size_t)(nl - buf_.data()) : end_;
+      } else {
+        while (i < end_ && !isspace((unsigned char)buf_[i])) ++i;
+      }
+      dst->append(buf_.data() + pos_, i - pos_);
+      *got = true;
+      pos_ = i;
+      if (i < end_) {
+        ++pos_;
+        return (unsigned char)buf_[i];
+      }
+    }
+  }
+
+ private:
+  gzFile f_;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
+};
+
+}  // namespace
+
+struct fem_seqfile {
+  gzFile gz = nullptr;
+  ByteStream *in = nullptr;
+  int last_char = 0;  // header character already consumed by the previous record
+  std::string name, comment, seq, qual;
+  // one record; returns sequence length, -1 end of file, -2 truncated quality, -3 stream error
+  long next() {
+    int c;
+    if (last_char == 0) {
+      while ((c = in->get()) >= 0 && c != '>' && c != '@') {
+      }
+      if (c < 0) return c;
+      last_char = c;
+    }
+    name.clear(), comment.clear(), seq.clear(), qual.clear();
+    bool got;
+    c = in->until(false, &name, &got);
+    if (c < 0 && !got) return c;
+    if (c >= 0 && c != '\n') {
+      int d = in->until(true, &comment, &got);
+      if (d == -3) return -3;
+    }
+    while ((c = in->get()) >= 0 && c != '>' && c != '+' && c != '@') {
+      if (c == '\n') continue;
+      seq.push_back((char)c);
+      int d = in->until(true, &seq, &got);
+      if (d == -3) return -3;
+      if (seq.size() > 1 && seq.back() == '\r') seq.pop_back();  // kseq strips a trailing CR (src/kseq.h ks_getuntil2)
+    }
+    if (c == '>' || c == '@') last_char = c;
+    if (c != '+') {
+      if (c != '>' && c != '@') last_char = 0;
+      return (long)seq.size();  // FASTA
+    }
+    while ((c = in->get()) >= 0 && c != '\n') {
+    }
+    if (c == -1) return -2;
+    while (qual.size() < seq.size()) {
+      int d = in->until(true, &qual, &got);
+      if (d == -3) return -3;
+      if (qual.size() > 1 && qual.back() == '\r') qual.pop_back();
+      if (d < 0) break;
+    }
+    last_char = 0;
+    if (seq.size() != qual.size()) return -2;
+    return (long)seq.size();
+  }
+};
+
+extern "C" {
+
+fem_seqfile *fem_seqfile_open(const char *path) {
+  gzFile gz = gzopen(path, "r");
+  if (!gz) return nullptr;
+  gzbuffer(gz, 1u << 20);
+  fem_seqfile *f = new fem_seqfile();
+  f->gz = gz;
+  f->in = new ByteStream(gz);
+  return f;
+}
+
+void fem_seqfile_close(fem_seqfile *f) {
+  if (!f) return;
+  delete f->in;
+  gzclose(f->gz);
+  delete f;
+}
+
+int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
+  if (!f || !out) return -1;
+  std::string bases, quals, names;
+  std::vector<uint64_t> off{0}, name_off{0};
+  bool any_qual = false, all_qual = true;
+  int rc = 0;
+  while (max_seqs == 0 || off.size() - 1 < max_seqs) {
+    long len = f->next();
+    if (len == 0) continue;  // zero-length records are skipped (src/sequence_batch.c:50-52)
+    if (len < 0) {
+      if (len != -1) rc = (int)len;  // "Didn't reach the end of sequence file, which might be corrupted!"
+      break;
+    }
+    bases += f->seq;
+    if (!f->qual.empty()) {
+      any_qual = true;
+      quals += f->qual;
+    } else {
+      all_qual = false;
+      quals.append(f->seq.size(), '\0');
+    }
+    names += f->name;
+    off.push_back(bases.size());
+    name_off.push_back(names.size());
+  }
+  memset(out, 0, sizeof *out);
+  out->n = off.size() - 1;
+  out->bases = (char *)malloc(bases.size() + 64);
+  out->names = (char *)malloc(names.size() + 1);
+  out->off = dup_vec(off);
+  out->name_off = dup_vec(name_off);
+  if (!out->bases || !out->names || !out->off || !out->name_off) return -4;
+  memcpy(out->bases, bases.data(), bases.size());
+  memset(out->bases + bases.size(), 0, 64);
+  memcpy(out->names, names.data(), names.size());
+  if (any_qual && all_qual) {
+    out->quals = (char *)malloc(quals.size() + 1);
+    if (!out->quals) return -4;
+    memcpy(out->quals, quals.data(), quals.size());
+  }
+  return rc;
+}
+
+void fem_seqset_free(fem_seqset *s) {
+  if (!s) return;
+  free(s->bases), free(s->off), free(s->quals), free(s->names), free(s->name_off);
+  memset(s, 0, sizeof *s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// index files (reference src/index.c:100-168)
+// ------------------------------------------------------------------------------------------------
+int fem_index_save(const char *path, int32_t k, int32_t step, const uint32_t *lookup, uint64_t n_occ,
+                   const uint64_t *occ) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  const size_t n_lookup = ((size_t)1 << (2 * k)) + 1;
+  const size_t n = (size_t)n_occ;
+  bool ok = fwrite(&k, sizeof(int32_t), 1, f) == 1 && fwrite(&step, sizeof(int32_t), 1, f) == 1 &&
+            fwrite(lookup, sizeof(uint32_t), n_lookup, f) == n_lookup && fwrite(&n, sizeof(size_t), 1, f) == 1 &&
+            (n == 0 || fwrite(occ, sizeof(uint64_t), n, f) == n);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? 0 : -2;
+}
+
+int fem_index_load(const char *path, int32_t *k, int32_t *step, uint32_t **lookup, uint64_t *n_occ, uint64_t **occ) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return -1;
+  *lookup = nullptr, *occ = nullptr;
+  int rc = 0;
+  size_t n = 0, n_lookup = 0;
+  if (fread(k, sizeof(int32_t), 1, f) != 1 || fread(step, sizeof(int32_t), 1, f) != 1) rc = -2;
+  if (rc == 0 && (*k < 1 || *k > 16)) rc = -3;
+  if (rc == 0) {
+    n_lookup = ((size_t)1 << (2 * *k)) + 1;
+    *lookup = (uint32_t *)malloc(n_lookup * sizeof(uint32_t));
+    if (!*lookup)
+      rc = -4;
+    else if (fread(*lookup, sizeof(uint32_t), n_lookup, f) != n_lookup || fread(&n, sizeof(size_t), 1, f) != 1)
+      rc = -2;
+  }
+  if (rc == 0) {
+    *occ = (uint64_t *)malloc(std::max<size_t>(n, 1) * sizeof(uint64_t));
+    if (!*occ)
+      rc = -4;
+    else if (n && fread(*occ, sizeof(uint64_t), n, f) != n)
+      rc = -2;
+  }
+  fclose(f);
+  if (rc != 0) {
+    free(*lookup), free(*occ);
+    *lookup = nullptr, *occ = nullptr;
+    return rc;
+  }
+  *n_occ = n;
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// mapping tail (reference src/align.c:53-92, 279-544)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Hit {  // Mapping (src/utils.h:44-49) + its sort key
+  uint64_t key;
+  uint64_t cand;
+  int16_t end;
+  uint8_t ed, dir;
+};
+
+// radix_sort_mapping: klib's KRADIX_SORT_INIT(mapping, Mapping, MappingSortKey, 8) (src/ksort.h:101-151).
+// <=64 records: insertion sort (stable).  More: in-place MSD radix sort, 8 bits per level starting at bit 56,
+// each level a cycle-leader permutation (NOT stable), buckets of <=64 finished by insertion sort.  Equal keys
+// are possible, so the exact permutation is part of the observable behaviour (it picks the primary record).
+void insertion_by_key(Hit *beg, Hit *end) {
+  for (Hit *i = beg + 1; i < end; ++i) {
+    if (i->key < (i - 1)->key) {
+      Hit tmp = *i, *j = i;
+      for (; j > beg && tmp.key < (j - 1)->key; --j) *j = *(j - 1);
+      *j = tmp;
+    }
+  }
+}
+
+void msd_radix_level(Hit *beg, Hit *end, int shift) {
+  struct Span {
+    Hit *b, *e;
+  } bin[256];
+  for (auto &s : bin) s.b = s.e = beg;
+  for (Hit *i = beg; i != end; ++i) ++bin[(i->key >> shift) & 255].e;
+  for (int k = 1; k < 256; ++k) {
+    bin[k].e += bin[k - 1].e - beg;
+    bin[k].b = bin[k - 1].e;
+  }
+  for (int k = 0; k < 256;) {
+    Span &cur = bin[k];
+    if (cur.b == cur.e) {
+      ++k;
+      continue;
+    }
+    int dst = (int)((cur.b->key >> shift) & 255);
+    if (dst == k) {
+      ++cur.b;
+      continue;
+    }
+    Hit carry = *cur.b;
+    do {  // follow the cycle until an element that belongs to bucket k comes back
+      Hit displaced = *bin[dst].b;
+      *bin[dst].b++ = carry;
+      carry = displaced;
+      dst = (int)((carry.key >> shift) & 255);
+    } while (dst != k);
+    *cur.b++ = carry;
+  }
+  bin[0].b = beg;
+  for (int k = 1; k < 256; ++k) bin[k].b = bin[k - 1].e;
+  if (shift) {
+    int next = shift > 8 ? shift - 8 : 0;
+    for (int k = 0; k < 256; ++k) {
+      ptrdiff_t n = bin[k].e - bin[k].b;
+      if (n > 64)
+        msd_radix_level(bin[k].b, bin[k].e, next);
+      else if (n > 1)
+        insertion_by_key(bin[k].b, bin[k].e);
+    }
+  }
+}
+
+void sort_hits(std::vector<Hit> &h) {
+  if (h.size() <= 64)
+    insertion_by_key(h.data(), h.data() + h.size());
+  else
+    msd_radix_level(h.data(), h.data() + h.size(), 56);
+}
+
+struct OpRun {
+  char op;
+  int n;
+};
+
+void append_uint(std::string &s, unsigned v) {
+  char tmp[12];
+  int n = 0;
+  do {
+    tmp[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) s.push_back(tmp[--n]);
+}
+
+// generate_MD_tag (src/align.c:501-544)
+void build_md(const char *ref_at_start, const char *text, const std::vector<uint32_t> &cigar, std::string &md) {
+  md.clear();
+  unsigned run = 0;
+  size_t rp = 0, tp = 0;
+  auto flush = [&] {
+    if (run) {
+      append_uint(md, run);
+      run = 0;
+    }
+  };
+  for (uint32_t c : cigar) {
+    const uint32_t n = c >> 4;
+    switch (c & 0xf) {
+      case 0:  // M
+        for (uint32_t i = 0; i < n; ++i, ++rp, ++tp) {
+          if (ref_at_start[rp] == text[tp]) {
+            ++run;
+          } else {
+            flush();
+            md.push_back(ref_at_start[rp]);
+          }
+        }
+        break;
+      case 1:  // I
+        tp += n;
+        break;
+      case 2:  // D
+        flush();
+        md.push_back('^');
+        md.append(ref_at_start + rp, n);
+        rp += n;
+        break;
+    }
+  }
+  flush();
+}
+
+struct Tracer {  // scratch reused across the mappings of one thread
+  std::vector<uint32_t> d0, hp;
+  std::vector<OpRun> runs;
+};
+
+// generate_alignment (src/align.c:279-499).  Returns the start offset inside pattern (>= 0), or -1 where the
+// reference would have tripped one of its asserts.
+int trace_alignment(int e, const char *pattern, const char *text, int len, int ed, int end, Tracer &tr,
+                    std::vector<uint32_t> &cigar, std::string &md) {
+  cigar.clear();
+  int start = end - len + 1;
+  if (start < 0) return -1;
+  bool identical = true;
+  for (int i = 0; i < len && identical; ++i) identical = text[i] == pattern[start + i];
+  if (identical) {  // src/align.c:294-300
+    cigar.push_back((uint32_t)len << 4);
+    build_md(pattern + start, text, cigar, md);
+    return start;
+  }
+  // re-run the recurrence keeping D0 and HP of every column (src/align.c:303-338)
+  tr.d0.resize((size_t)len);
+  tr.hp.resize((size_t)len);
+  uint32_t peq[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; ++i) peq[code_of(pattern[i])] |= 1u << i;
+  const uint32_t top = 1u << (2 * e);
+  uint32_t vp = 0, vn = 0;
+  for (int i = 0; i < len; ++i) {
+    peq[code_of(pattern[i + 2 * e])] |= top;
+    uint32_t x = peq[code_of(text[i])] | vn;
+    uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+    uint32_t hn = vp & d0;
+    uint32_t hp = vn | ~(vp | d0);
+    x = d0 >> 1;
+    vn = x & hp;
+    vp = hn | ~(x | hp);
+    tr.d0[(size_t)i] = d0;
+    tr.hp[(size_t)i] = hp;
+    for (uint32_t &q : peq) q >>= 1;
+  }
+  // walk back from (last read base, end) until `ed` errors are accounted for (src/align.c:340-440)
+  enum Move { MATCH, MISMATCH, INSERT, DELETE };
+  int bit = end - len + 1, t = len - 1, pe = end, n_err = 0;
+  auto classify = [&]() -> Move {
+    bool d = (tr.d0[(size_t)t] >> bit) & 1u;
+    if (d && pattern[pe] == text[t]) return MATCH;
+    if (!d) return MISMATCH;
+    if ((tr.hp[(size_t)t] >> bit) & 1u) return INSERT;
+    return DELETE;
+  };
+  tr.runs.clear();
+  OpRun cur{'S', 1};
+  switch (classify()) {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
+    case MATCH:
+      --t, --pe;
+      cur = {'M', 1};
+      break;
+    case MISMATCH:
+      --t, --pe, ++n_err;
+      cur = {'S', 1};
+      break;
+    case INSERT:
+      --t, ++bit, ++n_err, ++start;
+      cur = {'S', 1};
+      break;
+    case DELETE:
+      return -1;  // assert(1 == 0)
+  }
+  auto extend = [&](char op) {
+    if (cur.op == op) {
+      ++cur.n;
+    } else {
+      tr.runs.push_back(cur);
+      cur = {op, 1};
+    }
+  };
+  while (t >= 0 && n_err != ed) {
+    if (bit < 0 || bit > 31 || pe < 0) return -1;
+    switch (classify()) {
+      case MATCH:
+        --t, --pe;
+        extend('M');
+        break;
+      case MISMATCH:
+        --t, --pe, ++n_err;
+        if (cur.op == 'S')
+          ++cur.n;  // read-end errors pile up in the pseudo-run (src/align.c:398-399)
+        else
+          extend('M');
+        break;
+      case INSERT:
+        --t, ++bit, ++n_err, ++start;
+        if (cur.op == 'S')
+          ++cur.n;
+        else
+          extend('I');
+        break;
+      case DELETE:
+        --bit, --pe, ++n_err, --start;
+        extend('D');
+        break;
+    }
+  }
+  if (t >= 0) {  // everything left of the last error matches (src/align.c:445-455)
+    if (cur.op == 'M') {
+      cur.n += t + 1;
+    } else {
+      tr.runs.push_back(cur);
+      cur = {'M', t + 1};
+    }
+  }
+  tr.runs.push_back(cur);
+  size_t first = 0;
+  if (tr.runs[0].op == 'S') {  // the pseudo-run is added to the run that follows it (src/align.c:466-469)
+    if (tr.runs.size() < 2) return -1;
+    tr.runs[1].n += tr.runs[0].n;
+    first = 1;
+  }
+  for (size_t i = tr.runs.size(); i-- > first;) {
+    uint32_t op;
+    switch (tr.runs[i].op) {
+      case 'M': op = 0; break;
+      case 'I': op = 1; break;
+      case 'D': op = 2; break;
+      default: return -1;
+    }
+    cigar.push_back(((uint32_t)tr.runs[i].n << 4) | op);
+  }
+  build_md(pattern + start, text, cigar, md);
+  return start;
+}
+
+struct ReadView {
+  const char *bases;
+  uint32_t len;
+};
+
+// Mapping list of one read in verify_candidates' order: + strand then - strand, candidates ascending,
+// rejected ones skipped (src/map.c:31-49, src/align.c:21-49).
+void collect_hits(const fem_tail_input &in, uint64_t read, std::vector<Hit> &hits) {
+  hits.clear();
+  for (uint32_t dir = 0; dir < 2; ++dir) {
+    const uint64_t slot = 2 * read + dir;
+    const uint32_t b = in.cand_begin[slot], n = in.cand_count[slot];
+    for (uint32_t i = b; i < b + n; ++i) {
+      if (in.ed[i] == 0xFF) continue;
+      Hit h;
+      h.cand = in.cand[i], h.end = in.end[i], h.ed = in.ed[i], h.dir = (uint8_t)dir;
+      h.key = ((uint64_t)h.ed << 60) | ((uint64_t)h.dir << 59) | (h.cand + (uint64_t)(int64_t)h.end);  // src/align.c:53
+      hits.push_back(h);
+    }
+  }
+}
+
+void reverse_complement(const char *fwd, uint32_t len, std::string &out) {  // src/sequence_batch.h:90-98
+  out.resize(len);
+  for (uint32_t i = 0; i < len; ++i) out[i] = kCodeChar[3 ^ code_of(fwd[len - 1 - i])];
+}
+
+struct Record {
+  uint16_t flag;
+  uint32_t tid, pos0;
+  uint8_t nm;
+};
+
+// htslib's seq_nt16_table followed by seq_nt16_str (third-party, un-vendored in the reference: restated from
+// htslib's published tables): what SEQ looks like after a round trip through the BAM nibble encoding.
+struct SeqRoundTrip {
+  char t[256];
+  SeqRoundTrip() {
+    static const char iupac[] = "=ACMGRSVTWYHKDBN";
+    for (int i = 0; i < 256; ++i) t[i] = 'N';
+    for (int i = 0; i < 16; ++i) {
+      t[(unsigned char)iupac[i]] = iupac[i];
+      t[(unsigned char)tolower(iupac[i])] = iupac[i];
+    }
+    t['0'] = 'A', t['1'] = 'C', t['2'] = 'G', t['3'] = 'T';
+  }
+};
+const SeqRoundTrip kSeqText;
+
+template <typename Emit>
+void process_read(int e, const fem_tail_ref &ref, const char *fwd, uint32_t len, std::vector<Hit> &hits, Tracer &tr,
+                  std::string &rev, std::vector<uint32_t> &cigar, std::string &md, Emit &&emit) {
+  sort_hits(hits);
+  bool have_rev = false;
+  for (size_t mi = 0; mi < hits.size(); ++mi) {
+    const Hit &h = hits[mi];
+    const char *text = fwd;
+    if (h.dir) {
+      if (!have_rev) {
+        reverse_complement(fwd, len, rev);
+        have_rev = true;
+      }
+      text = rev.data();
+    }
+    const uint32_t tid = (uint32_t)(h.cand >> 32);
+    const char *pattern = ref.text + ref.off[tid] + (uint32_t)h.cand;
+    int start = trace_alignment(e, pattern, text, (int)len, h.ed, h.end, tr, cigar, md);
+    Record r;
+    r.flag = (uint16_t)((h.dir ? 16 : 0) | (mi > 0 ? 256 : 0));  // BAM_FREVERSE, BAM_FSECONDARY (src/align.c:82-84)
+    if (start < 0) {
+      r.flag |= 0x8000;  // the reference would have asserted; never happens on valid data
+      start = 0;
+      cigar.clear();
+      md.clear();
+    }
+    r.tid = tid;
+    r.pos0 = (uint32_t)start + (uint32_t)h.cand;  // src/align.c:80
+    r.nm = h.ed;
+    emit(mi, r, cigar, md);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fem_tail_records(int32_t e, const fem_tail_ref *ref, const char *read_bases, const uint64_t *read_off,
+                     const fem_tail_input *in, int n_threads, fem_records *out) {
+  if (!ref || !in || !out || (in->n_reads && (!read_bases || !read_off))) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const uint64_t n = in->n_reads;
+  struct Part {
+    std::vector<uint64_t> per_read;  // records of each read in this part
+    std::vector<Record> rec;
+    std::vector<uint64_t> cig_end, md_end;
+    std::vector<uint32_t> cig;
+    std::string md;
+  };
+  std::vector<Part> parts((size_t)n_threads);
+#pragma omp parallel num_threads(n_threads)
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    Part &p = parts[(size_t)t];
+    const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+    std::vector<Hit> hits;
+    Tracer tr;
+    std::string rev, md;
+    std::vector<uint32_t> cigar;
+    for (uint64_t r = lo; r < hi; ++r) {
+      collect_hits(*in, r, hits);
+      p.per_read.push_back(hits.size());
+      if (hits.empty()) continue;
+      process_read(e, *ref, read_bases + read_off[r], (uint32_t)(read_off[r + 1] - read_off[r]), hits, tr, rev, cigar,
+                   md, [&](size_t, const Record &rec, const std::vector<uint32_t> &cg, const std::string &m) {
+                     p.rec.push_back(rec);
+                     p.cig.insert(p.cig.end(), cg.begin(), cg.end());
+                     p.cig_end.push_back(p.cig.size());
+                     p.md += m;
+                     p.md_end.push_back(p.md.size());
+                   });
+    }
+  }
+  std::vector<uint64_t> rec_off{0}, cig_off{0}, md_off{0};
+  std::vector<uint16_t> flag;
+  std::vector<uint32_t> tid, pos0, cig;
+  std::vector<uint8_t> nm;
+  std::string md;
+  for (const Part &p : parts) {
+    for (uint64_t c : p.per_read) rec_off.push_back(rec_off.back() + c);
+    for (const Record &r : p.rec) flag.push_back(r.flag), tid.push_back(r.tid), pos0.push_back(r.pos0), nm.push_back(r.nm);
+    for (uint64_t c : p.cig_end) cig_off.push_back(cig.size() + c);
+    for (uint64_t c : p.md_end) md_off.push_back(md.size() + c);
+    cig.insert(cig.end(), p.cig.begin(), p.cig.end());
+    md += p.md;
+  }
+  while (rec_off.size() < n + 1) rec_off.push_back(rec_off.back());
+  memset(out, 0, sizeof *out);
+  out->n_records = flag.size();
+  out->rec_off = dup_vec(rec_off);
+  out->flag = dup_vec(flag), out->tid = dup_vec(tid), out->pos0 = dup_vec(pos0), out->nm = dup_vec(nm);
+  out->cigar_off = dup_vec(cig_off), out->cigar = dup_vec(cig), out->md_off = dup_vec(md_off);
+  out->md = (char *)malloc(md.size() + 1);
+  if (out->md) memcpy(out->md, md.data(), md.size());
+  return 0;
+}
+
+void fem_records_free(fem_records *r) {
+  if (!r) return;
+  free(r->rec_off), free(r->flag), free(r->tid), free(r->pos0), free(r->nm);
+  free(r->cigar_off), free(r->cigar), free(r->md_off), free(r->md);
+  memset(r, 0, sizeof *r);
+}
+
+int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len) {
+  if (!ref || !text || !text_len) return -1;
+  std::string s;
+  for (uint32_t i = 0; i < ref->n_seq; ++i) {  // "@SQ\tSN:%s\tLN:%d\n" (src/output_queue.c:107)
+    s += "@SQ\tSN:";
+    s.append(ref->names + ref->name_off[i], ref->name_off[i + 1] - ref->name_off[i]);
+    s += "\tLN:";
+    s += std::to_string((int)ref->len[i]);
+    s += "\n";
+  }
+  *text = (char *)malloc(s.size() + 1);
+  if (!*text) return -4;
+  memcpy(*text, s.data(), s.size());
+  *text_len = s.size();
+  return 0;
+}
+
+int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, const fem_tail_input *in, int n_threads,
+                 char **text, uint64_t *text_len) {
+  if (!ref || !reads || !in || !text || !text_len) return -1;
+  if (in->n_reads > reads->n) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const uint64_t n = in->n_reads;
+  std::vector<std::string> parts((size_t)n_threads);
+#pragma omp parallel num_threads(n_threads)
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    std::string &o = parts[(size_t)t];
+    const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+    std::vector<Hit> hits;
+    Tracer tr;
+    std::string rev, md;
+    std::vector<uint32_t> cigar;
+    for (uint64_t r = lo; r < hi; ++r) {
+      collect_hits(*in, r, hits);
+      if (hits.empty()) continue;  // unmapped reads produce no record (src/map.c:50)
+      const char *fwd = reads->bases + reads->off[r];
+      const uint32_t len = (uint32_t)(reads->off[r + 1] - reads->off[r]);
+      const char *qual = reads->quals ? reads->quals + reads->off[r] : nullptr;
+      const char *name = reads->names + reads->name_off[r];
+      const size_t name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
+      process_read(e, *ref, fwd, len, hits, tr, rev, cigar, md,
+                   [&](size_t rank, const Record &rec, const std::vector<uint32_t> &cg, const std::string &m) {
+                     // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL NM MD (src/align.c:546-632)
+                     o.append(name, name_len);
+                     o.push_back('\t');
+                     append_uint(o, rec.flag);
+                     o.push_back('\t');
+                     o.append(ref->names + ref->name_off[rec.tid], ref->name_off[rec.tid + 1] - ref->name_off[rec.tid]);
+                     o.push_back('\t');
+                     append_uint(o, rec.pos0 + 1u);
+                     o += "\t255\t";
+                     if (cg.empty()) o.push_back('*');
+                     for (uint32_t c : cg) {
+                       append_uint(o, c >> 4);
+                       o.push_back("MIDNSHP=XB"[c & 0xf]);
+                     }
+                     o += "\t*\t0\t0\t";
+                     if (rank == 0 && len > 0) {  // only the primary record carries SEQ/QUAL (src/align.c:83-88)
+                       for (uint32_t i = 0; i < len; ++i) o.push_back(kSeqText.t[(unsigned char)fwd[i]]);  // original read (src/align.c:79)
+                       o.push_back('\t');
+                       if (qual)
+                         o.append(qual, len);
+                       else
+                         o.push_back('*');
+                     } else {
+                       o += "*\t*";
+                     }
+                     o += "\tNM:i:";
+                     append_uint(o, rec.nm);
+                     o += "\tMD:Z:";
+                     o += m;
+                     o.push_back('\n');
+                   });
+    }
+  }
+  size_t total = 0;
+  for (const std::string &p : parts) total += p.size();
+  char *buf = (char *)malloc(total + 1);
+  if (!buf) return -4;
+  size_t at = 0;
+  for (const std::string &p : parts) {
+    memcpy(buf + at, p.data(), p.size());
+    at += p.size();
+  }
+  *text = buf;
+  *text_len = total;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic data; splitmix64 streams keyed by (seed, index)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct SplitMix {
+  uint64_t s;
+  explicit SplitMix(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  uint64_t below(uint64_t n) { return (uint64_t)(((unsigned __int128)next() * n) >> 64); }
+};
+inline uint64_t stream_seed(uint64_t seed, uint64_t tag, uint64_t index) {
+  SplitMix m(seed ^ (tag * 0xD6E8FEB86659FD93ull) ^ (index * 0xA0761D6478BD642Full));
+  m.next();
+  return m.next();
+}
+}  // namespace
+
+extern "C" {
+
+void fem_synth_reference(uint64_t seed, uint32_t n_seq, const uint64_t *seq_off, const uint32_t *seq_len, char *out,
+                         int n_threads) {
+  static const char acgt[4] = {'A', 'C', 'G', 'T'};
+  if (n_threads < 1) n_threads = 1;
+  const uint64_t chunk = 1u << 20;  // every 1 Mi bases of a sequence form their own stream -> parallel + reproducible
+  for (uint32_t s = 0; s < n_seq; ++s) {
+    const uint64_t len = seq_len[s], n_chunks = (len + chunk - 1) / chunk;
+    char *dst = out + seq_off[s];
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int64_t c = 0; c < (int64_t)n_chunks; ++c) {
+      SplitMix rng(stream_seed(seed, 0x5EC0 + s, (uint64_t)c));
+      const uint64_t lo = (uint64_t)c * chunk, hi = std::min(len, lo + chunk);
+      for (uint64_t i = lo; i < hi;) {
+        uint64_t bits = rng.next();
+        for (int j = 0; j < 32 && i < hi; ++j, ++i, bits >>= 2) dst[i] = acgt[bits & 3];
+      }
+    }
+  }
+}
+
+void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
+                     uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
+                     int n_threads) {
+  static const char acgt[4] = {'A', 'C', 'G', 'T'};
+  if (n_threads < 1) n_threads = 1;
+  // sequences long enough to hold a read, weighted by the number of admissible start positions
+  std::vector<uint64_t> cum(n_seq + 1, 0);
+  const uint64_t span = (uint64_t)L + (uint64_t)e;
+  for (uint32_t s = 0; s < n_seq; ++s) cum[s + 1] = cum[s] + (seq_len[s] > span ? seq_len[s] - span : 0);
+  const uint64_t total = cum[n_seq];
+#pragma omp parallel num_threads(n_threads)
+  {
+    std::vector<char> buf(span + 8);
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < (int64_t)n_reads; ++r) {
+      SplitMix rng(stream_seed(seed, 0x7EAD, first_read + (uint64_t)r));
+      char *dst = bases_out + (uint64_t)r * L;
+      if (total == 0) {
+        for (uint32_t i = 0; i < L; ++i) dst[i] = acgt[rng.below(4)];
+        continue;
+      }
+      const uint64_t pick = rng.below(total);
+      const uint32_t s = (uint32_t)(std::upper_bound(cum.begin(), cum.end(), pick) - cum.begin() - 1);
+      const uint64_t start = pick - cum[s];
+      memcpy(buf.data(), ref_text + seq_off[s] + start, span);
+      size_t cur = span;
+      const int n_err = (int)rng.below((uint64_t)e + 1);
+      for (int k = 0; k < n_err; ++k) {
+        const uint64_t kind = rng.below(10);
+        const size_t pos = 1 + (size_t)rng.below(cur > 2 ? cur - 2 : 1);
+        if (kind < 6) {  // substitution by a different base
+          const char old = buf[pos];
+          char nb;
+          do nb = acgt[rng.below(4)];
+          while (nb == old);
+          buf[pos] = nb;
+        } else if (kind < 8) {  // insertion
+          if (cur < buf.size()) {
+            memmove(buf.data() + pos + 1, buf.data() + pos, cur - pos);
+            buf[pos] = acgt[rng.below(4)];
+            ++cur;
+          }
+        } else {  // deletion
+          memmove(buf.data() + pos, buf.data() + pos + 1, cur - pos - 1);
+          --cur;
+        }
+      }
+      // cur >= span - e = L always holds
+      if (rng.below(2)) {
+        for (uint32_t i = 0; i < L; ++i) dst[i] = kCodeChar[3 ^ code_of(buf[L - 1 - i])];
+      } else {
+        memcpy(dst, buf.data(), L);
+      }
+    }
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+/*
+ * fem_host.h — host side of the drop-in: everything around the device hot path that the
+ * reference does on the CPU and that stays on the CPU here (C ABI, libfemhost.so).
+ *
+ *   sequence files   FASTA/FASTQ(.gz) loading           (reference src/sequence_batch.c:30-121, src/kseq.h:185-226)
+ *   index files      byte-compatible save / load        (src/index.c:100-168)
+ *   mapping tail     Mapping lists -> sorted records    (src/align.c:53-92, 279-544; src/ksort.h:101-151)
+ *   SAM text         header + records                   (src/output_queue.c:93-116, src/align.c:546-632)
+ *   synthetic data   seeded reference / read generator  (build-owned, not in the reference)
+ *
+ * No mapping arithmetic of the hot path (seeding, filtering, verification) lives here: that is libfemhip.so.
+ */
+#ifndef FEM_HOST_H_
+#define FEM_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- sequence files ---------------- */
+typedef struct fem_seqfile fem_seqfile; /* an open FASTA/FASTQ(.gz) stream */
+
+/* A set of sequences held in memory: concatenated characters + n+1 offsets (+ names, + qualities). */
+typedef struct {
+  uint64_t n;
+  char *bases;      /* concatenated sequence characters */
+  uint64_t *off;    /* n+1 */
+  char *quals;      /* concatenated quality strings (same offsets), or NULL for FASTA */
+  char *names;      /* concatenated names */
+  uint64_t *name_off; /* n+1 */
+} fem_seqset;
+
+fem_seqfile *fem_seqfile_open(const char *path);
+void fem_seqfile_close(fem_seqfile *f);
+/* Reads up to max_seqs records (0 = all), skipping zero-length ones as the reference does
+ * (src/sequence_batch.c:50-52,88-89).  Returns 0, or <0 on a malformed / truncated file. */
+int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out);
+void fem_seqset_free(fem_seqset *s);
+
+/* ---------------- index files (src/index.c:100-168) ---------------- */
+/* int32 k | int32 step | uint32 lookup[4^k+1] | size_t n | uint64 occ[n] */
+int fem_index_save(const char *path, int32_t k, int32_t step, const uint32_t *lookup, uint64_t n_occ, const uint64_t *occ);
+/* Allocates *lookup and *occ with malloc. */
+int fem_index_load(const char *path, int32_t *k, int32_t *step, uint32_t **lookup, uint64_t *n_occ, uint64_t **occ);
+
+/* ---------------- mapping tail ---------------- */
+/* What the device hands back per batch (fem_batch_result of include/fem_hip.h). */
+typedef struct {
+  uint64_t n_reads;
+  const uint32_t *cand_begin;
+  const uint32_t *cand_count;
+  const uint64_t *cand;
+  const uint8_t *ed;
+  const int16_t *end;
+} fem_tail_input;
+
+typedef struct {
+  const char *text;      /* reference characters, concatenated (raw FASTA case) */
+  const uint64_t *off;
+  const uint32_t *len;
+  uint32_t n_seq;
+  const char *names;     /* concatenated names */
+  const uint64_t *name_off;
+} fem_tail_ref;
+
+/* Records in output order, as arrays (tests compare these with the oracle's). */
+typedef struct {
+  uint64_t n_records;
+  uint64_t *rec_off;   /* n_reads+1 */
+  uint16_t *flag;
+  uint32_t *tid;
+  uint32_t *pos0;
+  uint8_t *nm;
+  uint64_t *cigar_off; /* n_records+1 */
+  uint32_t *cigar;     /* BAM encoding len<<4|op */
+  uint64_t *md_off;    /* n_records+1 */
+  char *md;
+} fem_records;
+
+/* process_mappings (src/align.c:56-92) for every read of a batch: rebuild the Mapping list in
+ * verify_candidates' order, radix_sort_mapping, traceback -> CIGAR/MD, record fields. */
+int fem_tail_records(int32_t e, const fem_tail_ref *ref, const char *read_bases, const uint64_t *read_off,
+                     const fem_tail_input *in, int n_threads, fem_records *out);
+void fem_records_free(fem_records *r);
+
+/* The same, rendered as SAM text (one line per record, reads in batch order, unmapped reads emit
+ * nothing, src/map.c:50-55).  *text is malloc'd. */
+int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, const fem_tail_input *in, int n_threads,
+                 char **text, uint64_t *text_len);
+/* "@SQ\tSN:%s\tLN:%d\n" per sequence (src/output_queue.c:104-108). *text is malloc'd. */
+int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len);
+
+/* ---------------- synthetic data ---------------- */
+/* iid uniform A/C/G/T; sequence i is a pure function of (seed, i). */
+void fem_synth_reference(uint64_t seed, uint32_t n_seq, const uint64_t *seq_off, const uint32_t *seq_len, char *out,
+                         int n_threads);
+/* Read r (global index first_read + r) is a pure function of (seed, r): uniform start, 0..e edits
+ * (60% substitution / 20% insertion / 20% deletion at interior offsets), truncated to L, reverse-complemented
+ * with probability 1/2.  bases_out holds n_reads*L characters. */
+void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
+                     uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
+                     int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEM_HOST_H_ */

@@ -1,0 +1,235 @@
+"""ctypes binding of libfemhost.so (fem_amd/csrc/fem_host.h): sequence/index files, mapping tail, synthetic data."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SeqSet(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("bases", C.c_void_p), ("off", C.c_void_p), ("quals", C.c_void_p),
+                ("names", C.c_void_p), ("name_off", C.c_void_p)]
+
+
+class TailInput(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("cand_begin", C.c_void_p), ("cand_count", C.c_void_p), ("cand", C.c_void_p),
+                ("ed", C.c_void_p), ("end", C.c_void_p)]
+
+
+class TailRef(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n_seq", C.c_uint32),
+                ("names", C.c_void_p), ("name_off", C.c_void_p)]
+
+
+class Records(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("rec_off", C.c_void_p), ("flag", C.c_void_p), ("tid", C.c_void_p),
+                ("pos0", C.c_void_p), ("nm", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("md_off", C.c_void_p), ("md", C.c_void_p)]
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libfemhost.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libfemhost.so is missing (%s): run `make -C fem_amd/csrc`" % path)
+        L = C.CDLL(path)
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+        L.fem_seqfile_open.restype = vp
+        L.fem_seqfile_open.argtypes = [C.c_char_p]
+        L.fem_seqfile_close.argtypes = [vp]
+        L.fem_seqfile_read.argtypes = [vp, u64, C.POINTER(SeqSet)]
+        L.fem_seqset_free.argtypes = [C.POINTER(SeqSet)]
+        L.fem_index_save.argtypes = [C.c_char_p, i32, i32, vp, u64, vp]
+        L.fem_index_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(u64),
+                                     C.POINTER(vp)]
+        L.fem_tail_records.argtypes = [i32, C.POINTER(TailRef), vp, vp, C.POINTER(TailInput), C.c_int,
+                                       C.POINTER(Records)]
+        L.fem_records_free.argtypes = [C.POINTER(Records)]
+        L.fem_tail_sam.argtypes = [i32, C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(TailInput), C.c_int,
+                                   C.POINTER(vp), C.POINTER(u64)]
+        L.fem_sam_header.argtypes = [C.POINTER(TailRef), C.POINTER(vp), C.POINTER(u64)]
+        L.fem_synth_reference.argtypes = [u64, C.c_uint32, vp, vp, vp, C.c_int]
+        L.fem_synth_reads.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
+        L.free = C.CDLL(None).free
+        L.free.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def _copy(ptr, n, dtype):
+    n = int(n)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+# ------------------------------------------------------------------------------------------ synthetic data
+def synth_reference(seed, seq_lens, threads=8):
+    """Concatenated iid A/C/G/T text for sequences of the given lengths -> (text uint8[total+64], off, len)."""
+    lens = np.asarray(seq_lens, dtype=np.uint32)
+    off = np.zeros(len(lens), dtype=np.uint64)
+    if len(lens) > 1:
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    total = int(lens.astype(np.uint64).sum())
+    text = np.zeros(total + 64, dtype=np.uint8)
+    lib().fem_synth_reference(seed, len(lens), off.ctypes.data, lens.ctypes.data, text.ctypes.data, threads)
+    return text, off, lens
+
+
+def synth_reads(seed, text, off, lens, n_reads, L, e, first_read=0, threads=8):
+    """n_reads reads of length L drawn from the reference with 0..e edits -> (bases uint8[n*L(+8)], offsets uint64[n+1])."""
+    bases = np.zeros(n_reads * L + 8, dtype=np.uint8)
+    lib().fem_synth_reads(seed, text.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens), first_read, n_reads,
+                          L, e, bases.ctypes.data, threads)
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
+    return bases, offsets
+
+
+# ------------------------------------------------------------------------------------------ files
+class Sequences:
+    """Host copy of a fem_seqset."""
+
+    def __init__(self, s):
+        n = int(s.n)
+        self.n = n
+        self.off = _copy(s.off, n + 1, np.uint64)
+        self.name_off = _copy(s.name_off, n + 1, np.uint64)
+        nb = int(self.off[-1]) if n else 0
+        self.bases = _copy(s.bases, nb, np.uint8)
+        self.quals = _copy(s.quals, nb, np.uint8) if s.quals else None
+        self.names_raw = _copy(s.names, int(self.name_off[-1]) if n else 0, np.uint8)
+
+    def seq(self, i):
+        return self.bases[int(self.off[i]):int(self.off[i + 1])].tobytes()
+
+    def name(self, i):
+        return self.names_raw[int(self.name_off[i]):int(self.name_off[i + 1])].tobytes().decode()
+
+    def qual(self, i):
+        return self.quals[int(self.off[i]):int(self.off[i + 1])].tobytes()
+
+
+def read_sequences(path, max_seqs=0):
+    L = lib()
+    f = L.fem_seqfile_open(path.encode())
+    if not f:
+        raise FileNotFoundError(path)
+    s = SeqSet()
+    rc = L.fem_seqfile_read(f, max_seqs, C.byref(s))
+    L.fem_seqfile_close(f)
+    try:
+        if rc != 0:
+            raise ValueError("malformed sequence file %s (rc=%d)" % (path, rc))
+        return Sequences(s)
+    finally:
+        L.fem_seqset_free(C.byref(s))
+
+
+def index_save(path, k, step, lookup, occ):
+    lookup = np.ascontiguousarray(lookup, np.uint32)
+    occ = np.ascontiguousarray(occ, np.uint64)
+    rc = lib().fem_index_save(path.encode(), k, step, lookup.ctypes.data, len(occ), occ.ctypes.data)
+    if rc != 0:
+        raise OSError("fem_index_save failed (%d)" % rc)
+
+
+def index_load(path):
+    L = lib()
+    k, step, n = C.c_int32(), C.c_int32(), C.c_uint64()
+    lp, op = C.c_void_p(), C.c_void_p()
+    rc = L.fem_index_load(path.encode(), C.byref(k), C.byref(step), C.byref(lp), C.byref(n), C.byref(op))
+    if rc != 0:
+        raise OSError("fem_index_load failed (%d)" % rc)
+    lookup = _copy(lp.value, (1 << (2 * k.value)) + 1, np.uint32)
+    occ = _copy(op.value, n.value, np.uint64)
+    L.free(lp)
+    L.free(op)
+    return k.value, step.value, lookup, occ
+
+
+# ------------------------------------------------------------------------------------------ mapping tail
+class TailReference:
+    def __init__(self, text, off, lens, names=None):
+        self.text = np.ascontiguousarray(text, np.uint8)
+        self.off = np.ascontiguousarray(off, np.uint64)
+        self.len = np.ascontiguousarray(lens, np.uint32)
+        names = names or ["chr%d" % (i + 1) for i in range(len(self.len))]
+        raw = [n.encode() for n in names]
+        self.name_off = np.zeros(len(raw) + 1, np.uint64)
+        self.name_off[1:] = np.cumsum([len(r) for r in raw])
+        self.names = np.frombuffer(b"".join(raw) + b"\0", np.uint8).copy()
+        self.c = TailRef(self.text.ctypes.data, self.off.ctypes.data, self.len.ctypes.data, len(self.len),
+                         self.names.ctypes.data, self.name_off.ctypes.data)
+
+
+class RecordArrays:
+    def __init__(self, r, n_reads):
+        nr = int(r.n_records)
+        self.rec_off = _copy(r.rec_off, n_reads + 1, np.uint64)
+        self.flag = _copy(r.flag, nr, np.uint16)
+        self.tid = _copy(r.tid, nr, np.uint32)
+        self.pos0 = _copy(r.pos0, nr, np.uint32)
+        self.nm = _copy(r.nm, nr, np.uint8)
+        self.cigar_off = _copy(r.cigar_off, nr + 1, np.uint64)
+        self.cigar = _copy(r.cigar, int(self.cigar_off[-1]), np.uint32)
+        self.md_off = _copy(r.md_off, nr + 1, np.uint64)
+        self.md = _copy(r.md, int(self.md_off[-1]), np.uint8)
+
+
+def _tail_input(n_reads, cand_begin, cand_count, cand, ed, end):
+    arrs = (np.ascontiguousarray(cand_begin, np.uint32), np.ascontiguousarray(cand_count, np.uint32),
+            np.ascontiguousarray(cand, np.uint64), np.ascontiguousarray(ed, np.uint8),
+            np.ascontiguousarray(end, np.int16))
+    t = TailInput(n_reads, *[a.ctypes.data for a in arrs])
+    return t, arrs
+
+
+def tail_records(e, ref, read_bases, read_off, cand_begin, cand_count, cand, ed, end, threads=1):
+    n_reads = len(read_off) - 1
+    t, keep = _tail_input(n_reads, cand_begin, cand_count, cand, ed, end)
+    bases = np.ascontiguousarray(read_bases, np.uint8)
+    off = np.ascontiguousarray(read_off, np.uint64)
+    r = Records()
+    rc = lib().fem_tail_records(e, C.byref(ref.c), bases.ctypes.data, off.ctypes.data, C.byref(t), threads, C.byref(r))
+    if rc != 0:
+        raise RuntimeError("fem_tail_records failed (%d)" % rc)
+    try:
+        return RecordArrays(r, n_reads)
+    finally:
+        lib().fem_records_free(C.byref(r))
+
+
+def sam_header(ref):
+    p, n = C.c_void_p(), C.c_uint64()
+    lib().fem_sam_header(C.byref(ref.c), C.byref(p), C.byref(n))
+    s = _copy(p.value, n.value, np.uint8).tobytes().decode()
+    lib().free(p)
+    return s
+
+
+def tail_sam(e, ref, names, read_bases, read_off, quals, cand_begin, cand_count, cand, ed, end, threads=1):
+    n_reads = len(read_off) - 1
+    t, keep = _tail_input(n_reads, cand_begin, cand_count, cand, ed, end)
+    bases = np.ascontiguousarray(read_bases, np.uint8)
+    off = np.ascontiguousarray(read_off, np.uint64)
+    q = np.ascontiguousarray(quals, np.uint8)
+    raw = [n.encode() for n in names]
+    name_off = np.zeros(n_reads + 1, np.uint64)
+    name_off[1:] = np.cumsum([len(r) for r in raw])
+    nm = np.frombuffer(b"".join(raw) + b"\0", np.uint8).copy()
+    s = SeqSet(n_reads, bases.ctypes.data, off.ctypes.data, q.ctypes.data, nm.ctypes.data, name_off.ctypes.data)
+    p, n = C.c_void_p(), C.c_uint64()
+    rc = lib().fem_tail_sam(e, C.byref(ref.c), C.byref(s), C.byref(t), threads, C.byref(p), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("fem_tail_sam failed (%d)" % rc)
+    text = _copy(p.value, n.value, np.uint8).tobytes().decode()
+    lib().free(p)
+    return text

@@ -1,0 +1,140 @@
+"""Host-side product code (libfemhost.so) against the oracle and against the file formats; runs without a GPU."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from fem_amd import host
+from oracle import fem_oracle as fo
+from tests import util
+
+
+def oracle_case(seed, e, a=1, L=100, n_reads=250, repeat=True):
+    rng = np.random.default_rng(seed)
+    if repeat:
+        seqs = util.repeat_rich_reference(rng, n_seq=3, unit_len=max(300, 2 * L), n_units=3, copies=110, spacer=150)
+    else:
+        seqs = [util.rand_seq(rng, 150_000), util.rand_seq(rng, 80_000)]
+    reads = util.make_reads(rng, seqs, n_reads, L, e, n_rate=0.002)
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    batch = fo.ReadBatch(reads)
+    res = fo.map_reads(ref, idx, batch, e=e, a=a)
+    return seqs, reads, ref, batch, res
+
+
+def as_device_layout(res):
+    """Oracle candidates in the layout libfemhip hands back (begin/count per (read, strand))."""
+    begin = res.cand_off[:-1].astype(np.uint32)
+    count = np.diff(res.cand_off.astype(np.int64)).astype(np.uint32)
+    return begin, count, res.cands, res.v_ed, res.v_end
+
+
+@pytest.mark.parametrize("e,L,repeat", [(3, 100, True), (7, 150, True), (2, 80, False), (1, 64, True)])
+def test_tail_records_equal_oracle(e, L, repeat):
+    seqs, reads, ref, batch, res = oracle_case(40 + e, e, L=L, repeat=repeat)
+    tref = host.TailReference(ref.text, ref.off, ref.len)
+    begin, count, cand, ed, end = as_device_layout(res)
+    for threads in (1, 3):
+        got = host.tail_records(e, tref, batch.bases, batch.off, begin, count, cand, ed, end, threads=threads)
+        assert np.array_equal(got.rec_off, res.rec_off)
+        assert np.array_equal(got.flag, res.r_flag)
+        assert np.array_equal(got.tid, res.r_tid)
+        assert np.array_equal(got.pos0, res.r_pos)
+        assert np.array_equal(got.nm, res.r_nm)
+        assert np.array_equal(got.cigar_off, res.cig_off)
+        assert np.array_equal(got.cigar, res.cig)
+        assert np.array_equal(got.md_off, res.md_off)
+        assert np.array_equal(got.md, res.md)
+    per_read = np.diff(res.rec_off.astype(np.int64))
+    if repeat and e >= 3:
+        assert per_read.max() > 64, "fixture must exercise klib's radix path (>64 mappings of one read)"
+    assert np.any((res.cig & 0xF) == 1) and np.any((res.cig & 0xF) == 2), "fixture must contain I and D"
+
+
+def expected_sam(seqs_names, reads, names, quals, res):
+    """SAM v1 text for the oracle's records (field rules of src/align.c:546-632, src/map.c:50-55)."""
+    lines = []
+    for r in range(len(reads)):
+        lo, hi = int(res.rec_off[r]), int(res.rec_off[r + 1])
+        for j in range(lo, hi):
+            primary = j == lo
+            lines.append("\t".join([
+                names[r], str(int(res.r_flag[j])), seqs_names[int(res.r_tid[j])], str(int(res.r_pos[j]) + 1), "255",
+                res.cigar_str(j), "*", "0", "0",
+                reads[r].decode().upper() if primary else "*", quals[r] if primary else "*",
+                "NM:i:%d" % int(res.r_nm[j]), "MD:Z:" + res.md_str(j)]))
+    return "".join(l + "\n" for l in lines)
+
+
+def test_sam_text_follows_the_record_rules():
+    e = 3
+    seqs, reads, ref, batch, res = oracle_case(7, e, n_reads=120)
+    names = ["r%d" % i for i in range(len(reads))]
+    quals = ["".join(chr(33 + (i * 7 + j) % 40) for j in range(len(r))) for i, r in enumerate(reads)]
+    tref = host.TailReference(ref.text, ref.off, ref.len, names=["chrA", "chrB", "chrC"])
+    begin, count, cand, ed, end = as_device_layout(res)
+    q = np.frombuffer("".join(quals).encode(), np.uint8)
+    text = host.tail_sam(e, tref, names, batch.bases, batch.off, q, begin, count, cand, ed, end, threads=2)
+    assert text == expected_sam(["chrA", "chrB", "chrC"], reads, names, quals, res)
+    assert host.sam_header(tref) == "".join("@SQ\tSN:%s\tLN:%d\n" % (n, len(s)) for n, s in zip(["chrA", "chrB", "chrC"], seqs))
+    # unmapped reads emit nothing; secondary records carry '*' for SEQ and QUAL and flag 256
+    n_mapped = int(np.count_nonzero(np.diff(res.rec_off.astype(np.int64))))
+    assert len({l.split("\t")[0] for l in text.splitlines()}) == n_mapped
+    assert any(int(l.split("\t")[1]) & 256 and l.split("\t")[9] == "*" for l in text.splitlines())
+
+
+def test_fasta_fastq_parsing_follows_kseq(tmp_path):
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">chr1 first comment\nACGTAC\nGTNN\n\nacgt\n>empty\n>chr2\tx\r\nGGCC\r\nTT\r\n>last\nA")
+    s = host.read_sequences(str(fa))
+    assert [s.name(i) for i in range(s.n)] == ["chr1", "chr2", "last"]  # zero-length record skipped
+    assert [s.seq(i) for i in range(s.n)] == [b"ACGTACGTNNacgt", b"GGCCTT", b"A"]
+    assert s.quals is None
+    fq = tmp_path / "reads.fq.gz"
+    with gzip.open(str(fq), "wb") as f:
+        f.write(b"@r0 desc\nACGT\n+\nIIII\n@r1\nGGGTTT\n+r1\n@@@+++\n@r2/1\nAC\nGT\n+\nII\nII\n")
+    s = host.read_sequences(str(fq))
+    assert [s.name(i) for i in range(s.n)] == ["r0", "r1", "r2/1"]
+    assert [s.seq(i) for i in range(s.n)] == [b"ACGT", b"GGGTTT", b"ACGT"]
+    assert [s.qual(i) for i in range(s.n)] == [b"IIII", b"@@@+++", b"IIII"]
+    s2 = host.read_sequences(str(fq), max_seqs=2)
+    assert s2.n == 2
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r0\nACGT\n+\nII\n")
+    with pytest.raises(ValueError):
+        host.read_sequences(str(bad))
+
+
+def test_index_file_is_byte_compatible(tmp_path):
+    rng = np.random.default_rng(2)
+    ref = fo.Reference([util.rand_seq(rng, 30_000), util.rand_seq(rng, 999)])
+    idx = fo.OracleIndex(ref)
+    a, b = str(tmp_path / "a.idx"), str(tmp_path / "b.idx")
+    idx.save(a)
+    host.index_save(b, 12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    assert open(a, "rb").read() == open(b, "rb").read()
+    k, step, lookup, occ = host.index_load(a)
+    assert (k, step) == (12, 3)
+    assert np.array_equal(lookup, idx.lookup) and np.array_equal(occ, idx.occ[:idx.n_occ])
+
+
+def test_synthetic_generator_is_reproducible_and_shardable():
+    text, off, lens = host.synth_reference(5, [200_000, 50_000, 70], threads=4)
+    text2, _, _ = host.synth_reference(5, [200_000, 50_000, 70], threads=1)
+    assert np.array_equal(text, text2)
+    body = text[:int(lens.sum())]
+    assert set(np.unique(body).tolist()) == {65, 67, 71, 84}
+    counts = np.bincount(body, minlength=256)[[65, 67, 71, 84]] / len(body)
+    assert np.all(np.abs(counts - 0.25) < 0.01)
+    bases, offs = host.synth_reads(9, text, off, lens, 1000, 100, 3, threads=4)
+    lo, _ = host.synth_reads(9, text, off, lens, 400, 100, 3, first_read=0, threads=2)
+    hi, _ = host.synth_reads(9, text, off, lens, 600, 100, 3, first_read=400, threads=3)
+    assert np.array_equal(bases[:40_000], lo[:40_000]) and np.array_equal(bases[40_000:100_000], hi[:60_000])
+    # the oracle maps most of them, on both strands
+    ref = fo.Reference([text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)])
+    idx = fo.OracleIndex(ref)
+    res = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offs), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    assert res.stats[1] > 750
+    assert 0.3 < np.mean(res.m_dir) < 0.7
