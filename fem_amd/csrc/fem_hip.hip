@@ -211,7 +211,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     s.per_read_cap = cap;
   }
   if (!s.d_cand) {
-    uint64_t want = std::max<uint64_t>(1u << 20, 2 * s.n_reads + (1u << 16));
+    uint64_t want = 2 * s.n_reads + (5u << 20);  // ~1 candidate per strand on typical data + chunk padding
     want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
     s.cand_cap = 0;
     size_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -673,6 +673,18 @@ int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per
   *gb_per_s = ms > 0 ? (2.0 * (double)bytes * iters) / (ms * 1e6) : 0.0;  // read + write
   return FEM_OK;
 }
+
+#ifdef FEM_STAMPS
+// diagnostic build only: read and clear the seed kernel's per-phase cycle totals
+int fem_dbg_stamps(uint64_t *out, int n) {
+  unsigned long long tmp[femk::kNumStamps];
+  if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(femk::g_stamp_cycles), sizeof tmp) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < femk::kNumStamps; ++i) out[i] = tmp[i];
+  memset(tmp, 0, sizeof tmp);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(femk::g_stamp_cycles), tmp, sizeof tmp);
+  return 0;
+}
+#endif
 
 int fem_dev_allreduce_stats(fem_dev *const *hs, int n, uint64_t *stats) {
   if (!hs || n <= 0 || !stats) return FEM_ERR_INVALID;

@@ -22,6 +22,8 @@ constexpr int kWave = 64;
 constexpr uint32_t kFlagCandOverflow = 1u;   // candidate output buffer too small
 constexpr uint32_t kFlagArenaOverflow = 2u;  // global arena too small
 constexpr uint32_t kFlagTooLarge = 4u;       // a single group exceeds 2^31 entries
+constexpr uint32_t kInvalidMeta = 0xFFFFFFFFu;  // padding slot in the candidate arrays (skipped by verify_kernel)
+constexpr uint32_t kSlotChunk = 256u;           // candidate slots a wave reserves per atomic on the shared cursor
 
 // Byte offsets (relative to a wave's LDS region) and capacities; filled by the host.
 struct SeedLayout {
@@ -73,6 +75,32 @@ struct Bufs {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Diagnostic build only (-DFEM_STAMPS, never the shipped library): per-phase cycle totals of the seed kernel.
+#ifdef FEM_STAMPS
+constexpr int kNumStamps = 12;
+__device__ unsigned long long g_stamp_cycles[kNumStamps];
+struct Prof {
+  unsigned long long acc[kNumStamps] = {};
+  unsigned long long last = 0;
+  __device__ void start() { last = __builtin_amdgcn_s_memtime(); }
+  __device__ void mark(int id) {
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[id] += t - last;
+    last = t;
+  }
+  __device__ void flush() {
+    if (lane_id() == 0)
+      for (int i = 0; i < kNumStamps; ++i) atomicAdd(&g_stamp_cycles[i], acc[i]);
+  }
+};
+#define STAMP_START(p) (p).start()
+#define STAMP(p, id) (p).mark(id)
+#else
+struct Prof {};
+#define STAMP_START(p) ((void)0)
+#define STAMP(p, id) ((void)0)
+#endif
 
 // Wave-synchronous ordering of LDS traffic: DS operations of one wave execute in
 // order, so only the compiler has to be kept from moving them.
@@ -143,7 +171,7 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const T *x, uint32_t lo, uin
 // ---------------------------------------------------------------------------
 template <bool GLOBAL>
 __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [step][R] of this strand */,
-                                 uint32_t *rb, const Bufs &b, uint64_t **result) {
+                                 uint32_t *rb, const Bufs &b, uint64_t **result, Prof &prof) {
   const uint32_t ln = lane_id();
   const uint64_t lt_mask = (1ull << ln) - 1ull;
   const int R = p.R;
@@ -198,6 +226,7 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
     }
     if (too_big) return 0xFFFFFFFEu;
     if (n > b.xcap) return 0xFFFFFFFFu;
+    STAMP(prof, 4);
 
     // ---- additional_qgram_filter (src/filter.c:118-131): v survives iff at least a+1 staged values lie
     //      in [v, v+e] (itself included); duplicates never survive the greedy pass below, so the set is enough.
@@ -243,6 +272,7 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
       }
       if (nF > b.fcap) return 0xFFFFFFFFu;
     }
+    STAMP(prof, 5);
 
     // ---- sort F (R sorted runs) into X by rank ----
     if (nF > 0) {
@@ -292,16 +322,30 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
       nA = nB;
       wave_sync<GLOBAL>();
     }
+    STAMP(prof, 6);
     // nF == 0: greedy(merge(cand, {})) == cand, because cand already satisfies the gap rule
   }
   *result = A;
   return nA;
 }
 
+// Candidate slots are handed out from one global cursor.  One returning atomic per (read, strand) on a single
+// address tops out near 90 M/s on this chip, so each wave reserves kSlotChunk slots at a time and fills them
+// locally; what is left of a chunk when the wave moves on is padded with kInvalidMeta.
+struct SlotChunk {
+  uint32_t next = 0, left = 0;
+};
+
+__device__ __forceinline__ void pad_chunk(const SeedParams &p, SlotChunk &ch) {
+  for (uint32_t i = lane_id(); i < ch.left; i += kWave)
+    if ((unsigned long long)ch.next + i < p.cand_cap) p.cand_meta[ch.next + i] = kInvalidMeta;
+  ch.left = 0;
+}
+
 // remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel
 template <bool GLOBAL>
 __device__ void clip_and_emit(const SeedParams &p, uint32_t read, uint32_t strand, uint32_t L, const uint64_t *list,
-                              uint32_t n, uint64_t *tmp, unsigned long long &cand_sum) {
+                              uint32_t n, uint64_t *tmp, unsigned long long &cand_sum, SlotChunk &ch) {
   const uint32_t ln = lane_id();
   const uint64_t lt_mask = (1ull << ln) - 1ull;
   uint32_t kept = 0;
@@ -322,8 +366,17 @@ __device__ void clip_and_emit(const SeedParams &p, uint32_t read, uint32_t stran
   }
   uint32_t base = 0;
   if (kept > 0) {
-    if (ln == 0) base = atomicAdd(&p.ctr[0], kept);
-    base = bcast0(base);
+    if (kept <= ch.left) {
+      base = ch.next;
+      ch.next += kept, ch.left -= kept;
+    } else {
+      // long lists get an exact reservation and leave the current chunk alone
+      uint32_t want = kept > kSlotChunk / 2 ? kept : kSlotChunk;
+      if (want == kSlotChunk) pad_chunk(p, ch);
+      if (ln == 0) base = atomicAdd(&p.ctr[0], want);
+      base = bcast0(base);
+      if (want == kSlotChunk) ch.next = base + kept, ch.left = kSlotChunk - kept;
+    }
     if ((unsigned long long)base + kept > p.cand_cap) {
       if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
     } else {
@@ -368,11 +421,14 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
   const uint32_t hash_mask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
   const uint32_t smax = p.lay.smax, cmax = p.lay.cmax, cw = p.lay.cw;
   unsigned long long pre_sum = 0, cand_sum = 0;
+  SlotChunk chunk;
+  Prof prof;
 
   const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t n_waves = gridDim.x * waves_per_block;
 
   for (uint32_t read = wave_global; read < p.n_reads; read += n_waves) {
+    STAMP_START(prof);
     const uint64_t off = p.read_off[read];
     const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
     const uint8_t *seq = p.bases + off;
@@ -436,6 +492,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       wave_sync_lds();
     }
     const bool strand_ok[2] = {n_fwd_amb <= (uint32_t)p.e, n_rev_amb <= (uint32_t)p.e};  // src/filter.c:180-182
+    STAMP(prof, 0);
 
     // ---- hashes + CSR lookups (src/utils.h:101-117, src/index.h:22-28); lane j owns seed j of the forward
     //      strand and seed S-1-j of the reverse strand (the reverse complement of the same k-mer) ----
@@ -459,6 +516,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       }
     }
     wave_sync_lds();
+    STAMP(prof, 1);
 
     // ---- seed selection DP (src/filter.c:3-43), one lane per (strand, phase group) ----
     uint32_t pre_g = 0;
@@ -517,6 +575,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       }
     }
     wave_sync_lds();
+    STAMP(prof, 2);
 
     // ---- per strand: lists, filter, de-dup, clip, emit ----
     for (uint32_t strand = 0; strand < 2; ++strand) {
@@ -539,9 +598,10 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       pre_sum += pre;
       const Picked *pk = picked + (size_t)strand * (uint32_t)step * (uint32_t)R;
       uint64_t *list = nullptr;
-      uint32_t n = strand_lists<false>(p, pk, rb, lds, &list);
+      STAMP(prof, 3);
+      uint32_t n = strand_lists<false>(p, pk, rb, lds, &list, prof);
       if (n < 0xFFFFFFFEu) {
-        clip_and_emit<false>(p, read, strand, L, list, n, list == lds.A ? lds.B : lds.A, cand_sum);
+        clip_and_emit<false>(p, read, strand, L, list, n, list == lds.A ? lds.B : lds.A, cand_sum, chunk);
       } else if (n == 0xFFFFFFFEu) {
         if (ln == 0) atomicOr(&p.ctr[1], kFlagTooLarge);
       } else {
@@ -568,17 +628,22 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
           g.B = g.A + pre_wide + 2;
           g.xcap = pre_max + 1u, g.fcap = pre_max + 1u;
           g.ccap = pre_wide > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pre_wide + 1u;
-          uint32_t n2 = strand_lists<true>(p, pk, rb, g, &list);
+          uint32_t n2 = strand_lists<true>(p, pk, rb, g, &list, prof);
           if (n2 < 0xFFFFFFFEu) {
-            clip_and_emit<true>(p, read, strand, L, list, n2, list == g.A ? g.B : g.A, cand_sum);
+            clip_and_emit<true>(p, read, strand, L, list, n2, list == g.A ? g.B : g.A, cand_sum, chunk);
           } else {
             if (ln == 0) atomicOr(&p.ctr[1], kFlagTooLarge);
           }
         }
       }
       wave_sync_lds();
+      STAMP(prof, 7);
     }
   }
+  pad_chunk(p, chunk);
+#ifdef FEM_STAMPS
+  prof.flush();
+#endif
   if (ln == 0) {
     if (pre_sum) atomicAdd(&p.stats[0], pre_sum);
     if (cand_sum) atomicAdd(&p.stats[1], cand_sum);
@@ -616,8 +681,12 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
     uint32_t i = i0 + threadIdx.x;
     bool active = i < total;
     bool accepted = false, first_of_read = false;
+    uint32_t meta = active ? p.cand_meta[i] : kInvalidMeta;
+    if (meta == kInvalidMeta) {
+      if (active) p.ed[i] = 0xFF, p.end[i] = 0;
+      active = false;
+    }
     if (active) {
-      const uint32_t meta = p.cand_meta[i];
       const uint32_t read = meta >> 1, strand = meta & 1u;
       const uint64_t c = p.cand[i];
       const uint8_t *pat = p.ref_codes + p.seq_off[(uint32_t)(c >> 32)] + (uint32_t)c;

@@ -67,7 +67,7 @@ typedef struct {
  * a Mapping, src/align.c:22,40). */
 typedef struct {
   uint64_t n_reads;
-  uint64_t n_candidates;
+  uint64_t n_candidates; /* slots in cand/ed/end; includes padding slots that no (read, strand) refers to */
   const uint32_t *cand_begin; /* 2*n_reads */
   const uint32_t *cand_count; /* 2*n_reads */
   const uint64_t *cand;       /* n_candidates: seq<<32 | (pos - e) */
