@@ -162,7 +162,7 @@ femk::SeedLayout make_layout(const fem_params &p, uint32_t max_len) {
   l.nkw = take(l.n_words * 4u);
   l.sf = take(2u * smax * 8u);
   l.dp_rows = take(n_groups * 2u * cmax * 4u);
-  l.dp_bits = take(n_groups * R * l.cw * 4u);
+  l.dp_bits = take(std::max(n_groups * R * l.cw * 4u, n_groups * R * 8u));  // serial form: bit rows; DPP form: one ballot per row
   l.picked = take(n_groups * R * 16u);
   l.rb = take(2u * (R + 1u) * 4u);
   l.X = take(l.xcap * 8u);

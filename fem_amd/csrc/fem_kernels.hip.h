@@ -394,6 +394,310 @@ __device__ void clip_and_emit(const SeedParams &p, uint32_t read, uint32_t stran
   cand_sum += kept;
 }
 
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// Register-only form of one strand (src/filter.c:190-223) for the common case in
+// which the step*R selected seeds hold at most 64 occurrences in total: every
+// occurrence lives in one lane, the last-seed rule, the window filter and the
+// staged greedy de-dup run on wave-uniform scalars (v_readlane), and nothing is
+// staged in LDS except one 64-entry scatter.  Same results as strand_lists().
+// Returns false (nothing done) when the strand does not qualify.
+// ---------------------------------------------------------------------------
+__device__ bool strand_small(const SeedParams &p, const Picked *pk /* [step][R] */, uint64_t *scatter /* LDS, 64 */,
+                             uint32_t read, uint32_t strand, uint32_t L, unsigned long long &cand_sum,
+                             SlotChunk &ch) {
+  const uint32_t ln = lane_id();
+  const int R = p.R;
+  const uint32_t n_seeds = (uint32_t)(p.step * R);
+  if (n_seeds > (uint32_t)kWave) return false;
+  const uint64_t e64 = (uint64_t)p.e;
+  // lane s < n_seeds holds seed s = (group, run)
+  uint32_t s_start = 0, s_lo = 0, s_freq = 0, s_grp = 0, s_run = 0;
+  if (ln < n_seeds) {
+    Picked q = pk[ln];
+    s_start = q.start, s_lo = q.lo, s_freq = q.freq;
+    s_grp = ln / (uint32_t)R, s_run = ln - s_grp * (uint32_t)R;
+  }
+  const uint64_t nonempty = __ballot(s_freq > 0);
+  uint32_t total = 0;
+  for (uint64_t m = nonempty; m;) {
+    int j = __builtin_ctzll(m);
+    m &= m - 1;
+    uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+    if (f > (uint32_t)kWave) return false;
+    total += f;
+  }
+  if (total > (uint32_t)kWave) return false;
+
+  uint32_t kept = 0;
+  uint64_t cv = 0;  // lane i holds candidate i of the strand (sorted, before the range clip)
+  if (total > (uint32_t)p.a) {
+    // ---- one occurrence per lane, runs in (group, run) order = the order of the staged lists ----
+    bool valid = false;
+    uint64_t v = 0;
+    uint32_t grp = 0, run = 0;
+    {
+      uint32_t at = 0;
+      for (uint64_t m = nonempty; m;) {
+        int j = __builtin_ctzll(m);
+        m &= m - 1;
+        uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
+        uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
+        uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)s_grp, j);
+        uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)s_run, j);
+        if (ln >= at && ln < at + f) {
+          uint64_t o = p.occ[(uint64_t)lo + (ln - at)];
+          valid = (uint32_t)o >= st;  // src/filter.c:89,106
+          v = o - st;
+          grp = gj, run = rj;
+        }
+        at += f;
+      }
+    }
+    // ---- last seed of each group: only values <= max of the other runs survive (src/filter.c:85) ----
+    for (uint32_t g = 0; g < (uint32_t)p.step; ++g) {
+      bool is_last = valid && grp == g && run == (uint32_t)(R - 1);
+      if (!__ballot(is_last)) continue;
+      uint64_t mu = __ballot(valid && grp == g && run != (uint32_t)(R - 1));
+      uint64_t max_u = 0;
+      for (uint64_t m = mu; m;) {
+        int j = __builtin_ctzll(m);
+        m &= m - 1;
+        uint64_t x = readlane64(v, j);
+        max_u = x > max_u ? x : max_u;
+      }
+      if (is_last && (mu == 0 || v > max_u)) valid = false;
+    }
+    // ---- additional_qgram_filter (src/filter.c:118-131): >= a+1 values of the same group in [v, v+e] ----
+    const uint64_t vm = __ballot(valid);
+    bool pass = false;
+    if ((uint32_t)__popcll(vm) > (uint32_t)p.a) {
+      uint32_t cnt = 0;
+      for (uint64_t m = vm; m;) {
+        int j = __builtin_ctzll(m);
+        m &= m - 1;
+        uint64_t x = readlane64(v, j);
+        uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)grp, j);
+        cnt += (uint32_t)(gj == grp && x >= v && x <= v + e64);
+      }
+      pass = valid && cnt > (uint32_t)p.a;
+    }
+    // ---- merge_kvec_t_uint64_t (src/filter.c:45-78), group after group ----
+    if (__ballot(pass)) {
+      uint32_t nA = 0;
+      for (uint32_t g = 0; g < (uint32_t)p.step; ++g) {
+        const bool mine = pass && grp == g;
+        const uint64_t mf = __ballot(mine);
+        const uint32_t nF = (uint32_t)__popcll(mf);
+        if (nF == 0) continue;
+        uint32_t rank = 0;  // position of v among this group's survivors
+        for (uint64_t m = mf; m;) {
+          int j = __builtin_ctzll(m);
+          m &= m - 1;
+          uint64_t x = readlane64(v, j);
+          rank += (uint32_t)(x < v || (x == v && (uint32_t)j < ln));
+        }
+        wave_sync_lds();
+        if (mine) scatter[rank] = v;
+        wave_sync_lds();
+        const uint64_t fs = ln < nF ? scatter[ln] : 0;
+        uint64_t merged = 0, last_kept = 0;
+        uint32_t nB = 0, ia = 0, jf = 0;
+        while (ia < nA || jf < nF) {  // wave-uniform two-pointer merge + greedy gap rule
+          uint64_t xa = readlane64(cv, (int)(ia < nA ? ia : 0));
+          uint64_t xf = readlane64(fs, (int)(jf < nF ? jf : 0));
+          bool take_a = ia < nA && (jf >= nF || xa < xf);
+          uint64_t x = take_a ? xa : xf;
+          ia += take_a ? 1u : 0u;
+          jf += take_a ? 0u : 1u;
+          if (nB == 0 || x > last_kept + e64) {
+            merged = ln == nB ? x : merged;
+            ++nB;
+            last_kept = x;
+          }
+        }
+        cv = merged;
+        nA = nB;
+      }
+      kept = nA;
+    }
+  }
+  // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over ----
+  bool ok = false;
+  if (ln < kept) {
+    uint32_t seq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
+    uint32_t slen = p.seq_len[seq];
+    ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+  }
+  const uint64_t mo = __ballot(ok);
+  const uint32_t n_out = (uint32_t)__popcll(mo);
+  uint32_t base = 0;
+  if (n_out > 0) {
+    if (n_out <= ch.left) {
+      base = ch.next;
+      ch.next += n_out, ch.left -= n_out;
+    } else {
+      pad_chunk(p, ch);
+      if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+      base = bcast0(base);
+      ch.next = base + n_out, ch.left = kSlotChunk - n_out;
+    }
+    if ((unsigned long long)base + n_out > p.cand_cap) {
+      if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+    } else if (ok) {
+      uint32_t at = base + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
+      p.cand[at] = cv - e64;
+      p.cand_meta[at] = read * 2u + strand;
+    }
+  }
+  if (ln == 0) {
+    p.cand_begin[read * 2u + strand] = base;
+    p.cand_count[read * 2u + strand] = n_out;
+  }
+  cand_sum += n_out;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Seed selection DP (src/filter.c:3-43) with the columns of a group spread over a
+// lane segment of width W (16, 32 or 64, aligned): row r is
+//     M[r][c] = min(M[r][c-1], M[r-1][c] + f)   with M[r][0] = +inf,
+// i.e. an exclusive prefix-min of v[c] = M[r-1][c] + f inside the segment, done with
+// DPP row shifts (+ row_bcast for W > 16): no LDS round trip per step.
+// D[r][c] == 2 ("take") iff v[c] is strictly below that prefix-min; the take bits of
+// a row are one ballot.  The traceback (src/filter.c:30-41) then needs R steps per
+// group: the chosen column of row r is the highest take bit at or below the column
+// chosen for row r+1.  Needs columns <= 64 per group and groups*R <= 64 lanes for the
+// rank sort; otherwise the caller uses the one-lane-per-group form.
+// Returns M[R][C-1] of group ln (lanes < 2*step).
+// ---------------------------------------------------------------------------
+constexpr int kMaxR = 10;  // e <= 7, a <= 2
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t x, uint32_t inf) {
+  uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)x, CTRL, ROW_MASK, 0xF, false);
+  return t < x ? t : x;
+}
+
+__device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *strand_ok, const uint2 *sf, uint32_t smax,
+                                     uint32_t W, unsigned long long *take_bits /* LDS [passes][R] */,
+                                     Picked *picked) {
+  const uint32_t ln = lane_id();
+  const int R = p.R, lg = p.lg, step = p.step;
+  const uint32_t n_groups = 2u * (uint32_t)step;
+  const uint32_t per_pass = (uint32_t)kWave / W;
+  const uint32_t n_pass = (n_groups + per_pass - 1u) / per_pass;
+  const uint32_t c = ln & (W - 1u), slot = ln / W;
+  const uint32_t inf = p.inf32;
+  uint32_t pre_mine = 0;
+  // the group whose traceback this lane does (lanes < n_groups)
+  const uint32_t own_strand = ln / (uint32_t)step, own_si = ln % (uint32_t)step;
+  const uint32_t own_ncols = (ln < n_groups && strand_ok[own_strand & 1u])
+                                 ? (uint32_t)((S - (int)own_si) / step - R * lg + 1) : 0u;  // C - 1
+  for (uint32_t ps = 0; ps < n_pass; ++ps) {
+    const uint32_t g = ps * per_pass + slot;
+    const uint32_t strand = g / (uint32_t)step, si = g % (uint32_t)step;
+    const bool g_ok = g < n_groups && strand_ok[strand & 1u];
+    const uint32_t ncols = g_ok ? (uint32_t)((S - (int)si) / step - R * lg + 1) : 0u;
+    const bool in_seg = c < ncols;
+    const uint2 *sfs = sf + (strand & 1u) * smax;
+    uint32_t f[kMaxR];
+#pragma unroll
+    for (int r = 1; r <= kMaxR; ++r)  // all LDS reads of the pass in flight together
+      f[r - 1] = (r <= R && in_seg) ? sfs[si + (uint32_t)step * (c + (uint32_t)((r - 1) * lg))].y : 0u;
+    uint32_t M = 0;  // M[0][c] = 0
+#pragma unroll
+    for (int r = 1; r <= kMaxR; ++r) {
+      if (r <= R) {
+        const uint32_t v = M + f[r - 1];  // uint32 wrap as in the reference
+        uint32_t x = in_seg ? v : inf;    // lanes outside a segment must not disturb the min
+        x = dpp_min_step<0x111, 0xF>(x, inf);  // row_shr:1
+        x = dpp_min_step<0x112, 0xF>(x, inf);  // row_shr:2
+        x = dpp_min_step<0x114, 0xF>(x, inf);  // row_shr:4
+        x = dpp_min_step<0x118, 0xF>(x, inf);  // row_shr:8
+        if (W > 16u) x = dpp_min_step<0x142, 0xA>(x, inf);  // row_bcast:15 into rows 1 and 3
+        if (W > 32u) x = dpp_min_step<0x143, 0xC>(x, inf);  // row_bcast:31 into rows 2 and 3
+        uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
+        ex = (c == 0 || ex > inf) ? inf : ex;  // M[r][0] = (uint32)occurrence_table_size
+        const bool take = in_seg && v < ex;    // strict: ties go horizontal (src/filter.c:20)
+        M = take ? v : ex;
+        const unsigned long long bits = __ballot(take);
+        if (ln == 0) take_bits[ps * (uint32_t)R + (uint32_t)(r - 1)] = bits;
+      }
+    }
+    // M[R][C-1] of the group this lane will trace
+    const uint32_t own_pass = ln / per_pass, own_slot = ln % per_pass;
+    const uint32_t src = own_slot * W + (own_ncols ? own_ncols - 1u : 0u);
+    const uint32_t got = __shfl(M, (int)src);
+    if (ln < n_groups && own_pass == ps) pre_mine = got;
+  }
+  wave_sync_lds();
+  // traceback, one lane per group
+  if (ln < n_groups) {
+    Picked *out = picked + (size_t)ln * (uint32_t)R;
+    const uint32_t own_pass = ln / per_pass, own_slot = ln % per_pass;
+    unsigned long long rows[kMaxR];
+#pragma unroll
+    for (int r = 1; r <= kMaxR; ++r) rows[r - 1] = (r <= R && own_ncols) ? take_bits[own_pass * (uint32_t)R + (uint32_t)(r - 1)] : 0ull;
+    const uint2 *sfo = sf + (own_strand & 1u) * smax;
+    int col = (int)own_ncols - 1, n_out = 0;
+    bool alive = own_ncols != 0;
+    uint32_t sidx[kMaxR];
+#pragma unroll
+    for (int r = kMaxR; r >= 1; --r) {
+      sidx[r - 1] = 0xFFFFFFFFu;
+      if (r <= R && alive) {
+        unsigned long long seg = (rows[r - 1] >> (own_slot * W)) & ((2ull << col) - 1ull);
+        if (seg == 0) {
+          alive = false;  // reached column 0 before taking R seeds (UB in reference): the rest stay zero
+        } else {
+          col = 63 - __builtin_clzll(seg);
+          sidx[r - 1] = own_si + (uint32_t)step * (uint32_t)(col + (r - 1) * lg);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = kMaxR; r >= 1; --r) {  // picked in traceback order: row R first
+      if (r <= R) {
+        Picked q{0, 0, 0, 0};
+        if (sidx[r - 1] != 0xFFFFFFFFu) {
+          uint2 s2 = sfo[sidx[r - 1]];
+          q = Picked{sidx[r - 1], s2.x, s2.y, 0};
+        }
+        // rows that were never reached come after the taken ones, as zeros
+        int slot_out = sidx[r - 1] != 0xFFFFFFFFu ? n_out++ : -1;
+        if (slot_out >= 0) out[slot_out] = q;
+      }
+    }
+    for (int t = n_out; t < R; ++t) out[t] = Picked{0, 0, 0, 0};
+  }
+  wave_sync_lds();
+  // qsort(compare_seed) (src/filter.c:204): stable by ascending frequency, as a rank sort with lane = (group, seed)
+  {
+    const uint32_t g = ln / (uint32_t)R, t = ln - g * (uint32_t)R;
+    const bool act = ln < n_groups * (uint32_t)R;
+    Picked mine{0, 0, 0, 0};
+    uint32_t rank = 0;
+    if (act) {
+      const Picked *grp = picked + (size_t)g * (uint32_t)R;
+      mine = grp[t];
+      for (uint32_t u = 0; u < (uint32_t)R; ++u) {
+        uint32_t fu = grp[u].freq;
+        rank += (uint32_t)(fu < mine.freq || (fu == mine.freq && u < t));
+      }
+    }
+    wave_sync_lds();
+    if (act) picked[(size_t)g * (uint32_t)R + rank] = mine;
+  }
+  return pre_mine;
+}
+
 // ---------------------------------------------------------------------------
 // seed + filter kernel: one wave per read, grid-stride over the batch
 // ---------------------------------------------------------------------------
@@ -518,9 +822,17 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
     wave_sync_lds();
     STAMP(prof, 1);
 
-    // ---- seed selection DP (src/filter.c:3-43), one lane per (strand, phase group) ----
+    // ---- seed selection DP (src/filter.c:3-43): columns over lanes when all groups fit in one wave,
+    //      else one lane per (strand, phase group) ----
     uint32_t pre_g = 0;
-    if (ln < 2u * (uint32_t)step && strand_ok[ln / (uint32_t)step]) {
+    uint32_t dp_w = 0;  // lane segment per group: 16, 32 or 64; 0 = does not fit
+    if (2u * (uint32_t)step * (uint32_t)R <= (uint32_t)kWave && R <= kMaxR) {
+      uint32_t widest = (uint32_t)(S / step - R * lg + 1);  // phase 0 has the most columns
+      dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : widest <= 64u ? 64u : 0u;
+    }
+    if (dp_w) {
+      pre_g = select_seeds_dpp(p, S, strand_ok, sf, smax, dp_w, (unsigned long long *)dp_bits, picked);
+    } else if (ln < 2u * (uint32_t)step && strand_ok[ln / (uint32_t)step]) {
       const uint32_t strand = ln / (uint32_t)step, si = ln % (uint32_t)step;
       const int G = (S - (int)si) / step;
       const int C = G - R * lg + 2;  // num_columns
@@ -599,6 +911,10 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       const Picked *pk = picked + (size_t)strand * (uint32_t)step * (uint32_t)R;
       uint64_t *list = nullptr;
       STAMP(prof, 3);
+      if (strand_small(p, pk, lds.X, read, strand, L, cand_sum, chunk)) {
+        STAMP(prof, 8);
+        continue;
+      }
       uint32_t n = strand_lists<false>(p, pk, rb, lds, &list, prof);
       if (n < 0xFFFFFFFEu) {
         clip_and_emit<false>(p, read, strand, L, list, n, list == lds.A ? lds.B : lds.A, cand_sum, chunk);
@@ -671,6 +987,40 @@ struct VerifyParams {
   unsigned long long *stats;   // [2] mappings, [3] mapped reads
 };
 
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+  uint32_t w;
+  __builtin_memcpy(&w, p, 4);  // gfx950 global loads take any byte address
+  return w;
+}
+
+// One column of the banded Myers recurrence (src/align.c:118-133).  pc = code of the reference base that enters
+// the band, tc = code of the read base.  B0..B2 are the bit planes of the pattern window (bit j = bit q of
+// code(pattern[col + j])), so Peq[tc] is a three-way XNOR instead of a five-entry table.
+struct MyersState {
+  uint32_t B0, B1, B2, VP, VN;
+  int score;
+};
+__device__ __forceinline__ bool myers_column(MyersState &m, uint32_t pc, uint32_t tc, int e, uint32_t band, uint32_t wm) {
+  const int sh = 2 * e;
+  m.B0 |= (pc & 1u) << sh;
+  m.B1 |= ((pc >> 1) & 1u) << sh;
+  m.B2 |= ((pc >> 2) & 1u) << sh;
+  uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
+  uint32_t eq = ~((m.B0 ^ m0) | (m.B1 ^ m1) | (m.B2 ^ m2)) & band;  // Peq[text[col]]
+  uint32_t X = eq | m.VN;
+  uint32_t D0 = ((((X & m.VP) + m.VP) ^ m.VP) | X) & wm;
+  uint32_t HN = m.VP & D0;
+  uint32_t HP = (m.VN | ~(m.VP | D0)) & wm;
+  X = D0 >> 1;
+  m.VN = X & HP;
+  m.VP = (HN | ~(X | HP)) & wm;
+  m.score += 1 - (int)(D0 & 1u);
+  m.B0 >>= 1;
+  m.B1 >>= 1;
+  m.B2 >>= 1;
+  return m.score > 3 * e;  // src/align.c:128-130; the SSE lanes run on but end up rejected as well
+}
+
 __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   const uint32_t total = min(p.ctr[0], p.cand_cap);
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -698,51 +1048,57 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
       const uint32_t rank = i - p.cand_begin[meta];
       const uint32_t n_here = p.cand_count[meta];
       const uint32_t wm = rank < (n_here & ~7u) ? 0xFFFFu : 0xFFFFFFFFu;
-      // bit planes of the pattern window: bit j of Bq = bit q of code(pattern[i + j])
-      uint32_t B0 = 0, B1 = 0, B2 = 0;
-      for (int j = 0; j < 2 * e; ++j) {
+      MyersState m{0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < 2 * e; ++j) {  // prime the window with pattern[0 .. 2e)
         uint32_t pc = pat[j];
-        B0 |= (pc & 1u) << j;
-        B1 |= ((pc >> 1) & 1u) << j;
-        B2 |= ((pc >> 2) & 1u) << j;
+        m.B0 |= (pc & 1u) << j;
+        m.B1 |= ((pc >> 1) & 1u) << j;
+        m.B2 |= ((pc >> 2) & 1u) << j;
       }
-      uint32_t VP = 0, VN = 0;
-      int score = 0;
       bool rejected = false;
-      for (int col = 0; col < L; ++col) {
-        uint32_t pc = pat[col + 2 * e];
-        B0 |= (pc & 1u) << (2 * e);
-        B1 |= ((pc >> 1) & 1u) << (2 * e);
-        B2 |= ((pc >> 2) & 1u) << (2 * e);
+      // four columns per step; the loads of the next step are issued before this step's arithmetic
+      const int n_full = L & ~3;
+      const uint8_t *pp = pat + 2 * e;
+      uint32_t pw = 0, rw = 0;
+      if (n_full > 0) {
+        pw = load_u32_unaligned(pp);
+        rw = load_u32_unaligned(strand == 0 ? rd : rd + L - 4);
+      }
+      for (int col = 0; col < n_full && !rejected; col += 4) {
+        const uint32_t pw_cur = pw, rw_cur = rw;
+        if (col + 4 < n_full) {
+          pw = load_u32_unaligned(pp + col + 4);
+          rw = load_u32_unaligned(strand == 0 ? rd + col + 4 : rd + L - 8 - col);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t pc = (pw_cur >> (8 * q)) & 0xFFu;
+          uint32_t tc;
+          if (strand == 0) {
+            tc = base_code((rw_cur >> (8 * q)) & 0xFFu);
+          } else {  // prepare_negative_sequence_at (src/sequence_batch.h:90-98): read backwards, complement
+            tc = base_code((rw_cur >> (8 * (3 - q))) & 0xFFu);
+            tc = tc < 4u ? 3u - tc : 4u;
+          }
+          if (!rejected) rejected = myers_column(m, pc, tc, e, band, wm);
+        }
+      }
+      for (int col = n_full; col < L && !rejected; ++col) {  // up to three trailing columns
+        uint32_t pc = pp[col];
         uint32_t tc;
         if (strand == 0) {
           tc = base_code(rd[col]);
-        } else {  // prepare_negative_sequence_at (src/sequence_batch.h:90-98)
+        } else {
           tc = base_code(rd[L - 1 - col]);
           tc = tc < 4u ? 3u - tc : 4u;
         }
-        uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
-        uint32_t eq = ~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)) & band;  // Peq[text[col]]
-        uint32_t X = eq | VN;
-        uint32_t D0 = ((((X & VP) + VP) ^ VP) | X) & wm;
-        uint32_t HN = VP & D0;
-        uint32_t HP = (VN | ~(VP | D0)) & wm;
-        X = D0 >> 1;
-        VN = X & HP;
-        VP = (HN | ~(X | HP)) & wm;
-        score += 1 - (int)(D0 & 1u);
-        if (score > 3 * e) {  // src/align.c:128-130; the SSE lanes run on but end up rejected as well
-          rejected = true;
-          break;
-        }
-        B0 >>= 1;
-        B1 >>= 1;
-        B2 >>= 1;
+        rejected = myers_column(m, pc, tc, e, band, wm);
       }
+      int score = m.score;
       int best = score, endp = L - 1;
       if (!rejected) {
         for (int j = 0; j < 2 * e; ++j) {  // first strict minimum (src/align.c:135-146)
-          score += (int)((VP >> j) & 1u) - (int)((VN >> j) & 1u);
+          score += (int)((m.VP >> j) & 1u) - (int)((m.VN >> j) & 1u);
           if (score < best) {
             best = score;
             endp = L + j;
