@@ -8,12 +8,14 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "fem_index_build.hip.h"
 #include "fem_kernels.hip.h"
+#include "fem_seed_fast.hip.h"
 
 namespace {
 
@@ -50,6 +52,8 @@ struct Slot {
   uint8_t *h_ctl = nullptr;  // pinned mirror
   uint64_t *d_arena = nullptr;
   uint64_t arena_cap = 0;
+  uint32_t *d_slow = nullptr;  // reads the fast seed kernel leaves to the generic one
+  uint32_t slow_cap = 0;
   // pinned host results
   uint32_t *h_begin = nullptr, *h_count = nullptr;
   size_t h_per_read_cap = 0;
@@ -89,8 +93,9 @@ struct fem_dev {
   std::vector<uint32_t> seq_len;
   Slot slot[kSlots];
   bool timing = false;
-  double t_ms[2] = {0, 0};
-  uint64_t t_n[2] = {0, 0};
+  double t_ms[3] = {0, 0, 0};
+  uint64_t t_n[3] = {0, 0, 0};
+  bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   std::vector<hipEvent_t> event_pool;
 };
 
@@ -173,6 +178,35 @@ femk::SeedLayout make_layout(const fem_params &p, uint32_t max_len) {
   return l;
 }
 
+// LDS of one wave of seed_fast_kernel: packed bases, (lookup, frequency) per seed, DP take bits, selected seeds, scatter
+femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len) {
+  femk::SeedLayout l{};
+  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
+  const uint32_t n_groups = 2u * (uint32_t)p.step;
+  l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
+  l.n_words = (max_len + 15u) / 16u + 2u;
+  l.xcap = 64;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  l.pkw = take(l.n_words * 4u);
+  l.nkw = take(l.n_words * 4u);
+  l.sf = take(2u * l.smax * 8u);
+  l.dp_bits = take(n_groups * R * 8u);
+  l.picked = take(n_groups * R * 16u);
+  l.X = take(l.xcap * 8u);
+  l.wave_bytes = o;
+  return l;
+}
+
+template <int R>
+void launch_fast(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL(femk::seed_fast_kernel<R>, grid, block, lds, st, sp);
+}
+
 hipEvent_t get_event(fem_dev *h) {
   if (!h->event_pool.empty()) {
     hipEvent_t e = h->event_pool.back();
@@ -230,6 +264,18 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     s.arena_cap = 4u << 20;  // entries (32 MiB); grown on demand
     HIP_TRY(h, hipMalloc((void **)&s.d_arena, s.arena_cap * sizeof(uint64_t)));
   }
+  {
+    // With long occurrence lists (large references) nearly every read overflows the lanes of the fast kernel
+    // and is queued; with short ones almost none is.  Size the queue for the likely case, grow + re-run otherwise.
+    const double avg_bucket = (double)h->n_occ / (double)(h->n_lookup ? h->n_lookup : 1);
+    uint64_t want = avg_bucket > 1.0 ? s.n_reads + (1u << 20) : (1u << 18);
+    if (want > s.slow_cap || !s.d_slow) {
+      if (s.d_slow) (void)hipFree(s.d_slow);
+      s.d_slow = nullptr;
+      HIP_TRY(h, hipMalloc((void **)&s.d_slow, want * sizeof(uint32_t)));
+      s.slow_cap = (uint32_t)want;
+    }
+  }
   return FEM_OK;
 }
 
@@ -272,25 +318,68 @@ int launch_batch(fem_dev *h, Slot &s) {
   sp.arena = s.d_arena, sp.arena_cap = s.arena_cap, sp.arena_ctr = d_arena_ctr;
   sp.lay = make_layout(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
 
-  uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / sp.lay.wave_bytes));
-  if (sp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
-  uint32_t lds_bytes = wpb * sp.lay.wave_bytes;
-  uint32_t waves_per_cu = std::min<uint32_t>(32u, (160u * 1024u / lds_bytes) * wpb);
-  uint64_t blocks_wanted = (s.n_reads + wpb - 1) / wpb;
-  uint64_t blocks_resident = (uint64_t)h->n_cu * std::max<uint32_t>(1u, waves_per_cu / wpb);
-  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks_wanted, blocks_resident * 4));
+  sp.n_seq = h->n_seq;
+  sp.slow_queue = s.d_slow, sp.slow_cap = s.slow_cap;
+  sp.work_queue = nullptr;
+  const int R = p.e + 1 + p.a;
+  const bool use_fast = !h->force_generic && p.k == femk::kK && p.step == femk::kStep && R >= 1 && R <= femk::kMaxR;
 
-  TimedLaunch t0{0, nullptr, nullptr}, t1{1, nullptr, nullptr};
-  if (s.n_reads) {
+  auto shape = [&](const femk::SeedLayout &lay, uint32_t *wpb_out, uint32_t *lds_out, uint32_t *grid_out) {
+    uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / lay.wave_bytes));
+    uint32_t lds_bytes = wpb * lay.wave_bytes;
+    uint32_t waves_per_cu = std::min<uint32_t>(32u, (160u * 1024u / lds_bytes) * wpb);
+    uint64_t blocks_wanted = (s.n_reads + wpb - 1) / wpb;
+    uint64_t blocks_resident = (uint64_t)h->n_cu * std::max<uint32_t>(1u, waves_per_cu / wpb);
+    *wpb_out = wpb, *lds_out = lds_bytes;
+    *grid_out = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks_wanted, blocks_resident * 4));
+  };
+  if (sp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
+
+  auto timed = [&](int id, auto &&launch) -> int {
+    TimedLaunch t{id, nullptr, nullptr};
     if (h->timing) {
-      t0.start = get_event(h), t0.stop = get_event(h);
-      HIP_TRY(h, hipEventRecord(t0.start, s.stream));
+      t.start = get_event(h), t.stop = get_event(h);
+      HIP_TRY(h, hipEventRecord(t.start, s.stream));
     }
-    hipLaunchKernelGGL(femk::seed_filter_kernel, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, sp);
+    launch();
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
-      HIP_TRY(h, hipEventRecord(t0.stop, s.stream));
-      s.pending.push_back(t0);
+      HIP_TRY(h, hipEventRecord(t.stop, s.stream));
+      s.pending.push_back(t);
+    }
+    return FEM_OK;
+  };
+
+  if (s.n_reads) {
+    int rc;
+    if (use_fast) {
+      femk::SeedParams fp = sp;
+      fp.lay = make_layout_fast(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
+      uint32_t wpb, lds_bytes, grid;
+      shape(fp.lay, &wpb, &lds_bytes, &grid);
+      rc = timed(0, [&] {
+        dim3 g(grid), b(64u * wpb);
+        switch (R) {
+          case 1: launch_fast<1>(g, b, lds_bytes, s.stream, fp); break;
+          case 2: launch_fast<2>(g, b, lds_bytes, s.stream, fp); break;
+          case 3: launch_fast<3>(g, b, lds_bytes, s.stream, fp); break;
+          case 4: launch_fast<4>(g, b, lds_bytes, s.stream, fp); break;
+          case 5: launch_fast<5>(g, b, lds_bytes, s.stream, fp); break;
+          case 6: launch_fast<6>(g, b, lds_bytes, s.stream, fp); break;
+          case 7: launch_fast<7>(g, b, lds_bytes, s.stream, fp); break;
+          case 8: launch_fast<8>(g, b, lds_bytes, s.stream, fp); break;
+          case 9: launch_fast<9>(g, b, lds_bytes, s.stream, fp); break;
+          default: launch_fast<10>(g, b, lds_bytes, s.stream, fp); break;
+        }
+      });
+      if (rc) return rc;
+      sp.work_queue = s.d_slow;  // the generic kernel finishes what the fast one queued
+    }
+    {
+      uint32_t wpb, lds_bytes, grid;
+      shape(sp.lay, &wpb, &lds_bytes, &grid);
+      rc = timed(2, [&] { hipLaunchKernelGGL(femk::seed_filter_kernel, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, sp); });
+      if (rc) return rc;
     }
 
     femk::VerifyParams vp{};
@@ -299,17 +388,9 @@ int launch_batch(fem_dev *h, Slot &s) {
     vp.cand = s.d_cand, vp.cand_meta = s.d_meta, vp.cand_begin = s.d_begin, vp.cand_count = s.d_count;
     vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
     vp.ed = s.d_ed, vp.end = s.d_end, vp.n_map = s.d_nmap, vp.stats = d_stats;
-    uint32_t vgrid = (uint32_t)h->n_cu * 8u;
-    if (h->timing) {
-      t1.start = get_event(h), t1.stop = get_event(h);
-      HIP_TRY(h, hipEventRecord(t1.start, s.stream));
-    }
-    hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing) {
-      HIP_TRY(h, hipEventRecord(t1.stop, s.stream));
-      s.pending.push_back(t1);
-    }
+    const uint32_t vgrid = (uint32_t)h->n_cu * 8u;
+    rc = timed(1, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
+    if (rc) return rc;
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.mapped = true;
@@ -363,6 +444,8 @@ int fem_dev_open(int device, fem_dev **out) {
       return FEM_ERR_HIP;
     }
   }
+  const char *fg = getenv("FEM_FORCE_GENERIC");
+  h->force_generic = fg && fg[0] == '1';
   *out = h;
   return FEM_OK;
 }
@@ -375,7 +458,7 @@ int fem_dev_close(fem_dev *h) {
     drain_timing(h, s);
     for (void *p : {(void *)s.d_bases, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
-                    (void *)s.d_arena})
+                    (void *)s.d_arena, (void *)s.d_slow})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
                     (void *)s.h_end})
@@ -551,6 +634,15 @@ int fem_dev_sync(fem_dev *h, int slot) {
       uint64_t want = (uint64_t)ctr[0] + ctr[0] / 8 + 1024;
       if ((rc = grow_candidates(h, s, std::min<uint64_t>(want, 0xFFFFFFF0ull)))) return rc;
     }
+    if (flags & femk::kFlagQueueOverflow) {
+      uint64_t want = (uint64_t)ctr[2] + ctr[2] / 8 + 4096;
+      (void)hipFree(s.d_slow);
+      s.d_slow = nullptr;
+      s.slow_cap = 0;
+      hipError_t e = hipMalloc((void **)&s.d_slow, want * sizeof(uint32_t));
+      if (e != hipSuccess) return fail(h, FEM_ERR_NOMEM, "slow-read queue does not fit in device memory");
+      s.slow_cap = (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull);
+    }
     if (flags & femk::kFlagArenaOverflow) {
       uint64_t want = arena_ctr[1] + arena_ctr[1] / 8 + 1024;
       (void)hipFree(s.d_arena);
@@ -634,13 +726,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
-  h->t_ms[0] = h->t_ms[1] = 0;
-  h->t_n[0] = h->t_n[1] = 0;
+  for (int i = 0; i < 3; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
   return FEM_OK;
 }
 
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
-  if (!h || kernel < 0 || kernel > 1) return FEM_ERR_INVALID;
+  if (!h || kernel < 0 || kernel > 2) return FEM_ERR_INVALID;
   if (ms_total) *ms_total = h->t_ms[kernel];
   if (launches) *launches = h->t_n[kernel];
   return FEM_OK;

@@ -24,6 +24,9 @@ constexpr uint32_t kFlagArenaOverflow = 2u;  // global arena too small
 constexpr uint32_t kFlagTooLarge = 4u;       // a single group exceeds 2^31 entries
 constexpr uint32_t kInvalidMeta = 0xFFFFFFFFu;  // padding slot in the candidate arrays (skipped by verify_kernel)
 constexpr uint32_t kSlotChunk = 256u;           // candidate slots a wave reserves per atomic on the shared cursor
+constexpr uint32_t kFlagQueueOverflow = 8u;     // slow-read queue too small
+constexpr uint32_t kQueueChunk = 32u;           // queue entries a wave reserves per atomic
+constexpr uint32_t kInvalidRead = 0xFFFFFFFFu;  // padding entry of the slow-read queue
 
 // Byte offsets (relative to a wave's LDS region) and capacities; filled by the host.
 struct SeedLayout {
@@ -54,7 +57,12 @@ struct SeedParams {
   uint32_t cand_cap;
   uint32_t *cand_begin;  // [2*n_reads]
   uint32_t *cand_count;  // [2*n_reads]
-  uint32_t *ctr;         // [0] candidate cursor, [1] flags
+  uint32_t *ctr;         // [0] candidate cursor, [1] flags, [2] slow-read queue cursor
+  uint32_t n_seq;
+  // reads the fast kernel cannot finish (lists too long for lanes, DP too wide) are queued for the generic kernel
+  uint32_t *slow_queue;        // written by seed_fast_kernel
+  uint32_t slow_cap;
+  const uint32_t *work_queue;  // read by seed_filter_kernel; nullptr = process every read of the batch
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries
@@ -585,11 +593,14 @@ __device__ __forceinline__ uint32_t dpp_min_step(uint32_t x, uint32_t inf) {
   return t < x ? t : x;
 }
 
+// RT / STEPT / LGT > 0 fix R, step and ceil(k/step) at compile time (seed_fast_kernel); 0 = take them from p.
+template <int RT, int STEPT, int LGT>
 __device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *strand_ok, const uint2 *sf, uint32_t smax,
                                      uint32_t W, unsigned long long *take_bits /* LDS [passes][R] */,
                                      Picked *picked) {
   const uint32_t ln = lane_id();
-  const int R = p.R, lg = p.lg, step = p.step;
+  const int R = RT ? RT : p.R, lg = LGT ? LGT : p.lg, step = STEPT ? STEPT : p.step;
+  constexpr int kUnroll = RT ? RT : kMaxR;
   const uint32_t n_groups = 2u * (uint32_t)step;
   const uint32_t per_pass = (uint32_t)kWave / W;
   const uint32_t n_pass = (n_groups + per_pass - 1u) / per_pass;
@@ -607,13 +618,13 @@ __device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *str
     const uint32_t ncols = g_ok ? (uint32_t)((S - (int)si) / step - R * lg + 1) : 0u;
     const bool in_seg = c < ncols;
     const uint2 *sfs = sf + (strand & 1u) * smax;
-    uint32_t f[kMaxR];
+    uint32_t f[kUnroll];
 #pragma unroll
-    for (int r = 1; r <= kMaxR; ++r)  // all LDS reads of the pass in flight together
+    for (int r = 1; r <= kUnroll; ++r)  // all LDS reads of the pass in flight together
       f[r - 1] = (r <= R && in_seg) ? sfs[si + (uint32_t)step * (c + (uint32_t)((r - 1) * lg))].y : 0u;
     uint32_t M = 0;  // M[0][c] = 0
 #pragma unroll
-    for (int r = 1; r <= kMaxR; ++r) {
+    for (int r = 1; r <= kUnroll; ++r) {
       if (r <= R) {
         const uint32_t v = M + f[r - 1];  // uint32 wrap as in the reference
         uint32_t x = in_seg ? v : inf;    // lanes outside a segment must not disturb the min
@@ -642,15 +653,15 @@ __device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *str
   if (ln < n_groups) {
     Picked *out = picked + (size_t)ln * (uint32_t)R;
     const uint32_t own_pass = ln / per_pass, own_slot = ln % per_pass;
-    unsigned long long rows[kMaxR];
+    unsigned long long rows[kUnroll];
 #pragma unroll
-    for (int r = 1; r <= kMaxR; ++r) rows[r - 1] = (r <= R && own_ncols) ? take_bits[own_pass * (uint32_t)R + (uint32_t)(r - 1)] : 0ull;
+    for (int r = 1; r <= kUnroll; ++r) rows[r - 1] = (r <= R && own_ncols) ? take_bits[own_pass * (uint32_t)R + (uint32_t)(r - 1)] : 0ull;
     const uint2 *sfo = sf + (own_strand & 1u) * smax;
     int col = (int)own_ncols - 1, n_out = 0;
     bool alive = own_ncols != 0;
-    uint32_t sidx[kMaxR];
+    uint32_t sidx[kUnroll];
 #pragma unroll
-    for (int r = kMaxR; r >= 1; --r) {
+    for (int r = kUnroll; r >= 1; --r) {
       sidx[r - 1] = 0xFFFFFFFFu;
       if (r <= R && alive) {
         unsigned long long seg = (rows[r - 1] >> (own_slot * W)) & ((2ull << col) - 1ull);
@@ -663,7 +674,7 @@ __device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *str
       }
     }
 #pragma unroll
-    for (int r = kMaxR; r >= 1; --r) {  // picked in traceback order: row R first
+    for (int r = kUnroll; r >= 1; --r) {  // picked in traceback order: row R first
       if (r <= R) {
         Picked q{0, 0, 0, 0};
         if (sidx[r - 1] != 0xFFFFFFFFu) {
@@ -731,7 +742,10 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
   const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t n_waves = gridDim.x * waves_per_block;
 
-  for (uint32_t read = wave_global; read < p.n_reads; read += n_waves) {
+  const uint32_t n_items = p.work_queue ? min(p.ctr[2], p.slow_cap) : p.n_reads;
+  for (uint32_t item = wave_global; item < n_items; item += n_waves) {
+    const uint32_t read = p.work_queue ? p.work_queue[item] : item;
+    if (read == kInvalidRead) continue;
     STAMP_START(prof);
     const uint64_t off = p.read_off[read];
     const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
@@ -831,7 +845,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
       dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : widest <= 64u ? 64u : 0u;
     }
     if (dp_w) {
-      pre_g = select_seeds_dpp(p, S, strand_ok, sf, smax, dp_w, (unsigned long long *)dp_bits, picked);
+      pre_g = select_seeds_dpp<0, 0, 0>(p, S, strand_ok, sf, smax, dp_w, (unsigned long long *)dp_bits, picked);
     } else if (ln < 2u * (uint32_t)step && strand_ok[ln / (uint32_t)step]) {
       const uint32_t strand = ln / (uint32_t)step, si = ln % (uint32_t)step;
       const int G = (S - (int)si) / step;

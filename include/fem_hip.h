@@ -120,7 +120,9 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);             /* s
 /* ---- measurement ---- */
 /* With timing on, every kernel launch is bracketed by HIP events on the stream
  * it is launched on; fem_dev_kernel_time reports their sum and count since
- * the last reset.  kernel: 0 = seed/filter kernel, 1 = verify kernel. */
+ * the last reset.  kernel: 0 = seed/filter kernel (fast form, k=12 step=3),
+ * 1 = verify kernel, 2 = seed/filter kernel (generic form: the reads the fast
+ * form queued, or every read when the fast form does not apply). */
 int fem_dev_set_timing(fem_dev *h, int on);
 int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);

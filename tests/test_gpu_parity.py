@@ -8,10 +8,15 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dev():
+@pytest.fixture(scope="module", params=["fast+generic", "generic-only"])
+def dev(request):
+    # "generic-only" skips seed_fast_kernel (FEM_FORCE_GENERIC is read by fem_dev_open): every fixture then
+    # exercises the generic seed kernel, which otherwise only sees the reads the fast kernel queues.
+    import os
     from fem_amd import Device
+    os.environ["FEM_FORCE_GENERIC"] = "1" if request.param == "generic-only" else "0"
     d = Device(0)
+    os.environ.pop("FEM_FORCE_GENERIC")
     yield d
     d.close()
 
