@@ -74,7 +74,7 @@ def main():
     w = WORKLOADS[args.workload]
     n_reads = args.reads or w["reads"]
     L, e, a, k, step = w["L"], w["e"], 1, 12, 3
-    threads = max(1, min(len(os.sched_getaffinity(0)), 64) // max(1, min(world, 8)))
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
 
     t0 = time.time()
     text, off, lens = host.synth_reference(w["seed"], w["seq_lens"], threads=threads)
@@ -179,7 +179,7 @@ def cpu_baseline(w, text, off, lens, n_sample, bases, offsets, dev, e, a):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of
     the same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
     from oracle import fem_oracle as fo
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), 16)  # the CPU share of a one-GPU box
     L = w["L"]
     ref = fo.Reference([text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)])
     t0 = time.time()

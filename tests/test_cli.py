@@ -1,0 +1,87 @@
+"""The drop-in command line (fem_amd/csrc/FEM): argument handling without a GPU, end-to-end `index` + `map` with one."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+from tests import util
+from tests.test_host import expected_sam
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FEM = os.path.join(ROOT, "fem_amd", "csrc", "FEM")
+
+
+def run(*args):
+    return subprocess.run([FEM] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+def test_usage_and_argument_errors():
+    import __graft_entry__ as g
+    g.build()
+    r = run()
+    assert r.returncode == 1 and b"Usage:   FEM <command>" in r.stderr           # src/FEM.c:24-28
+    r = run("frobnicate")
+    assert r.returncode == 1 and b"unrecognized command" in r.stderr               # src/FEM.c:37-39
+    r = run("index", "12", "3")
+    assert r.returncode == 1 and b"Usage: FEM index <window_size> <step_size> <reference> <output>" in r.stderr
+    r = run("map", "-h")
+    assert r.returncode == 0 and b"--read1" in r.stderr                            # src/FEM_map.c:123-125
+    r = run("map", "-e", "9", "--ref", "a", "--index", "b", "--read1", "c", "-o", "d")
+    assert r.returncode == 1 and b"Wrong error threshold." in r.stderr             # src/FEM_map.c:30-33
+    r = run("map", "-e", "3", "--index", "b", "--read1", "c", "-o", "d")
+    assert r.returncode == 1 and b"Reference file path is required." in r.stderr
+    r = run("map", "-a", "3", "--ref", "a", "--index", "b", "--read1", "c", "-o", "d")
+    assert r.returncode == 1 and b"Wrong number of additional q-grams." in r.stderr
+    r = run("map", "-f", "x")
+    assert r.returncode == 1 and b"Wrong name of seeding algorithm!" in r.stderr   # src/FEM_map.c:113-117
+
+
+def write_case(tmp_path, seed, e, L, n_reads, gz):
+    rng = np.random.default_rng(seed)
+    seqs = util.repeat_rich_reference(rng, n_seq=3, unit_len=300, n_units=4, copies=40, spacer=200)
+    seqs.append(util.rand_seq(rng, 150_000))
+    names = ["chr%s" % c for c in "ABCD"]
+    reads = util.make_reads(rng, seqs, n_reads, L, e, n_rate=0.002)
+    rnames = ["read_%d" % i for i in range(n_reads)]
+    quals = ["".join(chr(33 + (7 * i + j) % 41) for j in range(L)) for i in range(n_reads)]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "wb") as f:
+        for n, s in zip(names, seqs):
+            f.write(b">" + n.encode() + b" some description\n")
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + b"\n")
+    fq = tmp_path / ("reads.fq.gz" if gz else "reads.fq")
+    op = gzip.open if gz else open
+    with op(fq, "wb") as f:
+        for n, r, q in zip(rnames, reads, quals):
+            f.write(b"@" + n.encode() + b" 1:N:0\n" + r + b"\n+\n" + q.encode() + b"\n")
+    return seqs, names, reads, rnames, quals, str(fa), str(fq)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e,L,gz,batch", [(3, 100, False, 97), (7, 150, True, 1000000)])
+def test_index_and_map_end_to_end(tmp_path, e, L, gz, batch):
+    seqs, names, reads, rnames, quals, fa, fq = write_case(tmp_path, 77 + e, e, L, 600, gz)
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    want = fo.map_reads(ref, idx, fo.ReadBatch(reads), e=e)
+    index_path, sam_path, oracle_index = str(tmp_path / "ref.idx"), str(tmp_path / "out.sam"), str(tmp_path / "o.idx")
+    r = run("index", "12", "3", fa, index_path)
+    assert r.returncode == 0, r.stderr.decode()
+    idx.save(oracle_index)
+    assert open(index_path, "rb").read() == open(oracle_index, "rb").read()  # byte-identical index file
+    r = run("map", "-e", str(e), "-t", "3", "--ref", fa, "--index", index_path, "--read1", fq, "-o", sam_path,
+            "--batch", str(batch))
+    assert r.returncode == 0, r.stderr.decode()
+    text = open(sam_path).read()
+    header = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, len(s)) for n, s in zip(names, seqs))
+    assert text.startswith(header)
+    assert text[len(header):] == expected_sam(names, reads, rnames, quals, want)
+    err = r.stderr.decode()
+    for label, v in zip(["The number of read", "The number of mapped read",
+                         "The number of candidate before additional q-gram filter", "The number of candidate",
+                         "The number of mapping"], want.stats):
+        assert "%s: %d\n" % (label, int(v)) in err  # src/FEM_map.c:214-218
