@@ -96,6 +96,7 @@ struct fem_dev {
   double t_ms[3] = {0, 0, 0};
   uint64_t t_n[3] = {0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
+  bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
   std::vector<hipEvent_t> event_pool;
 };
 
@@ -179,7 +180,7 @@ femk::SeedLayout make_layout(const fem_params &p, uint32_t max_len) {
 }
 
 // LDS of one wave of seed_fast_kernel: packed bases, (lookup, frequency) per seed, DP take bits, selected seeds, scatter
-femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len) {
+femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool hash) {
   femk::SeedLayout l{};
   const uint32_t R = (uint32_t)(p.e + 1 + p.a);
   const uint32_t n_groups = 2u * (uint32_t)p.step;
@@ -197,14 +198,21 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len) {
   l.sf = take(2u * l.smax * 8u);
   l.dp_bits = take(n_groups * R * 8u);
   l.picked = take(n_groups * R * 16u);
-  l.X = take(l.xcap * 8u);
+  l.X = take(64u * 8u);  // scatter
+  if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
+    l.xcap = (uint32_t)femk::kMaxChunks * 64u;
+    l.F = take(femk::kBloomSlots / 16u * 4u);  // bitmap: two bits per key slot
+  }
   l.wave_bytes = o;
   return l;
 }
 
 template <int R>
-void launch_fast(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL(femk::seed_fast_kernel<R>, grid, block, lds, st, sp);
+void launch_fast(bool hash, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  if (hash)
+    hipLaunchKernelGGL((femk::seed_fast_kernel<R, true>), grid, block, lds, st, sp);
+  else
+    hipLaunchKernelGGL((femk::seed_fast_kernel<R, false>), grid, block, lds, st, sp);
 }
 
 hipEvent_t get_event(fem_dev *h) {
@@ -354,22 +362,24 @@ int launch_batch(fem_dev *h, Slot &s) {
     int rc;
     if (use_fast) {
       femk::SeedParams fp = sp;
-      fp.lay = make_layout_fast(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
+      // long occurrence lists (dense index): the hash-join form of the kernel; short ones: lists in lanes only
+      const bool hash = h->force_hash || (double)h->n_occ > (double)h->n_lookup;
+      fp.lay = make_layout_fast(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k), hash);
       uint32_t wpb, lds_bytes, grid;
       shape(fp.lay, &wpb, &lds_bytes, &grid);
       rc = timed(0, [&] {
         dim3 g(grid), b(64u * wpb);
         switch (R) {
-          case 1: launch_fast<1>(g, b, lds_bytes, s.stream, fp); break;
-          case 2: launch_fast<2>(g, b, lds_bytes, s.stream, fp); break;
-          case 3: launch_fast<3>(g, b, lds_bytes, s.stream, fp); break;
-          case 4: launch_fast<4>(g, b, lds_bytes, s.stream, fp); break;
-          case 5: launch_fast<5>(g, b, lds_bytes, s.stream, fp); break;
-          case 6: launch_fast<6>(g, b, lds_bytes, s.stream, fp); break;
-          case 7: launch_fast<7>(g, b, lds_bytes, s.stream, fp); break;
-          case 8: launch_fast<8>(g, b, lds_bytes, s.stream, fp); break;
-          case 9: launch_fast<9>(g, b, lds_bytes, s.stream, fp); break;
-          default: launch_fast<10>(g, b, lds_bytes, s.stream, fp); break;
+          case 1: launch_fast<1>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 2: launch_fast<2>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 3: launch_fast<3>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 4: launch_fast<4>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 5: launch_fast<5>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 6: launch_fast<6>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 7: launch_fast<7>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 8: launch_fast<8>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 9: launch_fast<9>(hash, g, b, lds_bytes, s.stream, fp); break;
+          default: launch_fast<10>(hash, g, b, lds_bytes, s.stream, fp); break;
         }
       });
       if (rc) return rc;
@@ -446,6 +456,8 @@ int fem_dev_open(int device, fem_dev **out) {
   }
   const char *fg = getenv("FEM_FORCE_GENERIC");
   h->force_generic = fg && fg[0] == '1';
+  const char *fh = getenv("FEM_FORCE_HASH");
+  h->force_hash = fh && fh[0] == '1';
   *out = h;
   return FEM_OK;
 }

@@ -33,7 +33,260 @@ __device__ __forceinline__ uint32_t pack4(uint32_t b) {
   return ((b & 3u) << 6) | ((b >> 4) & 0x30u) | ((b >> 14) & 0xCu) | (b >> 24);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// merge_kvec_t_uint64_t (src/filter.c:45-78) for one group: `fs` holds the group's nF survivors SORTED in lanes
+// 0..nF-1, `cv` the nA candidates so far; two-pointer merge on wave-uniform scalars with the greedy gap rule.
+// Returns the new count (the list may outgrow the wave: 0xFFFFFFFF).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t merge_group(uint64_t &cv, uint32_t nA, uint64_t fs, uint32_t nF, uint64_t e64) {
+  const uint32_t ln = lane_id();
+  uint64_t merged = 0, last_kept = 0;
+  uint32_t nB = 0, ia = 0, jf = 0;
+  while (ia < nA || jf < nF) {
+    const uint64_t xa = readlane64(cv, (int)(ia < nA ? ia : 0));
+    const uint64_t xf = readlane64(fs, (int)(jf < nF ? jf : 0));
+    const bool take_a = ia < nA && (jf >= nF || xa < xf);
+    const uint64_t x = take_a ? xa : xf;
+    ia += take_a ? 1u : 0u;
+    jf += take_a ? 0u : 1u;
+    if (nB == 0 || x > last_kept + e64) {
+      if (nB >= (uint32_t)kWave) return 0xFFFFFFFFu;
+      merged = ln == nB ? x : merged;
+      ++nB;
+      last_kept = x;
+    }
+  }
+  cv = merged;
+  return nB;
+}
+
+// Sort the nF (<= 64) values flagged `mine` (any lanes) into lanes 0..nF-1: rank by all-pairs compare on scalars,
+// then one scatter through LDS.
+__device__ __forceinline__ uint64_t sort_into_lanes(bool mine, uint64_t v, uint64_t mf, uint32_t nF, uint64_t *scatter) {
+  const uint32_t ln = lane_id();
+  uint32_t rank = 0;
+  for (uint64_t m = mf; m;) {
+    const int j = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint64_t x = readlane64(v, j);
+    rank += (uint32_t)(x < v || (x == v && (uint32_t)j < ln));
+  }
+  wave_sync_lds();
+  if (mine) scatter[rank] = v;
+  wave_sync_lds();
+  return ln < nF ? scatter[ln] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One strand whose 3*R selected seeds hold at most 64 occurrences: one occurrence per lane, everything else on
+// wave-uniform scalars (src/filter.c:80-131 as the closed form of SURVEY.md A.2, then :45-78 group by group).
+// Seeds live one per lane: lane lane0 + group*R + run.  Returns the number of candidates, left in cv.
+// ---------------------------------------------------------------------------------------------------------
 template <int R>
+__device__ uint32_t lists_in_lanes(const SeedParams &p, uint32_t lane0, uint64_t nonempty, uint32_t s_start,
+                                   uint32_t s_lo, uint32_t s_freq, uint32_t s_grp, uint32_t s_run, uint64_t *scatter,
+                                   uint64_t &cv) {
+  const uint32_t ln = lane_id();
+  constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
+  const uint64_t e64 = (uint64_t)p.e;
+  const uint64_t ne = (nonempty >> lane0) & ((1ull << kSeeds) - 1ull);
+  bool valid = false;
+  uint64_t v = 0;
+  uint32_t grp = 0, run = 0, at = 0;
+  for (uint64_t m = ne; m;) {
+    const int j = __builtin_ctzll(m) + (int)lane0;
+    m &= m - 1;
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
+    const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)s_grp, j);
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)s_run, j);
+    if (ln >= at && ln < at + f) {
+      const uint64_t o = p.occ[(uint64_t)lo + (ln - at)];
+      valid = (uint32_t)o >= st;  // src/filter.c:89,106
+      v = o - st;
+      grp = gj, run = rj;
+    }
+    at += f;
+  }
+  // last seed of each group: only values <= max of the other runs survive (src/filter.c:85)
+  for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
+    const bool is_last = valid && grp == g && run == (uint32_t)(R - 1);
+    if (!__ballot(is_last)) continue;
+    const uint64_t mu = __ballot(valid && grp == g && run != (uint32_t)(R - 1));
+    uint64_t max_u = 0;
+    for (uint64_t m = mu; m;) {
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint64_t x = readlane64(v, j);
+      max_u = x > max_u ? x : max_u;
+    }
+    if (is_last && (mu == 0 || v > max_u)) valid = false;
+  }
+  // additional_qgram_filter (src/filter.c:118-131): >= a+1 values of the same group in [v, v+e]
+  const uint64_t vm = __ballot(valid);
+  if ((uint32_t)__popcll(vm) <= (uint32_t)p.a) return 0;
+  uint32_t cnt = 0;
+  for (uint64_t m = vm; m;) {
+    const int j = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint64_t x = readlane64(v, j);
+    const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)grp, j);
+    cnt += (uint32_t)(gj == grp && x >= v && x <= v + e64);
+  }
+  const bool pass = valid && cnt > (uint32_t)p.a;
+  if (!__ballot(pass)) return 0;
+  uint32_t nA = 0;
+  for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
+    const bool mine = pass && grp == g;
+    const uint64_t mf = __ballot(mine);
+    const uint32_t nF = (uint32_t)__popcll(mf);
+    if (nF == 0) continue;
+    const uint64_t fs = sort_into_lanes(mine, v, mf, nF, scatter);
+    nA = merge_group(cv, nA, fs, nF, e64);
+    if (nA == 0xFFFFFFFFu) return nA;
+  }
+  return nA;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One strand with long occurrence lists (large references).  Per phase group:
+//   * the R sorted runs are read as ONE flat index space (consecutive lanes -> consecutive entries of a run:
+//     coalesced HBM walks, every chunk of the group in flight together) and kept in registers;
+//   * pre-filter: an LDS bitmap with two bits per key slot (key = v >> 3: present / seen-twice).  A value can
+//     have a neighbour in [v-e, v+e] (e <= 7) only if its own slot was hit twice or an adjacent slot is present,
+//     so everything that takes part in ANY within-e pair gets flagged; slot aliasing only adds false positives;
+//   * the few flagged values (true hits + ~n^2/slots chance ones) are compacted into lanes and the
+//     additional-q-gram filter is evaluated exactly on them: a value passes iff >= a+1 flagged values lie in
+//     [v, v+e] — every value in that range is itself flagged, so this equals the count over the whole list
+//     (closed form of src/filter.c:80-131);
+//   * survivors are sorted in lanes and merged greedily (src/filter.c:45-78).
+// Returns the number of candidates (in cv), or 0xFFFFFFFF if a group does not fit (the read is then queued).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxChunks = 8;             // a group may select up to 8 * 64 occurrences
+constexpr uint32_t kBloomSlots = 16384u;  // two bits each: 4 KiB of LDS per wave
+
+template <int R>
+__device__ uint32_t lists_bloom_join(const SeedParams &p, uint32_t lane0, const uint32_t *group_total, uint32_t s_start,
+                                     uint32_t s_lo, uint32_t s_freq, uint64_t *scatter, uint32_t *bloom, uint64_t &cv) {
+  const uint32_t ln = lane_id();
+  const uint64_t e64 = (uint64_t)p.e;
+  constexpr uint32_t kMask = kBloomSlots - 1u;
+  uint32_t nA = 0;
+  for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
+    const uint32_t n_g = group_total[g];
+    if (n_g <= (uint32_t)p.a) continue;
+    // per-run (first entry, read offset) as wave-uniform scalars; prefix sums of the frequencies
+    uint32_t pf[R + 1], base[R], start[R];
+    pf[0] = 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const int j = (int)(lane0 + g * (uint32_t)R) + t;
+      const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+      pf[t + 1] = pf[t] + f;
+      base[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j) - pf[t];  // entry idx of run t = occ[base[t] + idx]
+      start[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
+    }
+    const uint32_t n_u = pf[R - 1];  // entries of runs 0..R-2 (the set U); the last run follows
+    if (n_u == 0) continue;          // the last seed is merged only while the list has elements (src/filter.c:85)
+    // ---- load: chunk c holds flat entries c*64 + lane ----
+    uint64_t val[kMaxChunks];
+    uint32_t valid = 0;  // bit c: this lane's entry of chunk c takes part
+    uint64_t max_u = 0;
+    uint32_t any_u = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      val[c] = 0;
+      const uint32_t idx = (uint32_t)c * kWave + ln;
+      if ((uint32_t)c * kWave < n_g && idx < n_g) {
+        uint32_t b = base[0], st = start[0];
+#pragma unroll
+        for (int t = 1; t < R; ++t)
+          if (idx >= pf[t]) b = base[t], st = start[t];
+        const uint64_t o = p.occ[(uint32_t)(b + idx)];  // base may have wrapped: 32-bit sum
+        if ((uint32_t)o >= st) {                         // src/filter.c:89,106
+          const uint64_t v = o - st;
+          val[c] = v;
+          valid |= 1u << c;
+          if (idx < n_u) {
+            max_u = v > max_u ? v : max_u;
+            any_u = 1;
+          }
+        }
+      }
+    }
+    if (!__any(any_u)) continue;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(max_u >> 32), d) << 32) |
+                             (uint32_t)__shfl_xor((int)(uint32_t)max_u, d);
+      max_u = other > max_u ? other : max_u;
+    }
+    // ---- insert (last-run values above max(U) are dropped first) ----
+    uint32_t slot[kMaxChunks];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      slot[c] = 0;
+      if ((uint32_t)c * kWave < n_g) {
+        const uint32_t idx = (uint32_t)c * kWave + ln;
+        if (((valid >> c) & 1u) && idx >= n_u && val[c] > max_u) valid &= ~(1u << c);
+        if ((valid >> c) & 1u) {
+          const uint64_t key = val[c] >> 3;
+          const uint32_t sl = ((uint32_t)key + (uint32_t)(key >> 29) * 0x9E3779B1u) & kMask;  // neighbours stay adjacent
+          slot[c] = sl;
+          const uint32_t bit = 1u << (2u * (sl & 15u));
+          const uint32_t old = atomicOr(&bloom[sl >> 4], bit);
+          if (old & bit) atomicOr(&bloom[sl >> 4], bit << 1);  // second value on this slot
+        }
+      }
+    }
+    wave_sync_lds();
+    // ---- flag: own slot seen twice, or a neighbouring slot present ----
+    uint32_t n_flag = 0;
+    bool too_many = false;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      if ((uint32_t)c * kWave < n_g) {
+        bool flag = false;
+        if ((valid >> c) & 1u) {
+          const uint32_t sl = slot[c], lf = (sl - 1u) & kMask, rt = (sl + 1u) & kMask;
+          const uint32_t wc = bloom[sl >> 4], wl = bloom[lf >> 4], wr = bloom[rt >> 4];
+          // a == 0: the filter keeps every value (src/filter.c:120-128 with num_additional_qgrams 0)
+          flag = p.a == 0 || (((wc >> (2u * (sl & 15u) + 1u)) & 1u) | ((wl >> (2u * (lf & 15u))) & 1u) | ((wr >> (2u * (rt & 15u))) & 1u));
+        }
+        const uint64_t m = __ballot(flag);
+        const uint32_t pos = n_flag + (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+        if (flag && pos < (uint32_t)kWave) scatter[pos] = val[c];
+        n_flag += (uint32_t)__popcll(m);
+        too_many = too_many || n_flag > (uint32_t)kWave;
+      }
+    }
+    wave_sync_lds();
+    // ---- leave the bitmap clean for the next group (only the touched words) ----
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c)
+      if ((uint32_t)c * kWave < n_g && ((valid >> c) & 1u)) bloom[slot[c] >> 4] = 0;
+    if (too_many) return 0xFFFFFFFFu;
+    if (n_flag <= (uint32_t)p.a) continue;
+    // ---- exact window filter on the flagged values ----
+    const bool have = ln < n_flag;
+    const uint64_t fv = have ? scatter[ln] : 0;
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < n_flag; ++j) {
+      const uint64_t x = readlane64(fv, (int)j);
+      cnt += (uint32_t)(x >= fv && x <= fv + e64);
+    }
+    const bool pass = have && cnt > (uint32_t)p.a;
+    const uint64_t mf = __ballot(pass);
+    const uint32_t nF = (uint32_t)__popcll(mf);
+    if (nF == 0) continue;
+    const uint64_t fs = sort_into_lanes(pass, fv, mf, nF, scatter);
+    nA = merge_group(cv, nA, fs, nF, e64);
+    if (nA == 0xFFFFFFFFu) return nA;
+  }
+  return nA;
+}
+
+template <int R, bool HASH>
 __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);  // selected seeds per strand
@@ -48,6 +301,9 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   unsigned long long *take_bits = (unsigned long long *)(wbase + p.lay.dp_bits);
   Picked *picked = (Picked *)(wbase + p.lay.picked);
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
+  uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
+  if (HASH)
+    for (uint32_t i = ln; i < kBloomSlots / 16u; i += kWave) bloom[i] = 0;
   const uint32_t smax = p.lay.smax;
   const uint64_t e64 = (uint64_t)p.e;
   unsigned long long pre_sum = 0, cand_sum = 0;
@@ -80,6 +336,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
     uint32_t pre_g = 0;
     uint32_t s_start = 0, s_lo = 0, s_freq = 0, s_grp = 0, s_run = 0;
     uint64_t nonempty = 0;
+    uint32_t group_total[2 * kStep] = {0, 0, 0, 0, 0, 0}, strand_total[2] = {0, 0};
     if (!slow) {
       // ---- encode ----
       uint32_t any_n = 0;
@@ -164,20 +421,41 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
         if (!strand_ok[ln / kSeeds]) s_freq = 0;
       }
       nonempty = __ballot(s_freq > 0);
-      // a strand fits the lanes if its seeds hold at most 64 occurrences in total
-      for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
-        uint32_t total = 0;
-        for (uint64_t m = (nonempty >> (strand * kSeeds)) & ((1ull << kSeeds) - 1ull); m;) {
-          const int j = __builtin_ctzll(m) + (int)(strand * kSeeds);
+      // occurrences selected per (strand, group); a strand with <= 64 in total is done in registers, longer
+      // groups need the hash-join form (HASH) and its capacity
+      for (uint32_t g = 0; g < 2u * (uint32_t)kStep && !slow; ++g) {
+        uint32_t n_g = 0;
+        for (uint64_t m = (nonempty >> (g * (uint32_t)R)) & ((1ull << R) - 1ull); m;) {
+          const int j = __builtin_ctzll(m) + (int)(g * (uint32_t)R);
           m &= m - 1;
-          total += (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-          if (total > (uint32_t)kWave) break;  // (also keeps the sum from wrapping)
+          const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+          n_g = f > 0x7fffffffu - n_g ? 0x7fffffffu : n_g + f;
         }
-        slow = total > (uint32_t)kWave;
+        group_total[g] = n_g;
+        slow = n_g > (HASH ? p.lay.xcap : (uint32_t)kWave);  // xcap = most occurrences of one group the table takes
+      }
+      for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
+        strand_total[strand] = group_total[strand * kStep] + group_total[strand * kStep + 1] + group_total[strand * kStep + 2];
+        if (!HASH) slow = strand_total[strand] > (uint32_t)kWave;
       }
     }
 
-    if (slow) {  // hand the whole read to the generic kernel
+    // ---- per strand: lists -> candidates (sorted, before the range clip) in lanes 0..kept-1 of cv ----
+    uint64_t cvs[2] = {0, 0};
+    uint32_t kepts[2] = {0, 0};
+    for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
+      if (!strand_ok[strand]) continue;
+      if (strand_total[strand] <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
+      const uint32_t lane0 = strand * kSeeds;
+      if (strand_total[strand] <= (uint32_t)kWave)
+        kepts[strand] = lists_in_lanes<R>(p, lane0, nonempty, s_start, s_lo, s_freq, s_grp, s_run, scatter, cvs[strand]);
+      else if (HASH)
+        kepts[strand] = lists_bloom_join<R>(p, lane0, &group_total[strand * kStep], s_start, s_lo, s_freq, scatter, bloom,
+                                            cvs[strand]);
+      if (kepts[strand] == 0xFFFFFFFFu) slow = true;
+    }
+
+    if (slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
       if (qchunk.left == 0) {
         uint32_t base = 0;
         if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
@@ -193,124 +471,23 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       continue;
     }
 
-    // ---- per strand: lists in registers (same steps as strand_small() of the generic kernel) ----
+    // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
     for (uint32_t strand = 0; strand < 2u; ++strand) {
-      uint32_t n_out = 0, base = 0;
-      bool ok = false;
-      uint64_t cv = 0;  // lane i holds candidate i (sorted, before the range clip)
-      uint64_t mo = 0;
       if (strand_ok[strand]) {
         uint32_t pre = 0;  // uint32 sum of the groups' M[R][C-1] (src/filter.c:202)
         for (int si = 0; si < kStep; ++si) pre += (uint32_t)__builtin_amdgcn_readlane((int)pre_g, (int)(strand * kStep) + si);
         pre_sum += pre;
-        const uint32_t lane0 = strand * kSeeds;
-        const uint64_t ne = (nonempty >> lane0) & ((1ull << kSeeds) - 1ull);
-        uint32_t total = 0;
-        for (uint64_t m = ne; m;) {
-          const int j = __builtin_ctzll(m) + (int)lane0;
-          m &= m - 1;
-          total += (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-        }
-        uint32_t kept = 0;
-        if (total > (uint32_t)p.a) {
-          // one occurrence per lane, in (group, run) order = the order of the merged lists
-          bool valid = false;
-          uint64_t v = 0;
-          uint32_t grp = 0, run = 0;
-          uint32_t at = 0;
-          for (uint64_t m = ne; m;) {
-            const int j = __builtin_ctzll(m) + (int)lane0;
-            m &= m - 1;
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
-            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
-            const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)s_grp, j);
-            const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)s_run, j);
-            if (ln >= at && ln < at + f) {
-              const uint64_t o = p.occ[(uint64_t)lo + (ln - at)];
-              valid = (uint32_t)o >= st;  // src/filter.c:89,106
-              v = o - st;
-              grp = gj, run = rj;
-            }
-            at += f;
-          }
-          // last seed of each group: only values <= max of the other runs survive (src/filter.c:85)
-          for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
-            const bool is_last = valid && grp == g && run == (uint32_t)(R - 1);
-            if (!__ballot(is_last)) continue;
-            const uint64_t mu = __ballot(valid && grp == g && run != (uint32_t)(R - 1));
-            uint64_t max_u = 0;
-            for (uint64_t m = mu; m;) {
-              const int j = __builtin_ctzll(m);
-              m &= m - 1;
-              const uint64_t x = readlane64(v, j);
-              max_u = x > max_u ? x : max_u;
-            }
-            if (is_last && (mu == 0 || v > max_u)) valid = false;
-          }
-          // additional_qgram_filter (src/filter.c:118-131): >= a+1 values of the same group in [v, v+e]
-          const uint64_t vm = __ballot(valid);
-          bool pass = false;
-          if ((uint32_t)__popcll(vm) > (uint32_t)p.a) {
-            uint32_t cnt = 0;
-            for (uint64_t m = vm; m;) {
-              const int j = __builtin_ctzll(m);
-              m &= m - 1;
-              const uint64_t x = readlane64(v, j);
-              const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)grp, j);
-              cnt += (uint32_t)(gj == grp && x >= v && x <= v + e64);
-            }
-            pass = valid && cnt > (uint32_t)p.a;
-          }
-          // merge_kvec_t_uint64_t (src/filter.c:45-78), group after group
-          if (__ballot(pass)) {
-            uint32_t nA = 0;
-            for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
-              const bool mine = pass && grp == g;
-              const uint64_t mf = __ballot(mine);
-              const uint32_t nF = (uint32_t)__popcll(mf);
-              if (nF == 0) continue;
-              uint32_t rank = 0;  // position of v among this group's survivors
-              for (uint64_t m = mf; m;) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const uint64_t x = readlane64(v, j);
-                rank += (uint32_t)(x < v || (x == v && (uint32_t)j < ln));
-              }
-              wave_sync_lds();
-              if (mine) scatter[rank] = v;
-              wave_sync_lds();
-              const uint64_t fs = ln < nF ? scatter[ln] : 0;
-              uint64_t merged = 0, last_kept = 0;
-              uint32_t nB = 0, ia = 0, jf = 0;
-              while (ia < nA || jf < nF) {  // wave-uniform two-pointer merge + greedy gap rule
-                const uint64_t xa = readlane64(cv, (int)(ia < nA ? ia : 0));
-                const uint64_t xf = readlane64(fs, (int)(jf < nF ? jf : 0));
-                const bool take_a = ia < nA && (jf >= nF || xa < xf);
-                const uint64_t x = take_a ? xa : xf;
-                ia += take_a ? 1u : 0u;
-                jf += take_a ? 0u : 1u;
-                if (nB == 0 || x > last_kept + e64) {
-                  merged = ln == nB ? x : merged;
-                  ++nB;
-                  last_kept = x;
-                }
-              }
-              cv = merged;
-              nA = nB;
-            }
-            kept = nA;
-          }
-        }
-        // remove_out_ranged_candidates (src/filter.c:133-144)
-        if (ln < kept) {
-          const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
-          const uint32_t slen = p.seq_len[sq];
-          ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
-        }
-        mo = __ballot(ok);
-        n_out = (uint32_t)__popcll(mo);
       }
+      const uint64_t cv = cvs[strand];
+      bool ok = false;
+      if (ln < kepts[strand]) {
+        const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
+        const uint32_t slen = p.seq_len[sq];
+        ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+      }
+      const uint64_t mo = __ballot(ok);
+      const uint32_t n_out = (uint32_t)__popcll(mo);
+      uint32_t base = 0;
       if (n_out > 0) {
         if (n_out <= chunk.left) {
           base = chunk.next;

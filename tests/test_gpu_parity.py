@@ -8,15 +8,18 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fast+generic", "generic-only"])
+@pytest.fixture(scope="module", params=["fast+generic", "hash+generic", "generic-only"])
 def dev(request):
-    # "generic-only" skips seed_fast_kernel (FEM_FORCE_GENERIC is read by fem_dev_open): every fixture then
-    # exercises the generic seed kernel, which otherwise only sees the reads the fast kernel queues.
+    # The library picks the seed kernel by itself: seed_fast_kernel<R, false> (lists in lanes) for sparse
+    # indexes, <R, true> (hash join) for dense ones, and the generic kernel for whatever those queue.  The two
+    # environment hooks (read by fem_dev_open) force the other forms so that every fixture runs through all three.
     import os
     from fem_amd import Device
     os.environ["FEM_FORCE_GENERIC"] = "1" if request.param == "generic-only" else "0"
+    os.environ["FEM_FORCE_HASH"] = "1" if request.param == "hash+generic" else "0"
     d = Device(0)
     os.environ.pop("FEM_FORCE_GENERIC")
+    os.environ.pop("FEM_FORCE_HASH")
     yield d
     d.close()
 
