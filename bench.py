@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads of the same workload timed on the host cores")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the same workload timed on the host cores")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -148,6 +148,20 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+    # (FETCH_SIZE, WRITE_SIZE; summaries committed under profiles/), scaled to this run's reads per launch.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            prof = json.load(open(tpath))
+            for kname, ctr in prof["kernels"].items():
+                if dominant.split("_kernel")[0] in kname and "FETCH_SIZE" in ctr and ctr["FETCH_SIZE"]["mean_per_launch"] > 1e3:
+                    kib = ctr["FETCH_SIZE"]["mean_per_launch"] + ctr.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
+                    traffic = int(kib * 1024 * n_reads / prof["reads_per_launch"])
+        except Exception as ex:  # a malformed profile file must not break the measurement
+            log("could not read %s: %s" % (tpath, ex))
+
     out = {
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +176,7 @@ def main():
                    "kernel_ms": {k_: round(v_, 4) for k_, v_ in per_launch.items()},
                    "h2d_stage_s": round(h2d_s, 3)},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
     }
 
