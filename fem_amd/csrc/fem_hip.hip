@@ -83,6 +83,7 @@ struct fem_dev {
   uint64_t *d_occ = nullptr;
   uint64_t n_occ = 0;
   int32_t k = 0, step = 0;
+  uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
   // reference
   uint8_t *d_ref = nullptr;  // base codes
   uint64_t ref_bytes = 0;
@@ -327,6 +328,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   sp.lay = make_layout(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
 
   sp.n_seq = h->n_seq;
+  sp.nonempty = h->d_nonempty;
   sp.slow_queue = s.d_slow, sp.slow_cap = s.slow_cap;
   sp.work_queue = nullptr;
   const int R = p.e + 1 + p.a;
@@ -408,6 +410,22 @@ int launch_batch(fem_dev *h, Slot &s) {
   return FEM_OK;
 }
 
+// After the index is resident: for sparse indexes build the bucket non-empty bitmap the fast seed kernel tests first.
+int refresh_nonempty(fem_dev *h) {
+  if (h->d_nonempty) (void)hipFree(h->d_nonempty);
+  h->d_nonempty = nullptr;
+  const uint64_t n_buckets = h->n_lookup - 1;
+  if (h->n_occ >= n_buckets) return FEM_OK;  // dense index: nearly every bucket is non-empty, the test would not pay
+  const uint64_t words = n_buckets / 32 + 2;
+  HIP_TRY(h, hipMalloc((void **)&h->d_nonempty, words * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemset(h->d_nonempty, 0, words * sizeof(uint32_t)));
+  hipLaunchKernelGGL(femk::nonempty_bitmap_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, n_buckets,
+                     h->d_nonempty);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipDeviceSynchronize());
+  return FEM_OK;
+}
+
 int check_slot(fem_dev *h, int slot) {
   if (!h) return FEM_ERR_INVALID;
   if (slot < 0 || slot >= kSlots) return fail(h, FEM_ERR_INVALID, "slot out of range");
@@ -478,7 +496,8 @@ int fem_dev_close(fem_dev *h) {
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len})
+  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len,
+                  (void *)h->d_nonempty})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -506,7 +525,7 @@ int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lo
   HIP_TRY(h, hipMemcpy(h->d_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (n_occ) HIP_TRY(h, hipMemcpy(h->d_occ, occ, n_occ * sizeof(uint64_t), hipMemcpyHostToDevice));
   h->n_lookup = n_lookup, h->n_occ = n_occ, h->k = k, h->step = step;
-  return FEM_OK;
+  return refresh_nonempty(h);
 }
 
 int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len) {
@@ -554,6 +573,7 @@ int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_ou
   int rc = femix::build_index(h->d_ref, h->seq_off, h->seq_len, k, step, h->n_cu, &h->d_lookup, &h->d_occ, &n_occ, &err);
   if (rc != FEM_OK) return fail(h, rc, err);
   h->n_lookup = (1ull << (2 * k)) + 1, h->n_occ = n_occ, h->k = k, h->step = step;
+  if ((rc = refresh_nonempty(h))) return rc;
   if (n_occ_out) *n_occ_out = n_occ;
   if (lookup_out)
     HIP_TRY(h, hipMemcpy(lookup_out, h->d_lookup, h->n_lookup * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -872,4 +872,48 @@ void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_of
   }
 }
 
+int fem_synth_write_fastq(const char *path, const char *bases, uint32_t L, uint64_t n_reads, uint64_t first_index) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  std::vector<char> buf;
+  buf.reserve(1u << 24);
+  std::string qual(L, 'I');
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    char name[32];
+    int nl = snprintf(name, sizeof name, "@r%lu\n", (unsigned long)(first_index + i));
+    buf.insert(buf.end(), name, name + nl);
+    buf.insert(buf.end(), bases + i * L, bases + (i + 1) * L);
+    buf.push_back('\n');
+    buf.push_back('+');
+    buf.push_back('\n');
+    buf.insert(buf.end(), qual.begin(), qual.end());
+    buf.push_back('\n');
+    if (buf.size() > (1u << 24) - 1024) {
+      if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) {
+        fclose(f);
+        return -2;
+      }
+      buf.clear();
+    }
+  }
+  bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  return (fclose(f) == 0 && ok) ? 0 : -2;
+}
+
+int fem_synth_write_fasta(const char *path, const char *text, const uint64_t *seq_off, const uint32_t *seq_len,
+                          uint32_t n_seq) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  bool ok = true;
+  for (uint32_t s = 0; s < n_seq && ok; ++s) {
+    ok = fprintf(f, ">chr%u synthetic\n", s + 1) > 0;
+    const char *p = text + seq_off[s];
+    for (uint64_t i = 0; i < seq_len[s] && ok; i += 60) {
+      size_t n = (size_t)std::min<uint64_t>(60, seq_len[s] - i);
+      ok = fwrite(p + i, 1, n, f) == n && fputc('\n', f) != EOF;
+    }
+  }
+  return (fclose(f) == 0 && ok) ? 0 : -2;
+}
+
 }  // extern "C"

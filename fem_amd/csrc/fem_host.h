@@ -104,6 +104,12 @@ void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_of
                      uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
                      int n_threads);
 
+/* Writes reads as FASTQ ("@r<index>", constant quality 'I') or a reference as FASTA (60 columns); for the
+ * end-to-end measurements and tests.  Returns 0 or <0. */
+int fem_synth_write_fastq(const char *path, const char *bases, uint32_t L, uint64_t n_reads, uint64_t first_index);
+int fem_synth_write_fasta(const char *path, const char *text, const uint64_t *seq_off, const uint32_t *seq_len,
+                          uint32_t n_seq);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ struct SeedParams {
   uint32_t *slow_queue;        // written by seed_fast_kernel
   uint32_t slow_cap;
   const uint32_t *work_queue;  // read by seed_filter_kernel; nullptr = process every read of the batch
+  // one bit per hash bucket, set iff the bucket is non-empty (2 MiB for k = 12: stays in each XCD's L2).  Sparse
+  // indexes only (nullptr otherwise): most of the 2*(L-k+1) lookups per read then never touch the 64 MiB table.
+  const uint32_t *nonempty;
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries
@@ -1128,6 +1131,20 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
     if (lane_id() == 0) {
       if (m_acc) atomicAdd(&p.stats[2], (unsigned long long)__popcll(m_acc));
       if (m_first) atomicAdd(&p.stats[3], (unsigned long long)__popcll(m_first));
+    }
+  }
+}
+
+// bit h of `bits` = (lookup[h+1] != lookup[h]); one lane per bucket, one ballot per 64 buckets
+__global__ void nonempty_bitmap_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *bits) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t h0 = (uint64_t)blockIdx.x * blockDim.x; h0 < n_buckets; h0 += stride) {
+    const uint64_t h = h0 + threadIdx.x;
+    const bool set = h < n_buckets && lookup[h + 1] != lookup[h];
+    const uint64_t m = __ballot(set);
+    if ((threadIdx.x & 63u) == 0 && h < n_buckets) {  // h is a multiple of 64 here; the array has two spare words
+      bits[h >> 5] = (uint32_t)m;
+      bits[(h >> 5) + 1] = (uint32_t)(m >> 32);
     }
   }
 }

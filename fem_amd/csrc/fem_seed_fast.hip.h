@@ -286,6 +286,107 @@ __device__ uint32_t lists_bloom_join(const SeedParams &p, uint32_t lane0, const 
   return nA;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Seed selection for seed_fast_kernel: the DP of select_seeds_dpp (same table, same tie rule) with R, step and
+// ceil(k/step) fixed, followed by a traceback in which EVERY (group, row) lane walks the chain of "highest take
+// bit at or below the previous column" down to its own row, so each selected seed ends up in its own lane
+// without a round trip through LDS.  The stable frequency sort (src/filter.c:204) is a rank among the R lanes
+// of a group (R shuffles) and one forward permute puts the seeds in run order:
+//     lane = (strand * 3 + phase) * R + run  holds  (start, lookup[h], frequency) of that run.
+// Returns M[R][C-1] of group ln in lanes < 6 (for the "candidates before the filter" counter).
+// ---------------------------------------------------------------------------------------------------------
+template <int R>
+__device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *strand_ok, const uint2 *sf, uint32_t smax,
+                                       uint32_t W, unsigned long long *take_bits /* LDS [passes][R] */,
+                                       uint32_t &s_start, uint32_t &s_lo, uint32_t &s_freq) {
+  const uint32_t ln = lane_id();
+  constexpr uint32_t n_groups = 2u * (uint32_t)kStep;
+  constexpr uint32_t kFill = 0xFFFFFFFFu;  // identity of min: lets the DPP move fold into v_min_u32
+  const uint32_t per_pass = (uint32_t)kWave / W;
+  const uint32_t n_pass = (n_groups + per_pass - 1u) / per_pass;
+  const uint32_t c = ln & (W - 1u), slot = ln / W;
+  const uint32_t inf = p.inf32;
+  uint32_t pre_mine = 0;
+  for (uint32_t ps = 0; ps < n_pass; ++ps) {
+    const uint32_t g = ps * per_pass + slot;
+    const uint32_t strand = g / (uint32_t)kStep, si = g % (uint32_t)kStep;
+    const bool g_ok = g < n_groups && strand_ok[strand & 1u];
+    const uint32_t ncols = g_ok ? (uint32_t)((S - (int)si) / kStep - R * kLg + 1) : 0u;  // C - 1
+    const bool in_seg = c < ncols;
+    const uint2 *sfs = sf + (strand & 1u) * smax + si;
+    const uint32_t c_safe = in_seg ? c : 0u;  // keeps the unconditional LDS reads inside the array
+    uint32_t f[R];
+#pragma unroll
+    for (int r = 1; r <= R; ++r) f[r - 1] = sfs[(uint32_t)kStep * (c_safe + (uint32_t)((r - 1) * kLg))].y;
+    uint32_t M = 0;  // M[0][c] = 0
+#pragma unroll
+    for (int r = 1; r <= R; ++r) {
+      const uint32_t v = M + f[r - 1];  // uint32 wrap as in the reference
+      uint32_t x = in_seg ? v : kFill;
+      x = dpp_min_step<0x111, 0xF>(x, kFill);  // row_shr:1
+      x = dpp_min_step<0x112, 0xF>(x, kFill);  // row_shr:2
+      x = dpp_min_step<0x114, 0xF>(x, kFill);  // row_shr:4
+      x = dpp_min_step<0x118, 0xF>(x, kFill);  // row_shr:8
+      if (W > 16u) x = dpp_min_step<0x142, 0xA>(x, kFill);  // row_bcast:15 into rows 1 and 3
+      if (W > 32u) x = dpp_min_step<0x143, 0xC>(x, kFill);  // row_bcast:31 into rows 2 and 3
+      uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp((int)kFill, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
+      ex = (c == 0 || ex > inf) ? inf : ex;  // M[r][0] = (uint32)occurrence_table_size
+      const bool take = in_seg && v < ex;    // strict: ties go horizontal (src/filter.c:20)
+      M = take ? v : ex;
+      const unsigned long long bits = __ballot(take);
+      if (ln == 0) take_bits[ps * (uint32_t)R + (uint32_t)(r - 1)] = bits;
+    }
+    // M[R][C-1] of group ln: last column of that group's segment, if it ran in this pass
+    const uint32_t own_si = ln % (uint32_t)kStep;
+    const uint32_t own_ncols = (ln < n_groups && strand_ok[(ln / (uint32_t)kStep) & 1u])
+                                   ? (uint32_t)((S - (int)own_si) / kStep - R * kLg + 1) : 0u;
+    const uint32_t got = __shfl(M, (int)((ln % per_pass) * W + (own_ncols ? own_ncols - 1u : 0u)));
+    if (ln < n_groups && ln / per_pass == ps && own_ncols) pre_mine = got;
+  }
+  wave_sync_lds();
+  // ---- traceback: lane (g, t) finds the seed taken at row R - t ----
+  const uint32_t g = ln / (uint32_t)R, t = ln % (uint32_t)R;
+  const bool act = ln < n_groups * (uint32_t)R && strand_ok[(g / (uint32_t)kStep) & 1u];
+  const uint32_t g_c = act ? g : 0u;
+  const uint32_t si = g_c % (uint32_t)kStep;
+  const uint32_t ncols = (uint32_t)((S - (int)si) / kStep - R * kLg + 1);
+  const uint32_t pass_of = g_c / per_pass, slot_of = g_c % per_pass;
+  unsigned long long rows[R];
+#pragma unroll
+  for (int r = 1; r <= R; ++r) rows[r - 1] = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)];
+  int col = (int)ncols - 1;
+  bool alive = act;
+  uint32_t sidx = 0xFFFFFFFFu;
+#pragma unroll
+  for (int r = R; r >= 1; --r) {
+    if (alive && (uint32_t)(R - r) <= t) {
+      const unsigned long long seg = (rows[r - 1] >> (slot_of * W)) & ((2ull << col) - 1ull);
+      if (seg == 0) {
+        alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
+      } else {
+        col = 63 - __builtin_clzll(seg);
+        if ((uint32_t)(R - r) == t) sidx = si + (uint32_t)kStep * (uint32_t)(col + (r - 1) * kLg);
+      }
+    }
+  }
+  const bool have = alive && sidx != 0xFFFFFFFFu;
+  const uint2 q = sf[((g_c / (uint32_t)kStep) & 1u) * smax + (have ? sidx : 0u)];
+  uint32_t start = have ? sidx : 0u, lo = have ? q.x : 0u, freq = have ? q.y : 0u;
+  // ---- qsort(compare_seed): stable by ascending frequency; traceback order t breaks ties ----
+  uint32_t rank = 0;
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const uint32_t fu = (uint32_t)__shfl((int)freq, (int)(g * (uint32_t)R) + u);
+    rank += (uint32_t)(fu < freq || (fu == freq && (uint32_t)u < t));
+  }
+  const int dst = (int)((g * (uint32_t)R + rank) * 4u);  // ds_permute: byte address of the destination lane
+  s_start = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)start);
+  s_lo = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)lo);
+  s_freq = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)freq);
+  if (ln >= n_groups * (uint32_t)R) s_start = 0, s_lo = 0, s_freq = 0;
+  return pre_mine;
+}
+
 template <int R, bool HASH>
 __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -299,7 +400,6 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   uint32_t *nkw = (uint32_t *)(wbase + p.lay.nkw);
   uint2 *sf = (uint2 *)(wbase + p.lay.sf);
   unsigned long long *take_bits = (unsigned long long *)(wbase + p.lay.dp_bits);
-  Picked *picked = (Picked *)(wbase + p.lay.picked);
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
   if (HASH)
@@ -309,11 +409,13 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   unsigned long long pre_sum = 0, cand_sum = 0;
   SlotChunk chunk;   // candidate slots
   SlotChunk qchunk;  // slow-read queue entries
+  Prof prof;
 
   const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t n_waves = gridDim.x * waves_per_block;
 
   for (uint32_t read = wave_global; read < p.n_reads; read += n_waves) {
+    STAMP_START(prof);
     const uint64_t off = p.read_off[read];
     const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
     const uint8_t *seq = p.bases + off;
@@ -381,6 +483,10 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
         strand_ok[1] = n_rev_amb <= (uint32_t)p.e;
       }
       wave_sync_lds();
+      STAMP(prof, 0);
+#if defined(FEM_ABLATE) && FEM_ABLATE == 0
+      continue;
+#endif
 
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
       for (int j0 = 0; j0 < S; j0 += kWave) {
@@ -393,33 +499,51 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
           if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
           uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);  // reversed complement, pair order restored below
           const uint32_t hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-          if (strand_ok[0]) {
-            uint2 q;
-            __builtin_memcpy(&q, p.lookup + hf, 8);
-            sf[j] = make_uint2(q.x, q.y - q.x);
+          // (lookup[h], frequency) per seed.  With the non-empty bitmap (sparse index) an empty bucket costs one
+          // L2-resident bit test instead of a 64 MiB-table access; its lookup[h] is never used (frequency 0).
+          uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
+          bool need_f = strand_ok[0], need_r = strand_ok[1];
+          if (!HASH && p.nonempty) {
+            need_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
+            need_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
           }
-          if (strand_ok[1]) {
-            uint2 q;
-            __builtin_memcpy(&q, p.lookup + hr, 8);
-            sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(q.x, q.y - q.x);
+          if (need_f) {
+#ifdef FEM_EXP_SMALL_TABLE  // timing experiment only: confine the gathers to an L2-resident slice
+            __builtin_memcpy(&qf, p.lookup + (hf & 0xFFFFu), 8);
+#else
+            __builtin_memcpy(&qf, p.lookup + hf, 8);
+#endif
           }
+          if (need_r) {
+#ifdef FEM_EXP_SMALL_TABLE
+            __builtin_memcpy(&qr, p.lookup + (hr & 0xFFFFu), 8);
+#else
+            __builtin_memcpy(&qr, p.lookup + hr, 8);
+#endif
+          }
+          if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
+          if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
         }
       }
       wave_sync_lds();
+      STAMP(prof, 1);
+#if defined(FEM_ABLATE) && FEM_ABLATE == 1
+      continue;
+#endif
 
       // ---- seed selection ----
       const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
-      pre_g = select_seeds_dpp<R, kStep, kLg>(p, S, strand_ok, sf, smax, dp_w, take_bits, picked);
-      wave_sync_lds();
-
-      // ---- the selected seeds of both strands, one per lane: lane s = strand * kSeeds + group * R + run ----
+      pre_g = select_seeds_lanes<R>(p, S, strand_ok, sf, smax, dp_w, take_bits, s_start, s_lo, s_freq);
+      // lane s = strand * kSeeds + group * R + run now holds that run's seed
       if (ln < 2u * kSeeds) {
-        const Picked q = picked[ln];
         const uint32_t within = ln % kSeeds;
-        s_start = q.start, s_lo = q.lo, s_freq = q.freq;
         s_grp = within / (uint32_t)R, s_run = within % (uint32_t)R;
         if (!strand_ok[ln / kSeeds]) s_freq = 0;
       }
+      STAMP(prof, 2);
+#if defined(FEM_ABLATE) && FEM_ABLATE == 2
+      continue;
+#endif
       nonempty = __ballot(s_freq > 0);
       // occurrences selected per (strand, group); a strand with <= 64 in total is done in registers, longer
       // groups need the hash-join form (HASH) and its capacity
@@ -440,6 +564,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       }
     }
 
+    STAMP(prof, 3);
     // ---- per strand: lists -> candidates (sorted, before the range clip) in lanes 0..kept-1 of cv ----
     uint64_t cvs[2] = {0, 0};
     uint32_t kepts[2] = {0, 0};
@@ -471,6 +596,10 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       continue;
     }
 
+    STAMP(prof, 4);
+#if defined(FEM_ABLATE) && FEM_ABLATE == 4
+    continue;
+#endif
     // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
     for (uint32_t strand = 0; strand < 2u; ++strand) {
       if (strand_ok[strand]) {
@@ -512,7 +641,11 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       }
       cand_sum += n_out;
     }
+    STAMP(prof, 5);
   }
+#ifdef FEM_STAMPS
+  prof.flush();
+#endif
   pad_chunk(p, chunk);
   for (uint32_t i = ln; i < qchunk.left; i += kWave)
     if (qchunk.next + i < p.slow_cap) p.slow_queue[qchunk.next + i] = kInvalidRead;

@@ -57,6 +57,8 @@ def lib():
         L.fem_sam_header.argtypes = [C.POINTER(TailRef), C.POINTER(vp), C.POINTER(u64)]
         L.fem_synth_reference.argtypes = [u64, C.c_uint32, vp, vp, vp, C.c_int]
         L.fem_synth_reads.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
+        L.fem_synth_write_fastq.argtypes = [C.c_char_p, vp, C.c_uint32, u64, u64]
+        L.fem_synth_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint32]
         L.free = C.CDLL(None).free
         L.free.argtypes = [vp]
         _LIB = L
@@ -91,6 +93,18 @@ def synth_reads(seed, text, off, lens, n_reads, L, e, first_read=0, threads=8):
                           L, e, bases.ctypes.data, threads)
     offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
     return bases, offsets
+
+
+def write_fastq(path, bases, L, n_reads, first_index=0):
+    rc = lib().fem_synth_write_fastq(path.encode(), bases.ctypes.data, L, n_reads, first_index)
+    if rc != 0:
+        raise OSError("fem_synth_write_fastq failed (%d)" % rc)
+
+
+def write_fasta(path, text, off, lens):
+    rc = lib().fem_synth_write_fasta(path.encode(), text.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens))
+    if rc != 0:
+        raise OSError("fem_synth_write_fasta failed (%d)" % rc)
 
 
 # ------------------------------------------------------------------------------------------ files
