@@ -64,10 +64,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # Rehearsal hooks for a one-GPU box (never set by the driver): FEM_BENCH_ONE_GPU=1 puts every rank on GPU 0,
+    # FEM_BENCH_BACKEND=gloo reduces the counters over gloo instead of RCCL (RCCL refuses two ranks on one GPU).
+    backend = os.environ.get("FEM_BENCH_BACKEND", "nccl")
+    if os.environ.get("FEM_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from fem_amd import Device, host
 
@@ -90,7 +99,7 @@ def main():
     dev.stage_reads(bases, offsets, slot=0)
     h2d_s = time.time() - t0
 
-    stats_dev = torch.zeros(5, dtype=torch.int64, device="cuda")
+    stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
 
     def step_once():
         dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
@@ -118,7 +127,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     dev.set_timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

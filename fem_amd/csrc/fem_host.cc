@@ -1,7 +1,11 @@
 // fem_host.cc — host side of the drop-in (see fem_host.h).  C++17, OpenMP for the per-read loops.
 #include "fem_host.h"
 
+#include <fcntl.h>
 #include <omp.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -44,22 +48,19 @@ T *dup_vec(const std::vector<T> &v) {
 class ByteStream {
  public:
   explicit ByteStream(gzFile f) : f_(f), buf_(1u << 20) {}
+  ByteStream(const char *mem, size_t len) : mem_(mem), mem_len_(len) {}
+  // bytes handed out so far (memory source: the offset of the next byte in the map)
+  size_t tell() const { return mem_ ? mem_pos_ - (end_ - pos_) : consumed_ - (end_ - pos_); }
+  void seek_mem(size_t at) {  // memory source only
+    mem_pos_ = at;
+    pos_ = end_ = 0;
+    eof_ = false;
+  }
   int get() {  // next byte, -1 at end of file, -3 on a read error
     if (pos_ >= end_) {
-      if (eof_) return -1;
-      int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
-      if (n < 0) {
-        eof_ = true;
-        return -3;
-      }
-      if (n == 0) {
-        eof_ = true;
-        return -1;
-      }
-      pos_ = 0;
-      end_ = (size_t)n;
+      if (!refill()) return last_rc_;
     }
-    return (unsigned char)buf_[pos_++];
+    return (unsigned char)cur_[pos_++];
   }
   // Append bytes up to (not including) the next delimiter; returns the delimiter, -1 at EOF (with or
   // without bytes appended; *got tells), -3 on error.  line=true: delimiter '\n'; else any isspace().
@@ -67,32 +68,62 @@ class ByteStream {
     *got = false;
     for (;;) {
       if (pos_ >= end_) {
-        int c = get();
-        if (c < 0) return c;
-        --pos_;
+        if (!refill()) return last_rc_;
       }
       size_t i = pos_;
       if (line) {
-        const char *nl = (const char *)memchr(buf_.data() + pos_, '\n', end_ - pos_);
-        i = nl ? (size_t)(nl - buf_.data()) : end_;
+        const char *nl = (const char *)memchr(cur_ + pos_, '\n', end_ - pos_);
+        i = nl ? (size_t)(nl - cur_) : end_;
       } else {
-        while (i < end_ && !isspace((unsigned char)buf_[i])) ++i;
+        while (i < end_ && !isspace((unsigned char)cur_[i])) ++i;
       }
-      dst->append(buf_.data() + pos_, i - pos_);
+      dst->append(cur_ + pos_, i - pos_);
       *got = true;
       pos_ = i;
       if (i < end_) {
         ++pos_;
-        return (unsigned char)buf_[i];
+        return (unsigned char)cur_[i];
       }
     }
   }
 
  private:
-  gzFile f_;
+  bool refill() {
+    if (eof_) {
+      last_rc_ = -1;
+      return false;
+    }
+    if (mem_) {
+      if (mem_pos_ >= mem_len_) {
+        eof_ = true;
+        last_rc_ = -1;
+        return false;
+      }
+      size_t n = std::min<size_t>(mem_len_ - mem_pos_, 1u << 20);
+      cur_ = mem_ + mem_pos_;
+      mem_pos_ += n;
+      pos_ = 0, end_ = n;
+      return true;
+    }
+    int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+    if (n <= 0) {
+      eof_ = true;
+      last_rc_ = n < 0 ? -3 : -1;
+      return false;
+    }
+    cur_ = buf_.data();
+    consumed_ += (size_t)n;
+    pos_ = 0, end_ = (size_t)n;
+    return true;
+  }
+  gzFile f_ = nullptr;
+  const char *mem_ = nullptr;
+  size_t mem_len_ = 0, mem_pos_ = 0, consumed_ = 0;
   std::vector<char> buf_;
+  const char *cur_ = nullptr;
   size_t pos_ = 0, end_ = 0;
   bool eof_ = false;
+  int last_rc_ = -1;
 };
 
 }  // namespace
@@ -100,6 +131,9 @@ class ByteStream {
 struct fem_seqfile {
   gzFile gz = nullptr;
   ByteStream *in = nullptr;
+  const char *map = nullptr;  // plain (not gzip) regular files are memory-mapped
+  size_t map_len = 0;
+  bool fast_ok = true;        // 4-line FASTQ so far: the multi-threaded parser may be used
   int last_char = 0;  // header character already consumed by the previous record
   std::string name, comment, seq, qual;
   // one record; returns sequence length, -1 end of file, -2 truncated quality, -3 stream error
@@ -149,10 +183,32 @@ struct fem_seqfile {
 extern "C" {
 
 fem_seqfile *fem_seqfile_open(const char *path) {
-  gzFile gz = gzopen(path, "r");
-  if (!gz) return nullptr;
-  gzbuffer(gz, 1u << 20);
+  // plain regular file -> memory map (parallel parser possible); gzip or anything else -> zlib stream
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return nullptr;
+  struct stat st;
+  unsigned char magic[2] = {0, 0};
+  bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+               !(magic[0] == 0x1f && magic[1] == 0x8b);
   fem_seqfile *f = new fem_seqfile();
+  if (plain) {
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+      f->map = (const char *)m;
+      f->map_len = (size_t)st.st_size;
+      f->in = new ByteStream(f->map, f->map_len);
+      close(fd);
+      return f;
+    }
+  }
+  close(fd);
+  gzFile gz = gzopen(path, "r");
+  if (!gz) {
+    delete f;
+    return nullptr;
+  }
+  gzbuffer(gz, 1u << 20);
   f->gz = gz;
   f->in = new ByteStream(gz);
   return f;
@@ -161,51 +217,200 @@ fem_seqfile *fem_seqfile_open(const char *path) {
 void fem_seqfile_close(fem_seqfile *f) {
   if (!f) return;
   delete f->in;
-  gzclose(f->gz);
+  if (f->map) munmap((void *)f->map, f->map_len);
+  if (f->gz) gzclose(f->gz);
   delete f;
 }
 
+namespace {
+
+struct ParsedChunk {
+  std::string bases, quals, names;
+  std::vector<uint32_t> len, name_len;
+  bool any_qual = false, all_qual = true;
+};
+
+int finish_seqset(const std::vector<ParsedChunk> &parts, fem_seqset *out) {
+  uint64_t n = 0, nb = 0, nn = 0;
+  bool any_qual = false, all_qual = true;
+  for (const ParsedChunk &c : parts) {
+    n += c.len.size(), nb += c.bases.size(), nn += c.names.size();
+    any_qual = any_qual || c.any_qual;
+    all_qual = all_qual && c.all_qual;
+  }
+  memset(out, 0, sizeof *out);
+  out->n = n;
+  out->bases = (char *)malloc(nb + 64);
+  out->names = (char *)malloc(nn + 1);
+  out->off = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+  out->name_off = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+  const bool keep_qual = any_qual && all_qual;
+  if (keep_qual) out->quals = (char *)malloc(nb + 1);
+  if (!out->bases || !out->names || !out->off || !out->name_off || (keep_qual && !out->quals)) return -4;
+  std::vector<uint64_t> r0(parts.size() + 1, 0), b0(parts.size() + 1, 0), n0(parts.size() + 1, 0);
+  for (size_t i = 0; i < parts.size(); ++i) {
+    r0[i + 1] = r0[i] + parts[i].len.size();
+    b0[i + 1] = b0[i] + parts[i].bases.size();
+    n0[i + 1] = n0[i] + parts[i].names.size();
+  }
+#pragma omp parallel for schedule(static, 1) num_threads((int)std::max<size_t>(1, std::min<size_t>(parts.size(), 64)))
+  for (int64_t i = 0; i < (int64_t)parts.size(); ++i) {
+    const ParsedChunk &c = parts[(size_t)i];
+    memcpy(out->bases + b0[i], c.bases.data(), c.bases.size());
+    if (keep_qual) memcpy(out->quals + b0[i], c.quals.data(), c.quals.size());
+    memcpy(out->names + n0[i], c.names.data(), c.names.size());
+    uint64_t b = b0[i], m = n0[i];
+    for (size_t k = 0; k < c.len.size(); ++k) {
+      out->off[r0[i] + k] = b;
+      out->name_off[r0[i] + k] = m;
+      b += c.len[k];
+      m += c.name_len[k];
+    }
+  }
+  out->off[n] = nb;
+  out->name_off[n] = nn;
+  memset(out->bases + nb, 0, 64);
+  return 0;
+}
+
+void push_record(ParsedChunk &c, const char *name, size_t name_len, const char *seq, size_t len, const char *qual) {
+  c.bases.append(seq, len);
+  if (qual) {
+    c.any_qual = true;
+    c.quals.append(qual, len);
+  } else {
+    c.all_qual = false;
+    c.quals.append(len, '\0');
+  }
+  c.names.append(name, name_len);
+  c.len.push_back((uint32_t)len);
+  c.name_len.push_back((uint32_t)name_len);
+}
+
+// start of the first 4-line FASTQ record at or after `from`: a line that begins with '@' whose second-next line
+// begins with '+' (a quality line may begin with '@', but then the second-next line is a sequence line)
+size_t next_fastq_record(const char *m, size_t len, size_t from) {
+  size_t p = from;
+  if (p > 0 && m[p - 1] != '\n') {
+    const char *nl = (const char *)memchr(m + p, '\n', len - p);
+    if (!nl) return len;
+    p = (size_t)(nl - m) + 1;
+  }
+  while (p < len) {
+    const char *l1 = (const char *)memchr(m + p, '\n', len - p);
+    if (!l1) return len;
+    const char *l2 = (const char *)memchr(l1 + 1, '\n', len - (size_t)(l1 + 1 - m));
+    if (!l2) return len;
+    if (m[p] == '@' && (size_t)(l2 + 1 - m) < len && l2[1] == '+') return p;
+    p = (size_t)(l1 - m) + 1;
+  }
+  return len;
+}
+
+// strict 4-line FASTQ over [lo, hi) (record boundaries); false if anything else shows up
+bool parse_fastq_range(const char *m, size_t lo, size_t hi, ParsedChunk &c) {
+  size_t p = lo;
+  while (p < hi) {
+    if (m[p] == '\n') {  // blank line between records
+      ++p;
+      continue;
+    }
+    if (m[p] != '@') return false;
+    const char *e0 = (const char *)memchr(m + p, '\n', hi - p);
+    if (!e0) return false;
+    const char *s1 = e0 + 1;
+    const char *e1 = (const char *)memchr(s1, '\n', hi - (size_t)(s1 - m));
+    if (!e1) return false;
+    const char *s2 = e1 + 1;
+    if (s2 >= m + hi || *s2 != '+') return false;
+    const char *e2 = (const char *)memchr(s2, '\n', hi - (size_t)(s2 - m));
+    if (!e2) return false;
+    const char *s3 = e2 + 1;
+    const char *e3 = (const char *)memchr(s3, '\n', hi - (size_t)(s3 - m));
+    if (!e3) e3 = m + hi;  // last line of the file without a newline
+    size_t name_len = 0;
+    while (m + p + 1 + name_len < e0 && !isspace((unsigned char)m[p + 1 + name_len])) ++name_len;
+    size_t sl = (size_t)(e1 - s1), ql = (size_t)(e3 - s3);
+    if (sl > 1 && s1[sl - 1] == '\r') --sl;  // kseq strips a trailing CR
+    if (ql > 1 && s3[ql - 1] == '\r') --ql;
+    if (sl != ql) return false;                           // multi-line or truncated: let the exact parser decide
+    if (sl > 0 && (s1[0] == '>' || s1[0] == '@' || s1[0] == '+')) return false;
+    if (sl > 0) push_record(c, m + p + 1, name_len, s1, sl, s3);  // zero-length records are skipped
+    p = (size_t)(e3 - m) + (e3 < m + hi ? 1 : 0);
+  }
+  return true;
+}
+
+}  // namespace
+
 int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
   if (!f || !out) return -1;
-  std::string bases, quals, names;
-  std::vector<uint64_t> off{0}, name_off{0};
-  bool any_qual = false, all_qual = true;
+  std::vector<ParsedChunk> parts(1);
   int rc = 0;
-  while (max_seqs == 0 || off.size() - 1 < max_seqs) {
+  while (max_seqs == 0 || parts[0].len.size() < max_seqs) {
     long len = f->next();
     if (len == 0) continue;  // zero-length records are skipped (src/sequence_batch.c:50-52)
     if (len < 0) {
       if (len != -1) rc = (int)len;  // "Didn't reach the end of sequence file, which might be corrupted!"
       break;
     }
-    bases += f->seq;
-    if (!f->qual.empty()) {
-      any_qual = true;
-      quals += f->qual;
-    } else {
-      all_qual = false;
-      quals.append(f->seq.size(), '\0');
+    push_record(parts[0], f->name.data(), f->name.size(), f->seq.data(), f->seq.size(),
+                f->qual.empty() ? nullptr : f->qual.data());
+  }
+  int frc = finish_seqset(parts, out);
+  return frc ? frc : rc;
+}
+
+int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_seqset *out) {
+  if (!f || !out) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const size_t pos0 = f->in->tell();
+  // ---- memory-mapped plain file at a record boundary: split the window between threads ----
+  if (f->map && f->fast_ok && f->last_char == 0) {
+    const char *m = f->map;
+    const size_t len = f->map_len;
+    size_t lo = pos0;
+    while (lo < len && m[lo] != '@' && m[lo] != '>') ++lo;  // kseq skips to the first header character
+    if (lo >= len) {
+      std::vector<ParsedChunk> none(1);
+      f->in->seek_mem(len);
+      return finish_seqset(none, out);
     }
-    names += f->name;
-    off.push_back(bases.size());
-    name_off.push_back(names.size());
+    size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
+    if (m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
+      const size_t span = hi - lo;
+      int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, span / (1u << 20) + 1));
+      std::vector<size_t> cut((size_t)nt + 1, hi);
+      cut[0] = lo;
+      for (int t = 1; t < nt; ++t) cut[(size_t)t] = std::min(hi, next_fastq_record(m, len, lo + span * (size_t)t / (size_t)nt));
+      for (int t = 1; t <= nt; ++t) cut[(size_t)t] = std::max(cut[(size_t)t], cut[(size_t)t - 1]);
+      std::vector<ParsedChunk> parts((size_t)nt);
+      bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(nt) reduction(&& : ok)
+      for (int t = 0; t < nt; ++t) ok = parse_fastq_range(m, cut[(size_t)t], cut[(size_t)t + 1], parts[(size_t)t]) && ok;
+      if (ok) {
+        f->in->seek_mem(hi);
+        return finish_seqset(parts, out);
+      }
+    }
+    f->fast_ok = false;  // FASTA, multi-line FASTQ or malformed input: the exact sequential reader takes over
+    f->in->seek_mem(pos0);
   }
-  memset(out, 0, sizeof *out);
-  out->n = off.size() - 1;
-  out->bases = (char *)malloc(bases.size() + 64);
-  out->names = (char *)malloc(names.size() + 1);
-  out->off = dup_vec(off);
-  out->name_off = dup_vec(name_off);
-  if (!out->bases || !out->names || !out->off || !out->name_off) return -4;
-  memcpy(out->bases, bases.data(), bases.size());
-  memset(out->bases + bases.size(), 0, 64);
-  memcpy(out->names, names.data(), names.size());
-  if (any_qual && all_qual) {
-    out->quals = (char *)malloc(quals.size() + 1);
-    if (!out->quals) return -4;
-    memcpy(out->quals, quals.data(), quals.size());
+  // ---- sequential, kseq-exact ----
+  std::vector<ParsedChunk> parts(1);
+  int rc = 0;
+  while (approx_bytes == 0 || f->in->tell() - pos0 < approx_bytes) {
+    long l = f->next();
+    if (l == 0) continue;
+    if (l < 0) {
+      if (l != -1) rc = (int)l;
+      break;
+    }
+    push_record(parts[0], f->name.data(), f->name.size(), f->seq.data(), f->seq.size(),
+                f->qual.empty() ? nullptr : f->qual.data());
   }
-  return rc;
+  int frc = finish_seqset(parts, out);
+  return frc ? frc : rc;
 }
 
 void fem_seqset_free(fem_seqset *s) {

@@ -38,6 +38,10 @@ void fem_seqfile_close(fem_seqfile *f);
 /* Reads up to max_seqs records (0 = all), skipping zero-length ones as the reference does
  * (src/sequence_batch.c:50-52,88-89).  Returns 0, or <0 on a malformed / truncated file. */
 int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out);
+/* Reads whole records covering about approx_bytes of input (0 = the rest of the file).  Plain 4-line FASTQ files
+ * are memory-mapped and parsed by n_threads threads; gzip, FASTA and multi-line records go through the
+ * sequential reader (same records either way). */
+int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_seqset *out);
 void fem_seqset_free(fem_seqset *s);
 
 /* ---------------- index files (src/index.c:100-168) ---------------- */

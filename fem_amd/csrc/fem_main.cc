@@ -268,6 +268,21 @@ int map_main(int argc, char **argv) {
   }
 
   double t_start = real_time();
+  const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
+  // stage 4: one writer thread drains formatted SAM text (src/output_queue.c:60-91)
+  struct Text {
+    char *p;
+    uint64_t n;
+  };
+  Channel<Text> to_write(4);
+  std::thread writer([&] {
+    for (;;) {
+      Text t = to_write.pop();
+      if (!t.p) break;
+      fwrite(t.p, 1, t.n, out);
+      free(t.p);
+    }
+  });
   // stage 1: one reader thread parses FASTQ into batches (src/input_queue.c:53-79)
   Channel<Batch *> parsed(4);
   std::thread reader([&] {
@@ -278,7 +293,8 @@ int map_main(int argc, char **argv) {
     for (;;) {
       Batch *b = new Batch();
       b->id = id++;
-      int rc = ok ? fem_seqfile_read(f, batch_reads, &b->reads) : -1;
+      // batches are cut by bytes (~ batch_reads records of this file's shape); plain FASTQ is parsed by all threads
+      int rc = ok ? fem_seqfile_read_bytes(f, batch_bytes, n_threads, &b->reads) : -1;
       if (rc != 0 && ok) fprintf(stderr, "Didn't reach the end of sequence file, which might be corrupted!");
       if (rc != 0 || b->reads.n == 0) {
         b->last = true;
@@ -314,8 +330,7 @@ int map_main(int argc, char **argv) {
         fprintf(stderr, "[FEM] out of memory while formatting SAM records\n");
         exit_code = EXIT_FAILURE;
       } else {
-        fwrite(text, 1, len, out);
-        free(text);
+        to_write.push(Text{text, len});
       }
       for (int i = 0; i < 5; ++i) per_gpu[(size_t)f.gpu * 5 + (size_t)i] += res.stats[i];
       fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - t0);
@@ -362,6 +377,8 @@ int map_main(int argc, char **argv) {
     flight.pop_front();
   }
   reader.join();
+  to_write.push(Text{nullptr, 0});
+  writer.join();
   fclose(out);
 
   // MappingStats reduction (src/FEM_map.c:200-212): across GPUs it is one RCCL all-reduce of 5 counters

@@ -46,6 +46,7 @@ def lib():
         L.fem_seqfile_close.argtypes = [vp]
         L.fem_seqfile_read.argtypes = [vp, u64, C.POINTER(SeqSet)]
         L.fem_seqset_free.argtypes = [C.POINTER(SeqSet)]
+        L.fem_seqfile_read_bytes.argtypes = [vp, u64, C.c_int, C.POINTER(SeqSet)]
         L.fem_index_save.argtypes = [C.c_char_p, i32, i32, vp, u64, vp]
         L.fem_index_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(u64),
                                      C.POINTER(vp)]
@@ -145,6 +146,30 @@ def read_sequences(path, max_seqs=0):
         return Sequences(s)
     finally:
         L.fem_seqset_free(C.byref(s))
+
+
+def read_sequences_in_chunks(path, approx_bytes, threads=4):
+    """All records of a file through fem_seqfile_read_bytes (the CLI's batch reader), one Sequences per batch."""
+    L = lib()
+    f = L.fem_seqfile_open(path.encode())
+    if not f:
+        raise FileNotFoundError(path)
+    out = []
+    try:
+        while True:
+            s = SeqSet()
+            rc = L.fem_seqfile_read_bytes(f, approx_bytes, threads, C.byref(s))
+            try:
+                if rc != 0:
+                    raise ValueError("malformed sequence file %s (rc=%d)" % (path, rc))
+                if s.n == 0:
+                    break
+                out.append(Sequences(s))
+            finally:
+                L.fem_seqset_free(C.byref(s))
+    finally:
+        L.fem_seqfile_close(f)
+    return out
 
 
 def index_save(path, k, step, lookup, occ):

@@ -107,6 +107,41 @@ def test_fasta_fastq_parsing_follows_kseq(tmp_path):
         host.read_sequences(str(bad))
 
 
+def test_parallel_fastq_reader_equals_sequential_reader(tmp_path):
+    rng = np.random.default_rng(11)
+    n, L = 30_000, 100
+    recs = []
+    for i in range(n):
+        ln = L if i % 7 else int(rng.integers(1, 2 * L))
+        seq = util.rand_seq(rng, ln)
+        qual = bytes(rng.integers(33, 74, size=ln).astype(np.uint8))  # includes '@' and '+' as first characters
+        recs.append(b"@r%d extra\n" % i + seq + (b"\r\n" if i % 11 == 0 else b"\n") + b"+\n" + qual + b"\n")
+    recs.insert(5, b"@empty\n\n+\n\n")  # zero-length record: skipped by both readers
+    fq = tmp_path / "big.fq"
+    fq.write_bytes(b"".join(recs))
+    assert fq.stat().st_size > 4 << 20
+    whole = host.read_sequences(str(fq))
+    assert whole.n == n
+    for approx in (0, 1 << 20, 700_001):
+        parts = host.read_sequences_in_chunks(str(fq), approx, threads=4)
+        assert sum(p.n for p in parts) == n
+        assert b"".join(p.bases.tobytes() for p in parts) == whole.bases.tobytes()
+        assert b"".join(p.quals.tobytes() for p in parts) == whole.quals.tobytes()
+        assert b"".join(p.names_raw.tobytes() for p in parts) == whole.names_raw.tobytes()
+        lens = np.concatenate([np.diff(p.off.astype(np.int64)) for p in parts])
+        assert np.array_equal(lens, np.diff(whole.off.astype(np.int64)))
+    # multi-line FASTQ and gzip take the sequential path and give the same records
+    ml = tmp_path / "multiline.fq"
+    ml.write_bytes(b"@a\nACGT\nACG\n+\nIIII\nIII\n@b x\nTTTT\n+\nJJJJ\n")
+    parts = host.read_sequences_in_chunks(str(ml), 8, threads=3)
+    assert [p.seq(i) for p in parts for i in range(p.n)] == [b"ACGTACG", b"TTTT"]
+    gzp = tmp_path / "big.fq.gz"
+    with gzip.open(str(gzp), "wb", compresslevel=1) as f:
+        f.write(fq.read_bytes())
+    parts = host.read_sequences_in_chunks(str(gzp), 1 << 20, threads=4)
+    assert b"".join(p.bases.tobytes() for p in parts) == whole.bases.tobytes()
+
+
 def test_index_file_is_byte_compatible(tmp_path):
     rng = np.random.default_rng(2)
     ref = fo.Reference([util.rand_seq(rng, 30_000), util.rand_seq(rng, 999)])
