@@ -201,8 +201,8 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.picked = take(n_groups * R * 16u);
   l.X = take(64u * 8u);  // scatter
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
-    l.xcap = (uint32_t)femk::kMaxChunks * 64u;
-    l.F = take(femk::kBloomSlots / 16u * 4u);  // bitmap: two bits per key slot
+    l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;
+    l.F = take(femk::bloom_slots((int)R) / 16u * 4u);  // bitmap: two bits per key slot
   }
   l.wave_bytes = o;
   return l;

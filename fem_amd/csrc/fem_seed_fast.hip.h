@@ -163,15 +163,19 @@ __device__ uint32_t lists_in_lanes(const SeedParams &p, uint32_t lane0, uint64_t
 //   * survivors are sorted in lanes and merged greedily (src/filter.c:45-78).
 // Returns the number of candidates (in cv), or 0xFFFFFFFF if a group does not fit (the read is then queued).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kMaxChunks = 8;             // a group may select up to 8 * 64 occurrences
-constexpr uint32_t kBloomSlots = 16384u;  // two bits each: 4 KiB of LDS per wave
+// a group may select up to chunks * 64 occurrences: more seeds per group (larger e) mean longer lists
+constexpr int bloom_chunks(int R) { return R >= 7 ? 12 : 8; }
+// key slots of the pre-filter bitmap (two bits each): chance flags grow like n^2 / slots, so the long lists of
+// large R get twice the slots (4 KiB / 8 KiB of LDS per wave)
+constexpr uint32_t bloom_slots(int R) { return R >= 7 ? 32768u : 16384u; }
 
 template <int R>
 __device__ uint32_t lists_bloom_join(const SeedParams &p, uint32_t lane0, const uint32_t *group_total, uint32_t s_start,
                                      uint32_t s_lo, uint32_t s_freq, uint64_t *scatter, uint32_t *bloom, uint64_t &cv) {
   const uint32_t ln = lane_id();
   const uint64_t e64 = (uint64_t)p.e;
-  constexpr uint32_t kMask = kBloomSlots - 1u;
+  constexpr int kMaxChunks = bloom_chunks(R);
+  constexpr uint32_t kMask = bloom_slots(R) - 1u;
   uint32_t nA = 0;
   for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
     const uint32_t n_g = group_total[g];
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
   if (HASH)
-    for (uint32_t i = ln; i < kBloomSlots / 16u; i += kWave) bloom[i] = 0;
+    for (uint32_t i = ln; i < bloom_slots(R) / 16u; i += kWave) bloom[i] = 0;
   const uint32_t smax = p.lay.smax;
   const uint64_t e64 = (uint64_t)p.e;
   unsigned long long pre_sum = 0, cand_sum = 0;
