@@ -1,0 +1,44 @@
+"""Committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the ORACLE — the reference has no
+golden vectors and cannot be built here): the oracle must still reproduce them, and so must the device path."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import CASES, inputs, oracle_outputs
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_the_fixture(name):
+    want = np.load(os.path.join(HERE, name + ".npz"))
+    got = oracle_outputs(CASES[name])
+    for key in want.files:
+        assert np.array_equal(want[key], got[key]), key
+    if name == "c1_seed1":
+        assert int(want["stats"][0]) == 1000 and 700 < int(want["stats"][1]) < 950  # config 1: most reads map
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_reproduces_the_fixture(name):
+    import hashlib
+    from fem_amd import Device
+    case = CASES[name]
+    want = np.load(os.path.join(HERE, name + ".npz"))
+    text, off, lens, bases, offs = inputs(case)
+    dev = Device(0)
+    try:
+        dev.upload_reference([text[int(o):int(o) + int(l)] for o, l in zip(off, lens)])
+        n, lookup, occ = dev.build_index(12, 3)
+        assert np.array_equal(np.frombuffer(hashlib.sha256(lookup.tobytes() + occ.tobytes()).digest(), np.uint8),
+                              want["index_sha256"])
+        r = dev.map_batch(bases, offs, e=case["e"], a=case["a"])
+        o, cand, ed, end = r.per_strand()
+        assert np.array_equal(r.stats, want["stats"])
+        assert np.array_equal(o, want["cand_off"]) and np.array_equal(cand, want["cands"])
+        assert np.array_equal(ed, want["v_ed"])
+        assert np.array_equal(end[ed != 0xFF], want["v_end"][want["v_ed"] != 0xFF])
+    finally:
+        dev.close()
