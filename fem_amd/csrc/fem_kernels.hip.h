@@ -1004,6 +1004,11 @@ struct VerifyParams {
   unsigned long long *stats;   // [2] mappings, [3] mapped reads
 };
 
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p) {
+  uint4 w;
+  __builtin_memcpy(&w, p, 16);
+  return w;
+}
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
   uint32_t w;
   __builtin_memcpy(&w, p, 4);  // gfx950 global loads take any byte address
@@ -1073,34 +1078,42 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
         m.B2 |= ((pc >> 2) & 1u) << j;
       }
       bool rejected = false;
-      // four columns per step; the loads of the next step are issued before this step's arithmetic
-      const int n_full = L & ~3;
+      // sixteen columns per step from one 16-byte load of reference codes and one of read characters (each lane
+      // walks its own window, so wide loads are what keeps the request count down); the loads of the next step
+      // are issued before this step's arithmetic
+      const int n_full = L & ~15;
       const uint8_t *pp = pat + 2 * e;
-      uint32_t pw = 0, rw = 0;
+      uint4 pw = make_uint4(0, 0, 0, 0), rw = make_uint4(0, 0, 0, 0);
       if (n_full > 0) {
-        pw = load_u32_unaligned(pp);
-        rw = load_u32_unaligned(strand == 0 ? rd : rd + L - 4);
+        pw = load_u128_unaligned(pp);
+        rw = load_u128_unaligned(strand == 0 ? rd : rd + L - 16);
       }
-      for (int col = 0; col < n_full && !rejected; col += 4) {
-        const uint32_t pw_cur = pw, rw_cur = rw;
-        if (col + 4 < n_full) {
-          pw = load_u32_unaligned(pp + col + 4);
-          rw = load_u32_unaligned(strand == 0 ? rd + col + 4 : rd + L - 8 - col);
+      for (int col = 0; col < n_full && !rejected; col += 16) {
+        const uint4 pw_cur = pw, rw_cur = rw;
+        if (col + 16 < n_full) {
+          pw = load_u128_unaligned(pp + col + 16);
+          rw = load_u128_unaligned(strand == 0 ? rd + col + 16 : rd + L - 32 - col);
         }
+        const uint32_t pws[4] = {pw_cur.x, pw_cur.y, pw_cur.z, pw_cur.w};
+        const uint32_t rws[4] = {rw_cur.x, rw_cur.y, rw_cur.z, rw_cur.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          uint32_t pc = (pw_cur >> (8 * q)) & 0xFFu;
+        for (int q = 0; q < 16; ++q) {
+          const uint32_t pc = (pws[q >> 2] >> (8 * (q & 3))) & 0xFFu;
           uint32_t tc;
           if (strand == 0) {
-            tc = base_code((rw_cur >> (8 * q)) & 0xFFu);
+            tc = base_code((rws[q >> 2] >> (8 * (q & 3))) & 0xFFu);
           } else {  // prepare_negative_sequence_at (src/sequence_batch.h:90-98): read backwards, complement
-            tc = base_code((rw_cur >> (8 * (3 - q))) & 0xFFu);
+            const int qq = 15 - q;
+            tc = base_code((rws[qq >> 2] >> (8 * (qq & 3))) & 0xFFu);
             tc = tc < 4u ? 3u - tc : 4u;
           }
-          if (!rejected) rejected = myers_column(m, pc, tc, e, band, wm);
+          (void)myers_column(m, pc, tc, e, band, wm);
         }
+        // the score along the band's lowest diagonal never decreases, so testing the early-reject threshold
+        // (src/align.c:128-130) once per step rejects exactly the candidates a per-column test would
+        rejected = m.score > 3 * e;
       }
-      for (int col = n_full; col < L && !rejected; ++col) {  // up to three trailing columns
+      for (int col = n_full; col < L && !rejected; ++col) {  // up to fifteen trailing columns
         uint32_t pc = pp[col];
         uint32_t tc;
         if (strand == 0) {
