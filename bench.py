@@ -131,10 +131,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    fast_ms, fast_n = dev.kernel_time(0)   # seed_fast_kernel<R>
+    # per-kernel HIP-event totals over the timed region (a step may launch a kernel more than once: large batches
+    # are seeded and verified in two halves so that the verification of one overlaps the seeding of the other)
+    fast_ms, fast_n = dev.kernel_time(0)   # seed_fast_kernel<R, ...>
     ver_ms, ver_n = dev.kernel_time(1)     # verify_kernel
     gen_ms, gen_n = dev.kernel_time(2)     # seed_filter_kernel (generic form: queued reads)
-    seed_ms, seed_n = fast_ms + gen_ms, max(fast_n, gen_n)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n_reads * args.steps / elapsed / 1e6
 
@@ -143,13 +144,18 @@ def main():
     S = L - k + 1
     seed_bytes = N * L + 16 * S * N + 8 * P      # read bases + one 8-byte lookup pair per seed and strand + occurrences
     verify_bytes = (L + 2 * e) * Cn + 16 * M     # reference window per verification + result record
-    per_launch = {"seed_fast_kernel": fast_ms / max(fast_n, 1), "seed_filter_kernel": gen_ms / max(gen_n, 1),
-                  "verify_kernel": ver_ms / max(ver_n, 1)}
-    dominant = max(per_launch, key=per_launch.get)
-    dom_ms = per_launch[dominant]
+    step_ms = {"seed_fast_kernel": fast_ms / args.steps, "seed_filter_kernel": gen_ms / args.steps,
+               "verify_kernel": ver_ms / args.steps}
+    launches = {"seed_fast_kernel": fast_n / args.steps, "seed_filter_kernel": gen_n / args.steps,
+                "verify_kernel": ver_n / args.steps}
+    dominant = max(step_ms, key=step_ms.get)
     # the two seed kernels split the same reads: the dominant one is charged the seeding bytes of the whole batch
-    dom_bytes = verify_bytes if dominant == "verify_kernel" else seed_bytes
+    dom_bytes_step = verify_bytes if dominant == "verify_kernel" else seed_bytes
+    n_launch = max(launches[dominant], 1.0)
+    dom_ms = step_ms[dominant] / n_launch          # mean duration of one launch
+    dom_bytes = dom_bytes_step / n_launch          # algorithmic bytes of one launch
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    per_launch = {k_: (step_ms[k_] / max(launches[k_], 1.0)) for k_ in step_ms}
 
     if rank != 0:
         if world > 1:
@@ -167,7 +173,7 @@ def main():
             for kname, ctr in prof["kernels"].items():
                 if dominant.split("_kernel")[0] in kname and "FETCH_SIZE" in ctr and ctr["FETCH_SIZE"]["mean_per_launch"] > 1e3:
                     kib = ctr["FETCH_SIZE"]["mean_per_launch"] + ctr.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
-                    traffic = int(kib * 1024 * n_reads / prof["reads_per_launch"])
+                    traffic = int(kib * 1024 * (n_reads / n_launch) / prof["reads_per_launch"])
         except Exception as ex:  # a malformed profile file must not break the measurement
             log("could not read %s: %s" % (tpath, ex))
 
@@ -182,11 +188,12 @@ def main():
                                 "pre_filter": int(total_stats[2]), "candidates": int(total_stats[3]),
                                 "mappings": int(total_stats[4])},
                    "algorithmic_bytes_per_step_per_gpu": seed_bytes + verify_bytes,
-                   "kernel_ms": {k_: round(v_, 4) for k_, v_ in per_launch.items()},
+                   "kernel_ms_per_launch": {k_: round(v_, 4) for k_, v_ in per_launch.items()},
+                   "kernel_launches_per_step": {k_: round(v_, 2) for k_, v_ in launches.items()},
                    "h2d_stage_s": round(h2d_s, 3)},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
+                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
     }
 
     if not args.no_cpu and world == 1:

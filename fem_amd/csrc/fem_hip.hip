@@ -30,6 +30,8 @@ struct TimedLaunch {
 
 struct Slot {
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // verification of the first half of a batch, overlapped with the seeding of the second
+  hipEvent_t ev_half = nullptr, ev_verified = nullptr;
   // inputs
   uint8_t *d_bases = nullptr;
   size_t bases_cap = 0;
@@ -314,6 +316,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   sp.bases = s.d_bases;
   sp.read_off = s.d_off;
   sp.n_reads = (uint32_t)s.n_reads;
+  sp.read_begin = 0;
   sp.lookup = h->d_lookup;
   sp.occ = h->d_occ;
   sp.inf32 = (uint32_t)h->n_occ;
@@ -345,16 +348,16 @@ int launch_batch(fem_dev *h, Slot &s) {
   };
   if (sp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
 
-  auto timed = [&](int id, auto &&launch) -> int {
+  auto timed = [&](int id, hipStream_t st, auto &&launch) -> int {
     TimedLaunch t{id, nullptr, nullptr};
     if (h->timing) {
       t.start = get_event(h), t.stop = get_event(h);
-      HIP_TRY(h, hipEventRecord(t.start, s.stream));
+      HIP_TRY(h, hipEventRecord(t.start, st));
     }
     launch();
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
-      HIP_TRY(h, hipEventRecord(t.stop, s.stream));
+      HIP_TRY(h, hipEventRecord(t.stop, st));
       s.pending.push_back(t);
     }
     return FEM_OK;
@@ -362,6 +365,15 @@ int launch_batch(fem_dev *h, Slot &s) {
 
   if (s.n_reads) {
     int rc;
+    femk::VerifyParams vp{};
+    vp.bases = s.d_bases, vp.read_off = s.d_off;
+    vp.ref_codes = h->d_ref, vp.seq_off = h->d_seq_off;
+    vp.cand = s.d_cand, vp.cand_meta = s.d_meta, vp.cand_begin = s.d_begin, vp.cand_count = s.d_count;
+    vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
+    vp.ed = s.d_ed, vp.end = s.d_end, vp.n_map = s.d_nmap, vp.stats = d_stats;
+    vp.first = nullptr, vp.last = d_ctr;
+    const uint32_t vgrid = (uint32_t)h->n_cu * 8u;
+    bool halves = false;
     if (use_fast) {
       femk::SeedParams fp = sp;
       // long occurrence lists (dense index): the hash-join form of the kernel; short ones: lists in lanes only
@@ -369,40 +381,54 @@ int launch_batch(fem_dev *h, Slot &s) {
       fp.lay = make_layout_fast(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k), hash);
       uint32_t wpb, lds_bytes, grid;
       shape(fp.lay, &wpb, &lds_bytes, &grid);
-      rc = timed(0, [&] {
+      auto launch_range = [&](uint32_t lo, uint32_t hi) {
+        femk::SeedParams q = fp;
+        q.read_begin = lo, q.n_reads = hi;
         dim3 g(grid), b(64u * wpb);
         switch (R) {
-          case 1: launch_fast<1>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 2: launch_fast<2>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 3: launch_fast<3>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 4: launch_fast<4>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 5: launch_fast<5>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 6: launch_fast<6>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 7: launch_fast<7>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 8: launch_fast<8>(hash, g, b, lds_bytes, s.stream, fp); break;
-          case 9: launch_fast<9>(hash, g, b, lds_bytes, s.stream, fp); break;
-          default: launch_fast<10>(hash, g, b, lds_bytes, s.stream, fp); break;
+          case 1: launch_fast<1>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 2: launch_fast<2>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 3: launch_fast<3>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 4: launch_fast<4>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 5: launch_fast<5>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 6: launch_fast<6>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 7: launch_fast<7>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 8: launch_fast<8>(hash, g, b, lds_bytes, s.stream, q); break;
+          case 9: launch_fast<9>(hash, g, b, lds_bytes, s.stream, q); break;
+          default: launch_fast<10>(hash, g, b, lds_bytes, s.stream, q); break;
         }
-      });
+      };
+      // Large batches are seeded in two halves: the (latency-bound) verification of the first half runs on a
+      // second stream while the second half is being seeded.  ctr[3] snapshots the candidate cursor in between.
+      const uint32_t n_all = (uint32_t)s.n_reads;
+      const uint32_t half = n_all >= (1u << 20) ? ((n_all / 2u) & ~15u) : n_all;
+      halves = half < n_all;
+      rc = timed(0, s.stream, [&] { launch_range(0, half); });
       if (rc) return rc;
+      if (halves) {
+        HIP_TRY(h, hipMemcpyAsync(d_ctr + 3, d_ctr, sizeof(uint32_t), hipMemcpyDeviceToDevice, s.stream));
+        HIP_TRY(h, hipEventRecord(s.ev_half, s.stream));
+        HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_half, 0));
+        femk::VerifyParams va = vp;
+        va.first = nullptr, va.last = d_ctr + 3;
+        rc = timed(1, s.stream2, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream2, va); });
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(s.ev_verified, s.stream2));
+        rc = timed(0, s.stream, [&] { launch_range(half, n_all); });
+        if (rc) return rc;
+        vp.first = d_ctr + 3;
+      }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the fast one queued
     }
     {
       uint32_t wpb, lds_bytes, grid;
       shape(sp.lay, &wpb, &lds_bytes, &grid);
-      rc = timed(2, [&] { hipLaunchKernelGGL(femk::seed_filter_kernel, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, sp); });
+      rc = timed(2, s.stream, [&] { hipLaunchKernelGGL(femk::seed_filter_kernel, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, sp); });
       if (rc) return rc;
     }
-
-    femk::VerifyParams vp{};
-    vp.bases = s.d_bases, vp.read_off = s.d_off;
-    vp.ref_codes = h->d_ref, vp.seq_off = h->d_seq_off;
-    vp.cand = s.d_cand, vp.cand_meta = s.d_meta, vp.cand_begin = s.d_begin, vp.cand_count = s.d_count;
-    vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
-    vp.ed = s.d_ed, vp.end = s.d_end, vp.n_map = s.d_nmap, vp.stats = d_stats;
-    const uint32_t vgrid = (uint32_t)h->n_cu * 8u;
-    rc = timed(1, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
+    rc = timed(1, s.stream, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
     if (rc) return rc;
+    if (halves) HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_verified, 0));
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.mapped = true;
@@ -467,7 +493,10 @@ int fem_dev_open(int device, fem_dev **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
   for (int i = 0; i < kSlots; ++i) {
-    if (hipStreamCreateWithFlags(&h->slot[i].stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->slot[i].stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->slot[i].stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->slot[i].ev_half, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->slot[i].ev_verified, hipEventDisableTiming) != hipSuccess) {
       delete h;
       return FEM_ERR_HIP;
     }
@@ -494,6 +523,9 @@ int fem_dev_close(fem_dev *h) {
                     (void *)s.h_end})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.stream2) (void)hipStreamDestroy(s.stream2);
+    if (s.ev_half) (void)hipEventDestroy(s.ev_half);
+    if (s.ev_verified) (void)hipEventDestroy(s.ev_verified);
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len,

@@ -46,7 +46,8 @@ struct SeedLayout {
 struct SeedParams {
   const uint8_t *bases;
   const uint64_t *read_off;
-  uint32_t n_reads;
+  uint32_t n_reads;     // one past the last read of this launch
+  uint32_t read_begin;  // first read of this launch (seed_fast_kernel; the generic kernel always covers its queue / all reads)
   const uint32_t *lookup;
   const uint64_t *occ;
   uint32_t inf32;  // (uint32_t)occurrence_table_size, the DP's +inf (src/filter.c:9)
@@ -995,7 +996,9 @@ struct VerifyParams {
   const uint32_t *cand_meta;
   const uint32_t *cand_begin;
   const uint32_t *cand_count;
-  const uint32_t *ctr;  // [0] = number of candidates produced by the seed kernel
+  const uint32_t *ctr;  // [0] = number of candidates produced by the seed kernels
+  const uint32_t *first;  // candidate range of this launch: [*first (0 if null), *last); lets the verification of one
+  const uint32_t *last;   // half of a batch overlap the seeding of the other half
   uint32_t cand_cap;
   int32_t e;
   uint8_t *ed;
@@ -1044,12 +1047,13 @@ __device__ __forceinline__ bool myers_column(MyersState &m, uint32_t pc, uint32_
 }
 
 __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
-  const uint32_t total = min(p.ctr[0], p.cand_cap);
+  const uint32_t total = min(*p.last, p.cand_cap);
+  const uint32_t from = p.first ? min(*p.first, total) : 0u;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int e = p.e;
   const uint32_t top = 1u << (2 * e);
   const uint32_t band = (top << 1) - 1u;
-  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < total; i0 += stride) {
+  for (uint32_t i0 = from + blockIdx.x * blockDim.x; i0 < total; i0 += stride) {
     uint32_t i = i0 + threadIdx.x;
     bool active = i < total;
     bool accepted = false, first_of_read = false;

@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
   constexpr uint32_t kReadBlock = 16;
-  for (uint32_t r0 = wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
+  for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
   uint32_t blk_begin = 0, blk_count = 0;  // lane 2*i + strand: entry of read r0 + i
   bool blk_mine = false;                   // false for reads left to the generic kernel (it writes their entries)
   for (uint32_t rb = 0; rb < kReadBlock && r0 + rb < p.n_reads; ++rb) {
