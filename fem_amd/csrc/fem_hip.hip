@@ -100,6 +100,7 @@ struct fem_dev {
   uint64_t t_n[3] = {0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
+  bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
   std::vector<hipEvent_t> event_pool;
 };
 
@@ -257,6 +258,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
   }
   if (!s.d_cand) {
     uint64_t want = 2 * s.n_reads + (5u << 20);  // ~1 candidate per strand on typical data + chunk padding
+    if (h->tiny_buffers) want = 512;
     want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
     s.cand_cap = 0;
     size_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -272,7 +274,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     HIP_TRY(h, hipHostMalloc((void **)&s.h_ctl, kCtlBytes, hipHostMallocDefault));
   }
   if (!s.d_arena) {
-    s.arena_cap = 4u << 20;  // entries (32 MiB); grown on demand
+    s.arena_cap = h->tiny_buffers ? 256u : (4u << 20);  // entries (32 MiB); grown on demand
     HIP_TRY(h, hipMalloc((void **)&s.d_arena, s.arena_cap * sizeof(uint64_t)));
   }
   {
@@ -280,6 +282,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     // and is queued; with short ones almost none is.  Size the queue for the likely case, grow + re-run otherwise.
     const double avg_bucket = (double)h->n_occ / (double)(h->n_lookup ? h->n_lookup : 1);
     uint64_t want = avg_bucket > 1.0 ? s.n_reads + (1u << 20) : (1u << 18);
+    if (h->tiny_buffers) want = s.d_slow ? s.slow_cap : 32;
     if (want > s.slow_cap || !s.d_slow) {
       if (s.d_slow) (void)hipFree(s.d_slow);
       s.d_slow = nullptr;
@@ -505,6 +508,8 @@ int fem_dev_open(int device, fem_dev **out) {
   h->force_generic = fg && fg[0] == '1';
   const char *fh = getenv("FEM_FORCE_HASH");
   h->force_hash = fh && fh[0] == '1';
+  const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
+  h->tiny_buffers = tb && tb[0] == '1';
   *out = h;
   return FEM_OK;
 }
