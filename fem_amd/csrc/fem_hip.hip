@@ -16,6 +16,7 @@
 #include "fem_index_build.hip.h"
 #include "fem_kernels.hip.h"
 #include "fem_seed_fast.hip.h"
+#include "fem_tail.hip.h"
 
 namespace {
 
@@ -69,6 +70,7 @@ struct Slot {
   uint64_t stats[5] = {0, 0, 0, 0, 0};
   uint32_t n_cand = 0;
   std::vector<TimedLaunch> pending;
+  femt::Tail *tail = nullptr;  // device mapping tail (fem_dev_fetch_records), created on first use
 };
 
 constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
@@ -87,7 +89,8 @@ struct fem_dev {
   int32_t k = 0, step = 0;
   uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
   // reference
-  uint8_t *d_ref = nullptr;  // base codes
+  uint8_t *d_ref = nullptr;      // base codes
+  uint8_t *d_ref_raw = nullptr;  // the characters as uploaded (the traceback and MD compare and print them)
   uint64_t ref_bytes = 0;
   uint64_t *d_seq_off = nullptr;
   uint32_t *d_seq_len = nullptr;
@@ -96,8 +99,8 @@ struct fem_dev {
   std::vector<uint32_t> seq_len;
   Slot slot[kSlots];
   bool timing = false;
-  double t_ms[3] = {0, 0, 0};
-  uint64_t t_n[3] = {0, 0, 0};
+  double t_ms[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t t_n[6] = {0, 0, 0, 0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
@@ -531,10 +534,12 @@ int fem_dev_close(fem_dev *h) {
     if (s.stream2) (void)hipStreamDestroy(s.stream2);
     if (s.ev_half) (void)hipEventDestroy(s.ev_half);
     if (s.ev_verified) (void)hipEventDestroy(s.ev_verified);
+    delete s.tail;
+    s.tail = nullptr;
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len,
-                  (void *)h->d_nonempty})
+  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
+                  (void *)h->d_seq_len, (void *)h->d_nonempty})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -575,11 +580,12 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     h->seq_off[i] = total;
     total += seq_len[i];
   }
-  for (void *p : {(void *)h->d_ref, (void *)h->d_seq_off, (void *)h->d_seq_len})
+  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len})
     if (p) (void)hipFree(p);
-  h->d_ref = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
+  h->d_ref = nullptr, h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
   // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
   HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 64));
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 64));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_off, n_seq * sizeof(uint64_t)));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_len, n_seq * sizeof(uint32_t)));
   HIP_TRY(h, hipMemset(h->d_ref + total, 4, 64));
@@ -587,6 +593,8 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     if (seq_len[i]) HIP_TRY(h, hipMemcpy(h->d_ref + h->seq_off[i], seq[i], seq_len[i], hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_off, h->seq_off.data(), n_seq * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_len, h->seq_len.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_ref_raw, h->d_ref, total, hipMemcpyDeviceToDevice));
+  HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 64));
   if (total) {
     hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, total);
     HIP_TRY(h, hipGetLastError());
@@ -779,6 +787,32 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
   return FEM_OK;
 }
 
+int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
+  int rc = fem_dev_sync(h, slot);
+  if (rc) return rc;
+  if (!out) return fail(h, FEM_ERR_INVALID, "null result");
+  Slot &s = h->slot[slot];
+  if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
+  if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
+  femt::TailInput in{};
+  in.bases = s.d_bases, in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
+  in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
+  in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
+  in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
+  femt::TailOutput t{};
+  double ms[3] = {0, 0, 0};
+  std::string err;
+  rc = s.tail->run(in, s.stream, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr);
+  if (rc) return fail(h, rc, err);
+  if (h->timing)
+    for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;
+  out->n_reads = t.n_reads, out->n_records = t.n_records;
+  out->rec_begin = t.rec_begin, out->flag = t.flag, out->tid = t.tid, out->pos0 = t.pos0, out->nm = t.nm;
+  out->cigar_off = t.cigar_off, out->cigar = t.cigar, out->md_off = t.md_off, out->md = t.md;
+  memcpy(out->stats, s.stats, sizeof s.stats);
+  return FEM_OK;
+}
+
 int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fem_read_batch *reads) {
   int rc = fem_dev_stage_reads(h, slot, reads);
   if (rc) return rc;
@@ -795,12 +829,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
-  for (int i = 0; i < 3; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
+  for (int i = 0; i < 6; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
   return FEM_OK;
 }
 
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
-  if (!h || kernel < 0 || kernel > 2) return FEM_ERR_INVALID;
+  if (!h || kernel < 0 || kernel > 5) return FEM_ERR_INVALID;
   if (ms_total) *ms_total = h->t_ms[kernel];
   if (launches) *launches = h->t_n[kernel];
   return FEM_OK;

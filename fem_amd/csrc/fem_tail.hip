@@ -1,0 +1,781 @@
+// fem_tail.hip — device mapping tail: kernels + the host-side driver behind fem_dev_fetch_records.
+// See fem_tail.hip.h for what is computed and the reference lines it follows.
+#include "fem_tail.hip.h"
+
+#include <cstring>  // before rocprim: its headers use memcpy unqualified
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/fem_hip.h"
+
+namespace femt {
+namespace {
+
+constexpr uint32_t kOpM = 0, kOpI = 1, kOpD = 2, kOpS = 3;  // S: the traceback's pseudo-run (src/align.c:342), never emitted
+constexpr uint32_t kOpsCap = 16, kMdCap = 96;  // first-pass staging per record; anything longer goes to the overflow pass
+constexpr uint32_t kSortLdsHits = 2048;         // hits of one read the ordering kernel keeps in LDS
+constexpr uint16_t kFlagBroken = 0x8000;
+
+// ---- hit = one accepted candidate: Mapping (src/utils.h:44-49) ----
+// misc = end_position_offset (low 16) | edit_distance << 16 | direction << 24
+__device__ __forceinline__ uint64_t hit_key(uint64_t cand, uint32_t misc) {  // MappingSortKey, src/align.c:53
+  const int64_t end = (int16_t)(misc & 0xFFFFu);
+  return ((uint64_t)((misc >> 16) & 0xFFu) << 60) | ((uint64_t)((misc >> 24) & 1u) << 59) | (cand + (uint64_t)end);
+}
+
+struct Params {
+  // mapping outcome
+  const uint8_t *bases;
+  const uint64_t *read_off;
+  uint32_t n_reads;
+  const uint8_t *ref_raw;
+  uint64_t ref_bytes;
+  const uint64_t *seq_off;
+  const uint64_t *cand;
+  const uint8_t *ed;
+  const int16_t *end;
+  const uint32_t *cand_begin, *cand_count;
+  int32_t e;
+  uint32_t n_records;
+  const uint32_t *rec_begin;  // n_reads + 1
+  // hits in verify order (u_) and in record order (s_)
+  uint64_t *u_cand;
+  uint32_t *u_misc;
+  uint64_t *s_cand;
+  uint32_t *s_misc, *s_read;
+  uint32_t *queue;  // reads with three or more hits
+  uint32_t *ctl;    // [0] queue length, [1] records of the overflow pass, [2] staging too small even there
+  uint64_t *g_keys;  // ordering scratch for reads with more hits than fit LDS (n_records each)
+  uint32_t *g_idx;
+  // traceback
+  uint32_t lanes, text_words, pat_words, max_len;  // LDS plan of one block
+  uint32_t *t_ops;
+  uint8_t *t_md;
+  uint32_t ops_cap, md_cap;
+  const uint32_t *ovf_queue;  // overflow pass: the records to redo, staged at index * cap
+  uint32_t *ovf_out;          // first pass: where overflowing records are queued
+  uint32_t *src_slot;         // per record: 0 = first-pass staging, else 1 + index in the overflow staging
+  uint32_t *n_ops, *n_md;
+  uint16_t *flag;
+  uint32_t *tid, *pos0;
+  uint8_t *nm;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Ordering.  One lane per read rebuilds the read's Mapping list in verify_candidates' order (+ strand first,
+// candidates ascending, src/map.c:31-49); lists of one or two are ordered on the spot, longer ones are queued.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_kernel(Params p) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n_reads) return;
+  const uint32_t b = p.rec_begin[r], n = p.rec_begin[r + 1] - b;
+  if (n == 0) return;
+  uint32_t j = 0;
+  uint64_t c0 = 0, c1 = 0;
+  uint32_t m0 = 0, m1 = 0;
+  for (uint32_t dir = 0; dir < 2u; ++dir) {
+    const uint32_t s = 2u * r + dir, cb = p.cand_begin[s], cn = p.cand_count[s];
+    for (uint32_t i = cb; i < cb + cn; ++i) {
+      const uint32_t ed = p.ed[i];
+      if (ed == 0xFFu) continue;
+      const uint64_t c = p.cand[i];
+      const uint32_t m = (uint32_t)(uint16_t)p.end[i] | (ed << 16) | (dir << 24);
+      if (j == 0) c0 = c, m0 = m;
+      if (j == 1) c1 = c, m1 = m;
+      if (j < n) p.u_cand[b + j] = c, p.u_misc[b + j] = m;
+      ++j;
+    }
+  }
+  if (n <= 2u) {
+    const bool swap = n == 2u && hit_key(c1, m1) < hit_key(c0, m0);  // stable: equal keys keep verify order
+    p.s_cand[b] = swap ? c1 : c0, p.s_misc[b] = swap ? m1 : m0, p.s_read[b] = r;
+    if (n == 2u) p.s_cand[b + 1] = swap ? c0 : c1, p.s_misc[b + 1] = swap ? m0 : m1, p.s_read[b + 1] = r;
+  } else {
+    p.queue[atomicAdd(&p.ctl[0], 1u)] = r;
+  }
+}
+
+// klib's radix sort on (key, original index) pairs, run by one lane: KRADIX_SORT_INIT(mapping, Mapping,
+// MappingSortKey, 8) (src/ksort.h:101-151).  <= 64 records are never sent here.  Each level is an in-place
+// cycle-leader permutation into 256 buckets (not stable); buckets of <= 64 are finished by insertion sort, larger
+// ones recurse on the next byte.  Equal keys exist, so the exact permutation decides which record is the primary.
+__device__ void insertion_by_key(uint64_t *keys, uint32_t *idx, uint32_t beg, uint32_t end) {
+  for (uint32_t i = beg + 1; i < end; ++i) {
+    if (keys[i] < keys[i - 1]) {
+      const uint64_t tk = keys[i];
+      const uint32_t ti = idx[i];
+      uint32_t j = i;
+      for (; j > beg && tk < keys[j - 1]; --j) keys[j] = keys[j - 1], idx[j] = idx[j - 1];
+      keys[j] = tk, idx[j] = ti;
+    }
+  }
+}
+
+__device__ void radix_permute_level(uint64_t *keys, uint32_t *idx, uint32_t beg, uint32_t end, int shift, uint32_t *bin_b,
+                                    uint32_t *bin_e) {
+  for (int k = 0; k < 256; ++k) bin_e[k] = 0;
+  for (uint32_t i = beg; i < end; ++i) ++bin_e[(keys[i] >> shift) & 255u];
+  uint32_t run = beg;
+  for (int k = 0; k < 256; ++k) {
+    const uint32_t c = bin_e[k];
+    bin_b[k] = run;
+    run += c;
+    bin_e[k] = run;
+  }
+  for (int k = 0; k < 256;) {
+    if (bin_b[k] == bin_e[k]) {
+      ++k;
+      continue;
+    }
+    uint32_t at = bin_b[k];
+    int dst = (int)((keys[at] >> shift) & 255u);
+    if (dst == k) {
+      ++bin_b[k];
+      continue;
+    }
+    uint64_t ck = keys[at];
+    uint32_t ci = idx[at];
+    do {  // follow the cycle until an element of bucket k comes back
+      const uint32_t to = bin_b[dst]++;
+      const uint64_t dk = keys[to];
+      const uint32_t di = idx[to];
+      keys[to] = ck, idx[to] = ci;
+      ck = dk, ci = di;
+      dst = (int)((ck >> shift) & 255u);
+    } while (dst != k);
+    keys[bin_b[k]] = ck, idx[bin_b[k]] = ci;
+    ++bin_b[k];
+  }
+}
+
+struct RadixFrame {
+  uint32_t beg, end;
+  int shift, k;  // k < 0: level not permuted yet
+};
+
+__device__ void klib_radix_sort(uint64_t *keys, uint32_t *idx, uint32_t n, uint32_t *bin_b, uint32_t *bin_e_levels,
+                                RadixFrame *frames) {
+  int sp = 0;
+  frames[0] = RadixFrame{0u, n, 56, -1};
+  while (sp >= 0) {
+    RadixFrame &f = frames[sp];
+    uint32_t *bin_e = bin_e_levels + sp * 256;
+    if (f.k < 0) {
+      radix_permute_level(keys, idx, f.beg, f.end, f.shift, bin_b, bin_e);
+      f.k = 0;
+      if (f.shift == 0) {
+        --sp;
+        continue;
+      }
+    }
+    bool pushed = false;
+    while (f.k < 256) {
+      const int k = f.k++;
+      const uint32_t lo = k ? bin_e[k - 1] : f.beg, hi = bin_e[k];
+      if (hi - lo > 64u) {
+        frames[sp + 1] = RadixFrame{lo, hi, f.shift > 8 ? f.shift - 8 : 0, -1};
+        ++sp;
+        pushed = true;
+        break;
+      }
+      if (hi - lo > 1u) insertion_by_key(keys, idx, lo, hi);
+    }
+    if (!pushed) --sp;
+  }
+}
+
+__global__ void __launch_bounds__(64) sort_kernel(Params p) {
+  __shared__ uint32_t bin_b[256];
+  __shared__ uint32_t bin_e[8 * 256];
+  __shared__ RadixFrame frames[8];
+  __shared__ uint64_t l_keys[kSortLdsHits];
+  __shared__ uint32_t l_idx[kSortLdsHits];
+  const uint32_t ln = threadIdx.x;
+  const uint32_t n_queue = p.ctl[0];
+  for (uint32_t q = blockIdx.x; q < n_queue; q += gridDim.x) {
+    const uint32_t r = p.queue[q];
+    const uint32_t b = p.rec_begin[r], n = p.rec_begin[r + 1] - b;
+    if (n <= 64u) {  // insertion sort == any stable sort: rank = keys that must precede
+      const bool have = ln < n;
+      const uint64_t c = have ? p.u_cand[b + ln] : 0;
+      const uint32_t m = have ? p.u_misc[b + ln] : 0;
+      const uint64_t key = have ? hit_key(c, m) : ~0ull;
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < n; ++u) {
+        const uint64_t ku = __shfl(key, (int)u);
+        rank += (uint32_t)(ku < key || (ku == key && u < ln));
+      }
+      if (have) p.s_cand[b + rank] = c, p.s_misc[b + rank] = m, p.s_read[b + rank] = r;
+    } else {
+      uint64_t *keys = n <= kSortLdsHits ? l_keys : p.g_keys + b;
+      uint32_t *idx = n <= kSortLdsHits ? l_idx : p.g_idx + b;
+      for (uint32_t i = ln; i < n; i += 64u) keys[i] = hit_key(p.u_cand[b + i], p.u_misc[b + i]), idx[i] = i;
+      __threadfence();
+      __syncthreads();
+      if (ln == 0) klib_radix_sort(keys, idx, n, bin_b, bin_e, frames);
+      __threadfence();
+      __syncthreads();
+      for (uint32_t i = ln; i < n; i += 64u) {
+        const uint32_t src = idx[i];
+        p.s_cand[b + i] = p.u_cand[b + src], p.s_misc[b + i] = p.u_misc[b + src], p.s_read[b + i] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Traceback.  One lane per record; nothing crosses lanes.  Each lane keeps, word-interleaved in LDS (word w of
+// lane l at [w * lanes + l]): the read as aligned (raw characters, or the canonical reverse complement of
+// prepare_negative_sequence_at), the reference window pattern[0 .. L + 2e), and D0 / HP of every column.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t base_code(uint32_t c) {  // src/utils.h:72
+  const uint32_t x = (c >> 1) & 3u;
+  const uint32_t code = x ^ (x >> 1);
+  const uint32_t u = c & 0xDFu;
+  return ((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T')) ? code : 4u;
+}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+  uint32_t w;
+  __builtin_memcpy(&w, p, 4);
+  return w;
+}
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p) {
+  uint4 w;
+  __builtin_memcpy(&w, p, 16);
+  return w;
+}
+// four characters -> their complements in canonical upper case, anything but ACGT -> 'N' (src/sequence_batch.h:90-98)
+__device__ __forceinline__ uint32_t complement4(uint32_t chars) {
+  const uint32_t t = (chars >> 1) & 0x03030303u;
+  const uint32_t code = t ^ ((t >> 1) & 0x01010101u);
+  const uint32_t upper = chars & 0xDFDFDFDFu;
+  const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, code);
+  const uint32_t z = upper ^ expect;
+  const uint32_t nflag = ((((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) >> 7) & 0x01010101u;
+  return __builtin_amdgcn_perm(0x4E4E4E4Eu /* "NNNN" */, 0x54474341u, (code ^ 0x03030303u) | (nflag << 2));
+}
+
+struct LaneView {
+  const uint32_t *text, *pat;
+  uint32_t *d0, *hp;
+  uint32_t nl, ln;
+  __device__ __forceinline__ uint32_t text_at(uint32_t i) const { return (text[(i >> 2) * nl + ln] >> (8u * (i & 3u))) & 0xFFu; }
+  __device__ __forceinline__ uint32_t pat_at(uint32_t i) const { return (pat[(i >> 2) * nl + ln] >> (8u * (i & 3u))) & 0xFFu; }
+};
+
+struct Staging {  // where one record's CIGAR runs and MD characters are written
+  uint32_t *ops;
+  uint8_t *md;
+  uint32_t ops_cap, md_cap;
+  uint32_t n_ops = 0, n_md = 0;
+  bool overflow = false;
+  __device__ __forceinline__ void push_op(uint32_t op, uint32_t len) {
+    if (n_ops < ops_cap)
+      ops[n_ops] = (len << 4) | op;
+    else
+      overflow = true;
+    ++n_ops;
+  }
+  __device__ __forceinline__ void push_md(uint32_t ch) {
+    if (n_md < md_cap)
+      md[n_md] = (uint8_t)ch;
+    else
+      overflow = true;
+    ++n_md;
+  }
+  __device__ void push_number(uint32_t v) {
+    uint32_t digits = 1;
+    for (uint32_t t = v; t >= 10u; t /= 10u) ++digits;
+    uint32_t div = 1;
+    for (uint32_t i = 1; i < digits; ++i) div *= 10u;
+    for (; div; div /= 10u) push_md('0' + (v / div) % 10u);
+  }
+};
+
+// generate_alignment (src/align.c:279-499) + generate_MD_tag (src/align.c:501-544) for one record.
+// Returns the start offset inside pattern, or -1 where the reference would have tripped one of its asserts.
+// pattern = the window's first byte in HBM; [at_min, at_max] = offsets from it that stay inside the reference buffer.
+__device__ int trace_record(const LaneView &v, const uint8_t *pattern, int64_t at_min, int64_t at_max, int L, int e, int ed,
+                            int end, Staging &st) {
+  int start = end - L + 1;
+  if (start < 0) return -1;
+  const int pat_len = L + 2 * e;
+  bool identical = true;
+  for (int i = 0; i < L; ++i) {
+    if (v.text_at((uint32_t)i) != v.pat_at((uint32_t)(start + i))) {
+      identical = false;
+      break;
+    }
+  }
+  if (identical) {  // src/align.c:294-300
+    st.push_op(kOpM, (uint32_t)L);
+    st.push_number((uint32_t)L);
+    return start;
+  }
+  // ---- the recurrence again, D0 and HP of every column kept (src/align.c:303-338) ----
+  {
+    uint32_t B0 = 0, B1 = 0, B2 = 0;  // bit planes of the pattern window: Peq[c] is a three-way XNOR
+    for (int j = 0; j < 2 * e; ++j) {
+      const uint32_t pc = base_code(v.pat_at((uint32_t)j));
+      B0 |= (pc & 1u) << j, B1 |= ((pc >> 1) & 1u) << j, B2 |= ((pc >> 2) & 1u) << j;
+    }
+    const int sh = 2 * e;
+    const uint32_t band = (2u << sh) - 1u;
+    uint32_t vp = 0, vn = 0;
+    for (int i = 0; i < L; ++i) {
+      const uint32_t pc = base_code(v.pat_at((uint32_t)(i + sh))), tc = base_code(v.text_at((uint32_t)i));
+      B0 |= (pc & 1u) << sh, B1 |= ((pc >> 1) & 1u) << sh, B2 |= ((pc >> 2) & 1u) << sh;
+      const uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
+      uint32_t x = (~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)) & band) | vn;
+      const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+      const uint32_t hn = vp & d0;
+      const uint32_t hp = vn | ~(vp | d0);
+      x = d0 >> 1;
+      vn = x & hp;
+      vp = hn | ~(x | hp);
+      v.d0[(uint32_t)i * v.nl + v.ln] = d0;
+      v.hp[(uint32_t)i * v.nl + v.ln] = hp;
+      B0 >>= 1, B1 >>= 1, B2 >>= 1;
+    }
+  }
+  // ---- walk back from (last read base, end) until `ed` errors are accounted for (src/align.c:340-440) ----
+  enum Move { MATCH, MISMATCH, INSERT, DELETE };
+  int bit = end - L + 1, t = L - 1, pe = end, n_err = 0;
+  auto classify = [&]() -> Move {
+    const bool d = (v.d0[(uint32_t)t * v.nl + v.ln] >> bit) & 1u;
+    // pe never exceeds `end`, which lies inside the staged window
+    if (d && v.pat_at((uint32_t)pe) == v.text_at((uint32_t)t)) return MATCH;
+    if (!d) return MISMATCH;
+    if ((v.hp[(uint32_t)t * v.nl + v.ln] >> bit) & 1u) return INSERT;
+    return DELETE;
+  };
+  // The pseudo-run 'S' collects the errors at the read's 3' end and is finally added to the run that follows it
+  // (src/align.c:398-399,413-414,466-469); here its length rides along in s_len and is added when that run starts.
+  uint32_t cur_op = kOpS, cur_n = 1;
+  switch (classify()) {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
+    case MATCH: --t, --pe, cur_op = kOpM; break;
+    case MISMATCH: --t, --pe, ++n_err; break;
+    case INSERT: --t, ++bit, ++n_err, ++start; break;
+    case DELETE: return -1;  // assert(1 == 0)
+  }
+  auto extend = [&](uint32_t op) {
+    if (cur_op == op) {
+      ++cur_n;
+    } else if (cur_op == kOpS) {
+      cur_op = op, cur_n += 1;  // S(n) followed by op(1) ends up as op(1 + n)
+    } else {
+      st.push_op(cur_op, cur_n);
+      cur_op = op, cur_n = 1;
+    }
+  };
+  while (t >= 0 && n_err != ed) {
+    if (bit < 0 || bit > 31 || pe < 0) return -1;
+    switch (classify()) {
+      case MATCH: --t, --pe, extend(kOpM); break;
+      case MISMATCH:
+        --t, --pe, ++n_err;
+        if (cur_op == kOpS) ++cur_n; else extend(kOpM);
+        break;
+      case INSERT:
+        --t, ++bit, ++n_err, ++start;
+        if (cur_op == kOpS) ++cur_n; else extend(kOpI);
+        break;
+      case DELETE: --bit, --pe, ++n_err, --start, extend(kOpD); break;
+    }
+  }
+  if (t >= 0) {  // everything left of the last error matches (src/align.c:445-455)
+    if (cur_op == kOpM || cur_op == kOpS)
+      cur_op = kOpM, cur_n += (uint32_t)(t + 1);
+    else
+      st.push_op(cur_op, cur_n), cur_op = kOpM, cur_n = (uint32_t)(t + 1);
+  }
+  if (cur_op == kOpS) return -1;  // nothing but the pseudo-run: the reference indexes past its run list
+  st.push_op(cur_op, cur_n);
+  if (st.overflow) return start;  // redone with room in the overflow pass
+  // runs were produced right to left: reverse in place (src/align.c:470-479)
+  for (uint32_t i = 0, j = st.n_ops - 1u; i < j; ++i, --j) {
+    const uint32_t a = st.ops[i], b = st.ops[j];
+    st.ops[i] = b, st.ops[j] = a;
+  }
+  // ---- generate_MD_tag over pattern + start (src/align.c:501-544) ----
+  uint32_t run = 0, tp = 0;
+  int64_t rp = start;  // offset from pattern[0]; the 'S' fold can push a run beyond the staged window
+  auto ref_char = [&](int64_t at) -> uint32_t {
+    if (at >= 0 && at < pat_len) return v.pat_at((uint32_t)at);
+    return pattern[at < at_min ? at_min : at > at_max ? at_max : at];  // only walks the reference itself would reject
+  };
+  for (uint32_t k = 0; k < st.n_ops; ++k) {
+    const uint32_t op = st.ops[k] & 0xFu, n = st.ops[k] >> 4;
+    if (op == kOpM) {
+      for (uint32_t i = 0; i < n; ++i, ++rp, ++tp) {
+        const uint32_t rc = ref_char(rp);
+        if (rc == v.text_at(tp)) {
+          ++run;
+        } else {
+          if (run) st.push_number(run), run = 0;
+          st.push_md(rc);
+        }
+      }
+    } else if (op == kOpI) {
+      tp += n;
+    } else {
+      if (run) st.push_number(run), run = 0;
+      st.push_md('^');
+      for (uint32_t i = 0; i < n; ++i, ++rp) st.push_md(ref_char(rp));
+    }
+  }
+  if (run) st.push_number(run);
+  return start;
+}
+
+template <bool OVERFLOW_PASS>
+__global__ void __launch_bounds__(64) trace_kernel(Params p) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t nl = p.lanes, ln = threadIdx.x;
+  uint32_t *text_w = lds;
+  uint32_t *pat_w = text_w + p.text_words * nl;
+  uint32_t *d0_w = pat_w + p.pat_words * nl;
+  uint32_t *hp_w = d0_w + p.max_len * nl;
+  const uint32_t n_items = OVERFLOW_PASS ? p.ctl[1] : p.n_records;
+  for (uint32_t base = blockIdx.x * nl; base < n_items; base += gridDim.x * nl) {
+    const uint32_t item = base + ln;
+    if (ln >= nl || item >= n_items) continue;
+    const uint32_t rec = OVERFLOW_PASS ? p.ovf_queue[item] : item;
+    const uint32_t read = p.s_read[rec], misc = p.s_misc[rec];
+    const uint64_t cand = p.s_cand[rec];
+    const int end = (int16_t)(misc & 0xFFFFu), ed = (int)((misc >> 16) & 0xFFu);
+    const uint32_t dir = (misc >> 24) & 1u;
+    const uint64_t off = p.read_off[read];
+    const int L = (int)(p.read_off[read + 1] - off);
+    const uint8_t *fwd = p.bases + off;
+    const uint32_t tid = (uint32_t)(cand >> 32);
+    const uint64_t pat_abs = p.seq_off[tid] + (uint32_t)cand;
+    const uint8_t *pattern = p.ref_raw + pat_abs;
+    // ---- stage the read as aligned ----
+    for (int c = 0; c < L; c += 16) {
+      uint32_t w[4];
+      if (dir == 0) {
+        const uint4 q = load_u128_unaligned(fwd + c);  // may run past the read: those bytes are never looked at
+        w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+      } else if (L - 16 - c >= 0) {  // text[c + i] = complement(fwd[L - 1 - c - i])
+        const uint4 q = load_u128_unaligned(fwd + (L - 16 - c));
+        w[0] = __builtin_bswap32(complement4(q.w)), w[1] = __builtin_bswap32(complement4(q.z));
+        w[2] = __builtin_bswap32(complement4(q.y)), w[3] = __builtin_bswap32(complement4(q.x));
+      } else {
+        for (int k = 0; k < 4; ++k) {
+          const int p0 = L - 4 - c - 4 * k;  // fwd offset of the word's last character
+          uint32_t raw = 0;
+          if (p0 >= 0)
+            raw = load_u32_unaligned(fwd + p0);
+          else if (p0 > -4)
+            raw = load_u32_unaligned(fwd) << (8 * -p0);
+          w[k] = __builtin_bswap32(complement4(raw));
+        }
+      }
+      for (int k = 0; k < 4; ++k)
+        if ((uint32_t)(c / 4 + k) < p.text_words) text_w[(uint32_t)(c / 4 + k) * nl + ln] = w[k];
+    }
+    for (int c = 0; c < L + 2 * p.e; c += 16) {  // the reference buffer has 64 bytes of slack behind its last base
+      const uint4 q = load_u128_unaligned(pattern + c);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+      for (int k = 0; k < 4; ++k)
+        if ((uint32_t)(c / 4 + k) < p.pat_words) pat_w[(uint32_t)(c / 4 + k) * nl + ln] = w[k];
+    }
+    LaneView v{text_w, pat_w, d0_w, hp_w, nl, ln};
+    Staging st;
+    st.ops = p.t_ops + (size_t)item * p.ops_cap;
+    st.md = p.t_md + (size_t)item * p.md_cap;
+    st.ops_cap = p.ops_cap, st.md_cap = p.md_cap;
+    int start = trace_record(v, pattern, -(int64_t)pat_abs, (int64_t)p.ref_bytes - 1 - (int64_t)pat_abs, L, p.e, ed, end, st);
+    if (st.overflow) {
+      if (!OVERFLOW_PASS) {
+        p.ovf_out[atomicAdd(&p.ctl[1], 1u)] = rec;
+        p.n_ops[rec] = 0, p.n_md[rec] = 0;
+        continue;
+      }
+      atomicAdd(&p.ctl[2], 1u);  // cannot happen: the second staging holds the longest possible walk
+      start = -1;
+    }
+    const uint32_t rank = rec - p.rec_begin[read];
+    uint16_t flag = (uint16_t)((dir ? 16u : 0u) | (rank ? 256u : 0u));  // BAM_FREVERSE, BAM_FSECONDARY (src/align.c:82-84)
+    if (start < 0) flag |= kFlagBroken, start = 0, st.n_ops = 0, st.n_md = 0;
+    p.flag[rec] = flag;
+    p.tid[rec] = tid;
+    p.pos0[rec] = (uint32_t)start + (uint32_t)cand;  // src/align.c:80
+    p.nm[rec] = (uint8_t)ed;
+    p.n_ops[rec] = st.n_ops, p.n_md[rec] = st.n_md;
+    p.src_slot[rec] = OVERFLOW_PASS ? item + 1u : 0u;
+  }
+}
+
+struct CompactParams {
+  uint32_t n_records;
+  const uint32_t *src_slot, *n_ops, *n_md, *cigar_off, *md_off;
+  const uint32_t *t_ops, *o_ops;  // first-pass and overflow staging
+  const uint8_t *t_md, *o_md;
+  uint32_t ops_cap, md_cap, o_ops_cap, o_md_cap;
+  uint32_t *cigar;
+  uint8_t *md;
+};
+
+__global__ void __launch_bounds__(256) compact_kernel(CompactParams p) {
+  const uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rec >= p.n_records) return;
+  const uint32_t slot = p.src_slot[rec];
+  const uint32_t *ops = slot ? p.o_ops + (size_t)(slot - 1u) * p.o_ops_cap : p.t_ops + (size_t)rec * p.ops_cap;
+  const uint8_t *md = slot ? p.o_md + (size_t)(slot - 1u) * p.o_md_cap : p.t_md + (size_t)rec * p.md_cap;
+  const uint32_t no = p.n_ops[rec], nm = p.n_md[rec], co = p.cigar_off[rec], mo = p.md_off[rec];
+  for (uint32_t i = 0; i < no; ++i) p.cigar[co + i] = ops[i];
+  for (uint32_t i = 0; i < nm; ++i) p.md[mo + i] = md[i];
+}
+
+// ---- host-side buffer helpers ----
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t need(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr, cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, cap = 0;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t need(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct Tail::Impl {
+  DevBuf rec_begin, queue, ctl, u_cand, u_misc, s_cand, s_misc, s_read, t_ops, t_md, o_ops, o_md, ovf, src_slot, n_ops, n_md,
+      flag, tid, pos0, nm, cigar_off, md_off, cigar, md, scan_tmp;
+  PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  ~Impl() {
+    for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf,
+                      &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp})
+      b->release();
+    for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md})
+      b->release();
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+Tail::~Tail() { delete impl_; }
+
+#define TAIL_TRY(expr)                                                             \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+      return e_ == hipErrorOutOfMemory ? FEM_ERR_NOMEM : FEM_ERR_HIP;              \
+    }                                                                              \
+  } while (0)
+
+int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms) {
+  if (!impl_) impl_ = new (std::nothrow) Impl();
+  if (!impl_) return FEM_ERR_NOMEM;
+  Impl &m = *impl_;
+  if (in.n_records > 0xFFFFFFF0ull) {
+    if (err) *err = "more than 2^32 mappings in one batch; split the batch";
+    return FEM_ERR_UNSUPPORTED;
+  }
+  const uint32_t n = in.n_reads, nr = (uint32_t)in.n_records;
+  for (hipEvent_t &e : m.ev)
+    if (!e) TAIL_TRY(hipEventCreate(&e));
+
+  // ---- LDS plan of the traceback kernel: lanes = records one 64-thread block walks at a time ----
+  const uint32_t max_len = std::max<uint32_t>(in.max_len, 1);
+  const uint32_t text_words = (max_len + 3) / 4 + 4, pat_words = (max_len + 2 * (uint32_t)in.e + 3) / 4 + 4;
+  const uint32_t words_per_lane = text_words + pat_words + 2 * max_len;
+  const uint32_t lanes = std::min<uint32_t>(64, (64u * 1024u / 4u) / words_per_lane);
+  if (lanes == 0) {
+    if (err) *err = "read too long for the device traceback";
+    return FEM_ERR_UNSUPPORTED;
+  }
+  const uint32_t lds_bytes = lanes * words_per_lane * 4u;
+  const uint32_t ops_cap = tiny ? 1u : kOpsCap, md_cap = tiny ? 2u : kMdCap;
+  // longest possible walk: every step opens a run; the MD of a run never exceeds two characters per column
+  const uint32_t o_ops_cap = 2 * max_len + 2 * (uint32_t)in.e + 8, o_md_cap = 8 * max_len + 128;
+
+  TAIL_TRY(m.rec_begin.need(((size_t)n + 1) * 4));
+  TAIL_TRY(m.queue.need(std::max<size_t>(n, 1) * 4));
+  TAIL_TRY(m.ctl.need(16));
+  TAIL_TRY(m.h_ctl.need(32));
+  const size_t r1 = (size_t)nr + 1;
+  TAIL_TRY(m.u_cand.need(r1 * 8));
+  TAIL_TRY(m.u_misc.need(r1 * 4));
+  TAIL_TRY(m.s_cand.need(r1 * 8));
+  TAIL_TRY(m.s_misc.need(r1 * 4));
+  TAIL_TRY(m.s_read.need(r1 * 4));
+  TAIL_TRY(m.t_ops.need(r1 * ops_cap * 4));
+  TAIL_TRY(m.t_md.need(r1 * std::max<uint32_t>(md_cap, 12)));  // doubles as the ordering scratch (8 + 4 bytes per hit)
+  TAIL_TRY(m.ovf.need(r1 * 4));
+  TAIL_TRY(m.src_slot.need(r1 * 4));
+  TAIL_TRY(m.n_ops.need(r1 * 4));
+  TAIL_TRY(m.n_md.need(r1 * 4));
+  TAIL_TRY(m.flag.need(r1 * 2));
+  TAIL_TRY(m.tid.need(r1 * 4));
+  TAIL_TRY(m.pos0.need(r1 * 4));
+  TAIL_TRY(m.nm.need(r1));
+  TAIL_TRY(m.cigar_off.need(r1 * 4));
+  TAIL_TRY(m.md_off.need(r1 * 4));
+
+  size_t tmp_a = 0, tmp_b = 0;
+  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_a, (const uint32_t *)in.n_map, m.rec_begin.as<uint32_t>(), 0u, (size_t)n,
+                                   rocprim::plus<uint32_t>(), stream));
+  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_b, m.n_ops.as<uint32_t>(), m.cigar_off.as<uint32_t>(), 0u, r1,
+                                   rocprim::plus<uint32_t>(), stream));
+  size_t tmp_bytes = std::max(tmp_a, tmp_b);
+  TAIL_TRY(m.scan_tmp.need(std::max<size_t>(tmp_bytes, 16)));
+  tmp_bytes = m.scan_tmp.cap;
+
+  Params p{};
+  p.bases = in.bases, p.read_off = in.read_off, p.n_reads = n;
+  p.ref_raw = in.ref_raw, p.ref_bytes = in.ref_bytes, p.seq_off = in.seq_off;
+  p.cand = in.cand, p.ed = in.ed, p.end = in.end, p.cand_begin = in.cand_begin, p.cand_count = in.cand_count;
+  p.e = in.e, p.n_records = nr;
+  p.rec_begin = m.rec_begin.as<uint32_t>();
+  p.u_cand = m.u_cand.as<uint64_t>(), p.u_misc = m.u_misc.as<uint32_t>();
+  p.s_cand = m.s_cand.as<uint64_t>(), p.s_misc = m.s_misc.as<uint32_t>(), p.s_read = m.s_read.as<uint32_t>();
+  p.queue = m.queue.as<uint32_t>(), p.ctl = m.ctl.as<uint32_t>();
+  p.g_keys = m.t_md.as<uint64_t>();
+  p.g_idx = (uint32_t *)(m.t_md.as<uint8_t>() + r1 * 8);
+  p.lanes = lanes, p.text_words = text_words, p.pat_words = pat_words, p.max_len = max_len;
+  p.t_ops = m.t_ops.as<uint32_t>(), p.t_md = m.t_md.as<uint8_t>(), p.ops_cap = ops_cap, p.md_cap = md_cap;
+  p.ovf_queue = nullptr, p.ovf_out = m.ovf.as<uint32_t>(), p.src_slot = m.src_slot.as<uint32_t>();
+  p.n_ops = m.n_ops.as<uint32_t>(), p.n_md = m.n_md.as<uint32_t>();
+  p.flag = m.flag.as<uint16_t>(), p.tid = m.tid.as<uint32_t>(), p.pos0 = m.pos0.as<uint32_t>(), p.nm = m.nm.as<uint8_t>();
+
+  uint32_t *h_ctl = m.h_ctl.as<uint32_t>();
+  TAIL_TRY(hipEventRecord(m.ev[0], stream));
+  TAIL_TRY(hipMemsetAsync(m.ctl.p, 0, 16, stream));
+  if (n) {
+    TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, (const uint32_t *)in.n_map, m.rec_begin.as<uint32_t>(), 0u,
+                                     (size_t)n, rocprim::plus<uint32_t>(), stream));
+  }
+  TAIL_TRY(hipMemsetD32Async((hipDeviceptr_t)(m.rec_begin.as<uint32_t>() + n), (int)nr, 1, stream));
+  uint32_t n_overflow = 0;
+  if (nr) {
+    hipLaunchKernelGGL(gather_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, p);
+    TAIL_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sort_kernel, dim3((uint32_t)n_cu * 4u), dim3(64), 0, stream, p);
+    TAIL_TRY(hipGetLastError());
+    TAIL_TRY(hipEventRecord(m.ev[1], stream));
+    const uint32_t blocks = std::min<uint32_t>((nr + lanes - 1) / lanes, (uint32_t)n_cu * 16u);
+    hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, p);
+    TAIL_TRY(hipGetLastError());
+    TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipStreamSynchronize(stream));
+    n_overflow = h_ctl[1];
+    if (n_overflow) {  // records whose CIGAR or MD outgrew the first staging: once more, with room for any walk
+      TAIL_TRY(m.o_ops.need((size_t)n_overflow * o_ops_cap * 4));
+      TAIL_TRY(m.o_md.need((size_t)n_overflow * o_md_cap));
+      Params q = p;
+      q.ovf_queue = m.ovf.as<uint32_t>();
+      q.t_ops = m.o_ops.as<uint32_t>(), q.t_md = m.o_md.as<uint8_t>(), q.ops_cap = o_ops_cap, q.md_cap = o_md_cap;
+      const uint32_t b2 = std::min<uint32_t>((n_overflow + lanes - 1) / lanes, (uint32_t)n_cu * 16u);
+      hipLaunchKernelGGL(trace_kernel<true>, dim3(b2), dim3(64), lds_bytes, stream, q);
+      TAIL_TRY(hipGetLastError());
+    }
+  } else {
+    TAIL_TRY(hipEventRecord(m.ev[1], stream));
+  }
+  TAIL_TRY(hipEventRecord(m.ev[2], stream));
+  // ---- compaction: offsets by exclusive scans over n_records + 1 lengths (the last one zero) ----
+  TAIL_TRY(hipMemsetAsync(m.n_ops.as<uint32_t>() + nr, 0, 4, stream));
+  TAIL_TRY(hipMemsetAsync(m.n_md.as<uint32_t>() + nr, 0, 4, stream));
+  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, m.n_ops.as<uint32_t>(), m.cigar_off.as<uint32_t>(), 0u, r1,
+                                   rocprim::plus<uint32_t>(), stream));
+  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, m.n_md.as<uint32_t>(), m.md_off.as<uint32_t>(), 0u, r1,
+                                   rocprim::plus<uint32_t>(), stream));
+  TAIL_TRY(hipMemcpyAsync(h_ctl + 4, m.cigar_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(h_ctl + 5, m.md_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipStreamSynchronize(stream));
+  const uint32_t n_cigar = h_ctl[4], n_md = h_ctl[5];
+  TAIL_TRY(m.cigar.need(std::max<size_t>(n_cigar, 1) * 4));
+  TAIL_TRY(m.md.need(std::max<size_t>(n_md, 1)));
+  if (nr) {
+    CompactParams c{};
+    c.n_records = nr, c.src_slot = p.src_slot, c.n_ops = p.n_ops, c.n_md = p.n_md;
+    c.cigar_off = m.cigar_off.as<uint32_t>(), c.md_off = m.md_off.as<uint32_t>();
+    c.t_ops = p.t_ops, c.t_md = p.t_md, c.o_ops = m.o_ops.as<uint32_t>(), c.o_md = m.o_md.as<uint8_t>();
+    c.ops_cap = ops_cap, c.md_cap = md_cap, c.o_ops_cap = o_ops_cap, c.o_md_cap = o_md_cap;
+    c.cigar = m.cigar.as<uint32_t>(), c.md = m.md.as<uint8_t>();
+    hipLaunchKernelGGL(compact_kernel, dim3((nr + 255u) / 256u), dim3(256), 0, stream, c);
+    TAIL_TRY(hipGetLastError());
+  }
+  TAIL_TRY(hipEventRecord(m.ev[3], stream));
+  // ---- copy back ----
+  TAIL_TRY(m.h_rec_begin.need(((size_t)n + 1) * 4));
+  TAIL_TRY(m.h_flag.need(r1 * 2));
+  TAIL_TRY(m.h_tid.need(r1 * 4));
+  TAIL_TRY(m.h_pos0.need(r1 * 4));
+  TAIL_TRY(m.h_nm.need(r1));
+  TAIL_TRY(m.h_cigar_off.need(r1 * 4));
+  TAIL_TRY(m.h_md_off.need(r1 * 4));
+  TAIL_TRY(m.h_cigar.need(std::max<size_t>(n_cigar, 1) * 4));
+  TAIL_TRY(m.h_md.need(std::max<size_t>(n_md, 1)));
+  TAIL_TRY(hipMemcpyAsync(m.h_rec_begin.p, m.rec_begin.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(m.h_cigar_off.p, m.cigar_off.p, r1 * 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(m.h_md_off.p, m.md_off.p, r1 * 4, hipMemcpyDeviceToHost, stream));
+  if (nr) {
+    TAIL_TRY(hipMemcpyAsync(m.h_flag.p, m.flag.p, (size_t)nr * 2, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipMemcpyAsync(m.h_tid.p, m.tid.p, (size_t)nr * 4, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipMemcpyAsync(m.h_pos0.p, m.pos0.p, (size_t)nr * 4, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipMemcpyAsync(m.h_nm.p, m.nm.p, (size_t)nr, hipMemcpyDeviceToHost, stream));
+  }
+  if (n_cigar) TAIL_TRY(hipMemcpyAsync(m.h_cigar.p, m.cigar.p, (size_t)n_cigar * 4, hipMemcpyDeviceToHost, stream));
+  if (n_md) TAIL_TRY(hipMemcpyAsync(m.h_md.p, m.md.p, (size_t)n_md, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipStreamSynchronize(stream));
+  if (h_ctl[2] != 0) {
+    if (err) *err = "device traceback: a record outgrew the overflow staging (internal error)";
+    return FEM_ERR_HIP;
+  }
+  if (ms) {
+    for (int i = 0; i < 3; ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, m.ev[i], m.ev[i + 1]) == hipSuccess) ms[i] += t;
+    }
+  }
+  out->n_reads = n, out->n_records = nr;
+  out->rec_begin = m.h_rec_begin.as<uint32_t>();
+  out->flag = m.h_flag.as<uint16_t>(), out->tid = m.h_tid.as<uint32_t>(), out->pos0 = m.h_pos0.as<uint32_t>();
+  out->nm = m.h_nm.as<uint8_t>();
+  out->cigar_off = m.h_cigar_off.as<uint32_t>(), out->cigar = m.h_cigar.as<uint32_t>();
+  out->md_off = m.h_md_off.as<uint32_t>(), out->md = m.h_md.as<char>();
+  return FEM_OK;
+}
+
+}  // namespace femt

@@ -1,0 +1,61 @@
+// fem_tail.hip.h — the mapping tail on the device: what process_mappings does for every mapped read
+// (reference src/align.c:53-92) — order the read's Mappings with radix_sort_mapping, then for each one
+// generate_alignment (src/align.c:279-499: ungapped shortcut, or the Myers recurrence re-run with D0/HP kept per
+// column and the traceback with its 'S' pseudo-run) and generate_MD_tag (src/align.c:501-544).
+// Input: the per-candidate verification outcome the mapping kernels left in HBM.  Output: records in the reference's
+// order (FLAG, reference id, POS, NM, BAM-encoded CIGAR, MD), compacted on the device, copied to pinned host memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace femt {
+
+struct TailInput {  // device pointers unless noted
+  const uint8_t *bases;        // raw read characters, concatenated
+  const uint64_t *read_off;    // n_reads + 1
+  uint32_t n_reads;
+  uint32_t max_len;            // host: longest read of the batch
+  const uint8_t *ref_raw;      // raw reference characters (case kept: the traceback compares characters, src/align.c:355)
+  uint64_t ref_bytes;          // host: bytes in ref_raw, its slack included
+  const uint64_t *seq_off;
+  const uint64_t *cand;        // per candidate slot
+  const uint8_t *ed;           // 0xFF = rejected
+  const int16_t *end;
+  const uint32_t *cand_begin;  // 2 * n_reads
+  const uint32_t *cand_count;
+  const uint32_t *n_map;       // n_reads: accepted candidates of each read
+  int32_t e;
+  uint64_t n_records;          // host: total accepted candidates (the "number of mapping" counter)
+};
+
+struct TailOutput {  // pinned host memory owned by the Tail object, valid until its next run
+  uint64_t n_reads, n_records;
+  const uint32_t *rec_begin;  // n_reads + 1: records of read i are [rec_begin[i], rec_begin[i+1]), primary first
+  const uint16_t *flag;       // 16 = reverse strand, 256 = secondary; 0x8000 = the reference would have asserted
+  const uint32_t *tid;
+  const uint32_t *pos0;       // 0-based leftmost reference position
+  const uint8_t *nm;
+  const uint32_t *cigar_off;  // n_records + 1
+  const uint32_t *cigar;      // BAM encoding len << 4 | op (M 0, I 1, D 2)
+  const uint32_t *md_off;     // n_records + 1
+  const char *md;
+};
+
+class Tail {
+ public:
+  Tail() = default;
+  ~Tail();
+  Tail(const Tail &) = delete;
+  Tail &operator=(const Tail &) = delete;
+  // Runs on `stream` and waits for it.  ms[0..2] (optional) receive the device time of: ordering, traceback, compaction.
+  // tiny = test hook: per-record CIGAR/MD staging starts far too small so that the overflow pass runs.
+  int run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms);
+
+ private:
+  struct Impl;
+  Impl *impl_ = nullptr;
+};
+
+}  // namespace femt

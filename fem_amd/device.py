@@ -13,6 +13,7 @@ ABI_SYMBOLS = [
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_fetch_records",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_allreduce_stats",
 ]
@@ -35,6 +36,12 @@ class _BatchResult(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_candidates", C.c_uint64), ("cand_begin", C.c_void_p),
                 ("cand_count", C.c_void_p), ("cand", C.c_void_p), ("ed", C.c_void_p), ("end", C.c_void_p),
                 ("stats", C.c_uint64 * 5)]
+
+
+class _BatchRecords(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_records", C.c_uint64), ("rec_begin", C.c_void_p), ("flag", C.c_void_p),
+                ("tid", C.c_void_p), ("pos0", C.c_void_p), ("nm", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar", C.c_void_p), ("md_off", C.c_void_p), ("md", C.c_void_p), ("stats", C.c_uint64 * 5)]
 
 
 def hip_library_path():
@@ -69,6 +76,7 @@ def load_hip():
     L.fem_dev_sync.argtypes = [vp, C.c_int]
     L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
     L.fem_dev_fetch.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
+    L.fem_dev_fetch_records.argtypes = [vp, C.c_int, C.POINTER(_BatchRecords)]
     L.fem_dev_set_timing.argtypes = [vp, C.c_int]
     L.fem_dev_reset_timing.argtypes = [vp]
     L.fem_dev_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -111,6 +119,24 @@ class BatchResult:
             starts = np.repeat(self.cand_begin.astype(np.int64) - off[:-1].astype(np.int64), cnt)
             idx = np.arange(total, dtype=np.int64) + starts
         return off, self.cand[idx], self.ed[idx], self.end[idx]
+
+
+class BatchRecords:
+    """Host copy of fem_batch_records: the batch's output records in the reference's order."""
+
+    def __init__(self, r):
+        n, nr = int(r.n_reads), int(r.n_records)
+        self.n_reads, self.n_records = n, nr
+        self.rec_begin = _copy(r.rec_begin, n + 1, np.uint32)
+        self.flag = _copy(r.flag, nr, np.uint16)
+        self.tid = _copy(r.tid, nr, np.uint32)
+        self.pos0 = _copy(r.pos0, nr, np.uint32)
+        self.nm = _copy(r.nm, nr, np.uint8)
+        self.cigar_off = _copy(r.cigar_off, nr + 1, np.uint32)
+        self.cigar = _copy(r.cigar, int(self.cigar_off[-1]) if nr + 1 else 0, np.uint32)
+        self.md_off = _copy(r.md_off, nr + 1, np.uint32)
+        self.md = _copy(r.md, int(self.md_off[-1]) if nr + 1 else 0, np.uint8)
+        self.stats = np.array(list(r.stats), dtype=np.uint64)
 
 
 class Device:
@@ -199,6 +225,12 @@ class Device:
         r = _BatchResult()
         self._check(self._L.fem_dev_fetch(self._h, slot, C.byref(r)))
         return BatchResult(r)
+
+    def fetch_records(self, slot=0):
+        """The device mapping tail: sorted records with CIGAR and MD (fem_dev_fetch_records)."""
+        r = _BatchRecords()
+        self._check(self._L.fem_dev_fetch_records(self._h, slot, C.byref(r)))
+        return BatchRecords(r)
 
     def map_batch(self, bases, offsets, e=3, a=1, k=12, step=3, slot=0):
         b, keep = self._batch(bases, offsets)

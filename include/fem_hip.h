@@ -78,6 +78,27 @@ typedef struct {
   uint64_t stats[5];
 } fem_batch_result;
 
+/* The records of one batch as process_mappings would hand them to the writer
+ * (src/align.c:56-92): each mapped read's Mappings ordered by radix_sort_mapping
+ * (src/align.c:53,66; klib semantics, src/ksort.h:101-151), then per Mapping
+ * generate_alignment + generate_MD_tag (src/align.c:279-544) and the record
+ * fields of generate_bam1_t (src/align.c:546-632).  Pointers refer to pinned
+ * host memory owned by the handle, valid until the slot's next fetch_records. */
+typedef struct {
+  uint64_t n_reads;
+  uint64_t n_records;
+  const uint32_t *rec_begin; /* n_reads+1: records of read i are [rec_begin[i], rec_begin[i+1]); the first is the primary */
+  const uint16_t *flag;      /* 16 = BAM_FREVERSE, 256 = BAM_FSECONDARY; 0x8000 = the reference would have asserted (empty CIGAR/MD) */
+  const uint32_t *tid;       /* reference sequence index */
+  const uint32_t *pos0;      /* 0-based leftmost position (src/align.c:80) */
+  const uint8_t *nm;         /* edit distance */
+  const uint32_t *cigar_off; /* n_records+1 */
+  const uint32_t *cigar;     /* BAM encoding: len<<4 | op, M=0 I=1 D=2 */
+  const uint32_t *md_off;    /* n_records+1 */
+  const char *md;            /* MD tag characters, not NUL-terminated */
+  uint64_t stats[5];
+} fem_batch_records;
+
 typedef struct fem_dev fem_dev;
 
 /* ---- lifetime ---- */
@@ -116,13 +137,18 @@ int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p);          /* k
 int fem_dev_sync(fem_dev *h, int slot);                                     /* wait; re-runs on scratch overflow */
 int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* sync + the five counters */
 int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);             /* sync + full result to the host */
+/* sync + the mapping tail on the device (replaces process_mappings, src/map.c:50-54 -> src/align.c:56-92, up to
+ * the point where the reference packs a bam1_t): sorted records with CIGAR and MD.  Independent of fem_dev_fetch. */
+int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
 
 /* ---- measurement ---- */
 /* With timing on, every kernel launch is bracketed by HIP events on the stream
  * it is launched on; fem_dev_kernel_time reports their sum and count since
  * the last reset.  kernel: 0 = seed/filter kernel (fast form, k=12 step=3),
  * 1 = verify kernel, 2 = seed/filter kernel (generic form: the reads the fast
- * form queued, or every read when the fast form does not apply). */
+ * form queued, or every read when the fast form does not apply); of
+ * fem_dev_fetch_records: 3 = ordering of the mappings, 4 = traceback + MD,
+ * 5 = compaction (one entry per call, several kernels each). */
 int fem_dev_set_timing(fem_dev *h, int on);
 int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);
