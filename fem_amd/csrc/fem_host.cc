@@ -780,6 +780,43 @@ struct SeqRoundTrip {
 };
 const SeqRoundTrip kSeqText;
 
+// One SAM line: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL NM MD (src/align.c:546-632)
+void append_sam_line(std::string &o, const fem_tail_ref &ref, const char *name, size_t name_len, const Record &rec,
+                     const uint32_t *cigar, size_t n_cigar, const char *md, size_t n_md, bool primary, const char *fwd,
+                     uint32_t len, const char *qual) {
+  o.append(name, name_len);
+  o.push_back('\t');
+  append_uint(o, rec.flag);
+  o.push_back('\t');
+  o.append(ref.names + ref.name_off[rec.tid], ref.name_off[rec.tid + 1] - ref.name_off[rec.tid]);
+  o.push_back('\t');
+  append_uint(o, rec.pos0 + 1u);
+  o += "\t255\t";
+  if (n_cigar == 0) o.push_back('*');
+  for (size_t i = 0; i < n_cigar; ++i) {
+    append_uint(o, cigar[i] >> 4);
+    o.push_back("MIDNSHP=XB"[cigar[i] & 0xf]);
+  }
+  o += "\t*\t0\t0\t";
+  if (primary && len > 0) {  // only the primary record carries SEQ/QUAL (src/align.c:83-88)
+    const size_t at = o.size();
+    o.resize(at + len);
+    for (uint32_t i = 0; i < len; ++i) o[at + i] = kSeqText.t[(unsigned char)fwd[i]];  // original read (src/align.c:79)
+    o.push_back('\t');
+    if (qual)
+      o.append(qual, len);
+    else
+      o.push_back('*');
+  } else {
+    o += "*\t*";
+  }
+  o += "\tNM:i:";
+  append_uint(o, rec.nm);
+  o += "\tMD:Z:";
+  o.append(md, n_md);
+  o.push_back('\n');
+}
+
 template <typename Emit>
 void process_read(int e, const fem_tail_ref &ref, const char *fwd, uint32_t len, std::vector<Hit> &hits, Tracer &tr,
                   std::string &rev, std::vector<uint32_t> &cigar, std::string &md, Emit &&emit) {
@@ -927,37 +964,60 @@ int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, co
       const size_t name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
       process_read(e, *ref, fwd, len, hits, tr, rev, cigar, md,
                    [&](size_t rank, const Record &rec, const std::vector<uint32_t> &cg, const std::string &m) {
-                     // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL NM MD (src/align.c:546-632)
-                     o.append(name, name_len);
-                     o.push_back('\t');
-                     append_uint(o, rec.flag);
-                     o.push_back('\t');
-                     o.append(ref->names + ref->name_off[rec.tid], ref->name_off[rec.tid + 1] - ref->name_off[rec.tid]);
-                     o.push_back('\t');
-                     append_uint(o, rec.pos0 + 1u);
-                     o += "\t255\t";
-                     if (cg.empty()) o.push_back('*');
-                     for (uint32_t c : cg) {
-                       append_uint(o, c >> 4);
-                       o.push_back("MIDNSHP=XB"[c & 0xf]);
-                     }
-                     o += "\t*\t0\t0\t";
-                     if (rank == 0 && len > 0) {  // only the primary record carries SEQ/QUAL (src/align.c:83-88)
-                       for (uint32_t i = 0; i < len; ++i) o.push_back(kSeqText.t[(unsigned char)fwd[i]]);  // original read (src/align.c:79)
-                       o.push_back('\t');
-                       if (qual)
-                         o.append(qual, len);
-                       else
-                         o.push_back('*');
-                     } else {
-                       o += "*\t*";
-                     }
-                     o += "\tNM:i:";
-                     append_uint(o, rec.nm);
-                     o += "\tMD:Z:";
-                     o += m;
-                     o.push_back('\n');
+                     append_sam_line(o, *ref, name, name_len, rec, cg.data(), cg.size(), m.data(), m.size(), rank == 0, fwd,
+                                     len, qual);
                    });
+    }
+  }
+  size_t total = 0;
+  for (const std::string &p : parts) total += p.size();
+  char *buf = (char *)malloc(total + 1);
+  if (!buf) return -4;
+  size_t at = 0;
+  for (const std::string &p : parts) {
+    memcpy(buf + at, p.data(), p.size());
+    at += p.size();
+  }
+  *text = buf;
+  *text_len = total;
+  return 0;
+}
+
+int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rv, int n_threads, char **text,
+                    uint64_t *text_len) {
+  if (!ref || !reads || !rv || !text || !text_len) return -1;
+  if (rv->n_reads > reads->n) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const uint64_t n = rv->n_reads;
+  std::vector<std::string> parts((size_t)n_threads);
+#pragma omp parallel num_threads(n_threads)
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    std::string &o = parts[(size_t)t];
+    // threads take contiguous read ranges holding about the same number of records
+    const uint64_t total = rv->rec_begin[n];
+    auto cut = [&](uint64_t k) -> uint64_t {
+      if (k == 0) return 0;
+      if (k >= (uint64_t)nt) return n;
+      const uint64_t target = total * k / (uint64_t)nt;
+      return (uint64_t)(std::lower_bound(rv->rec_begin, rv->rec_begin + n, (uint32_t)target) - rv->rec_begin);
+    };
+    const uint64_t lo = cut((uint64_t)t), hi = cut((uint64_t)t + 1);
+    if (hi > lo) o.reserve((size_t)((rv->rec_begin[hi] - rv->rec_begin[lo]) * 300ull));
+    for (uint64_t r = lo; r < hi; ++r) {
+      const uint32_t b = rv->rec_begin[r], e_ = rv->rec_begin[r + 1];
+      if (b == e_) continue;  // unmapped reads produce no record (src/map.c:50)
+      const char *fwd = reads->bases + reads->off[r];
+      const uint32_t len = (uint32_t)(reads->off[r + 1] - reads->off[r]);
+      const char *qual = reads->quals ? reads->quals + reads->off[r] : nullptr;
+      const char *name = reads->names + reads->name_off[r];
+      const size_t name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
+      for (uint32_t j = b; j < e_; ++j) {
+        Record rec;
+        rec.flag = rv->flag[j], rec.tid = rv->tid[j], rec.pos0 = rv->pos0[j], rec.nm = rv->nm[j];
+        append_sam_line(o, *ref, name, name_len, rec, rv->cigar + rv->cigar_off[j], rv->cigar_off[j + 1] - rv->cigar_off[j],
+                        rv->md + rv->md_off[j], rv->md_off[j + 1] - rv->md_off[j], j == b, fwd, len, qual);
+      }
     }
   }
   size_t total = 0;

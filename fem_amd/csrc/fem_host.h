@@ -94,6 +94,23 @@ void fem_records_free(fem_records *r);
  * nothing, src/map.c:50-55).  *text is malloc'd. */
 int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, const fem_tail_input *in, int n_threads,
                  char **text, uint64_t *text_len);
+/* Records already computed (the device mapping tail, fem_dev_fetch_records of include/fem_hip.h), rendered as the
+ * same SAM text as fem_tail_sam.  The fields mirror fem_batch_records. */
+typedef struct {
+  uint64_t n_reads;
+  uint64_t n_records;
+  const uint32_t *rec_begin; /* n_reads+1 */
+  const uint16_t *flag;
+  const uint32_t *tid;
+  const uint32_t *pos0;
+  const uint8_t *nm;
+  const uint32_t *cigar_off; /* n_records+1 */
+  const uint32_t *cigar;
+  const uint32_t *md_off;    /* n_records+1 */
+  const char *md;
+} fem_record_view;
+int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rec, int n_threads,
+                    char **text, uint64_t *text_len);
 /* "@SQ\tSN:%s\tLN:%d\n" per sequence (src/output_queue.c:104-108). *text is malloc'd. */
 int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len);
 

@@ -316,23 +316,42 @@ int map_main(int argc, char **argv) {
   uint64_t totals[5] = {0, 0, 0, 0, 0};
   std::vector<uint64_t> per_gpu((size_t)n_gpus * 5, 0);
   int exit_code = 0;
+  const char *ht = getenv("FEM_HOST_TAIL");
+  const bool host_tail = ht && ht[0] == '1';
   auto retire = [&](InFlight f) {
-    fem_batch_result res;
     double t0 = real_time();
-    int rc = fem_dev_map_batch_wait(devs[(size_t)f.gpu], f.slot, &res);
+    uint64_t stats[5] = {0, 0, 0, 0, 0};
+    char *text = nullptr;
+    uint64_t len = 0;
+    int rc, fmt = 0;
+    if (host_tail) {  // FEM_HOST_TAIL=1: ordering / traceback / MD by libfemhost from the per-candidate outcome
+      fem_batch_result res;
+      rc = fem_dev_map_batch_wait(devs[(size_t)f.gpu], f.slot, &res);
+      if (!rc) {
+        fem_tail_input in{res.n_reads, res.cand_begin, res.cand_count, res.cand, res.ed, res.end};
+        fmt = fem_tail_sam(params.e, &ref.view, &f.b->reads, &in, n_threads, &text, &len);
+        memcpy(stats, res.stats, sizeof stats);
+      }
+    } else {  // default: the records come off the device, the host only renders text
+      fem_batch_records rec;
+      rc = fem_dev_fetch_records(devs[(size_t)f.gpu], f.slot, &rec);
+      if (!rc) {
+        fem_record_view rv{rec.n_reads, rec.n_records, rec.rec_begin, rec.flag, rec.tid, rec.pos0, rec.nm,
+                           rec.cigar_off, rec.cigar, rec.md_off, rec.md};
+        fmt = fem_records_sam(&ref.view, &f.b->reads, &rv, n_threads, &text, &len);
+        memcpy(stats, rec.stats, sizeof stats);
+      }
+    }
     if (rc) {
       exit_code = dev_fail(devs[(size_t)f.gpu], "mapping", rc);
     } else {
-      fem_tail_input in{res.n_reads, res.cand_begin, res.cand_count, res.cand, res.ed, res.end};
-      char *text = nullptr;
-      uint64_t len = 0;
-      if (fem_tail_sam(params.e, &ref.view, &f.b->reads, &in, n_threads, &text, &len) != 0) {
+      if (fmt != 0) {
         fprintf(stderr, "[FEM] out of memory while formatting SAM records\n");
         exit_code = EXIT_FAILURE;
       } else {
         to_write.push(Text{text, len});
       }
-      for (int i = 0; i < 5; ++i) per_gpu[(size_t)f.gpu * 5 + (size_t)i] += res.stats[i];
+      for (int i = 0; i < 5; ++i) per_gpu[(size_t)f.gpu * 5 + (size_t)i] += stats[i];
       fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - t0);
     }
     fem_seqset_free(&f.b->reads);

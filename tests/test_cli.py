@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FEM = os.path.join(ROOT, "fem_amd", "csrc", "FEM")
 
 
-def run(*args):
-    return subprocess.run([FEM] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+def run(*args, env=None):
+    full = dict(os.environ, **env) if env else None
+    return subprocess.run([FEM] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=full)
 
 
 def test_usage_and_argument_errors():
@@ -80,6 +81,12 @@ def test_index_and_map_end_to_end(tmp_path, e, L, gz, batch):
     header = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, len(s)) for n, s in zip(names, seqs))
     assert text.startswith(header)
     assert text[len(header):] == expected_sam(names, reads, rnames, quals, want)
+    # the same run with the ordering / traceback / MD done by libfemhost instead of the device
+    host_sam = str(tmp_path / "host.sam")
+    r2 = run("map", "-e", str(e), "-t", "3", "--ref", fa, "--index", index_path, "--read1", fq, "-o", host_sam,
+             "--batch", str(batch), env={"FEM_HOST_TAIL": "1"})
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert open(host_sam).read() == text
     err = r.stderr.decode()
     for label, v in zip(["The number of read", "The number of mapped read",
                          "The number of candidate before additional q-gram filter", "The number of candidate",
