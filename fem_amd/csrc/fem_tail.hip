@@ -7,6 +7,8 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/fem_hip.h"
@@ -51,7 +53,8 @@ struct Params {
   uint64_t *g_keys;  // ordering scratch for reads with more hits than fit LDS (n_records each)
   uint32_t *g_idx;
   // traceback
-  uint32_t lanes, text_words, pat_words, max_len;  // LDS plan of one block
+  uint32_t lanes, text_words, pat_words, max_len;  // LDS plan of one block of the general kernel
+  uint32_t fast_lanes, fast_ops;                   // ... and of the first-pass kernel (lanes, runs kept per lane)
   uint32_t *t_ops;
   uint8_t *t_md;
   uint32_t ops_cap, md_cap;
@@ -512,6 +515,276 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Traceback, first pass: the form nearly every record takes.  Same walk as trace_record, but the lane keeps one
+// packed word per column in LDS — the band bits (0 .. 2e) of D0 and HP and, in the same positions, whether the
+// reference character on that diagonal EQUALS the read character (the traceback and the MD tag compare characters,
+// not codes, src/align.c:355,523) — and reads the sequences straight from HBM, sixteen columns per load.
+// Character equality is derived from the code-equality mask Peq: for characters of the canonical alphabet
+// "ACGTN" it is the same thing, a reference character outside it (lower case, IUPAC) equals no canonical one, and
+// a read with such characters is left to the general kernel.  So is every walk that leaves the band, and every
+// record whose CIGAR or MD outgrows the staging; the general kernel (trace_kernel) redoes those from scratch.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t canonical_char(uint32_t code) {  // "ACGTN"[code]
+  return (uint32_t)(0x4E54474341ull >> (8u * code)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t byte_of(const uint4 &w, int q) {  // q is a compile-time constant after unrolling
+  const uint32_t x = q < 4 ? w.x : q < 8 ? w.y : q < 12 ? w.z : w.w;
+  return (x >> (8 * (q & 3))) & 0xFFu;
+}
+
+// The packed column word (3 x (2e+1) bits) is kept in as few LDS bytes as hold it — LDS per block is what limits the
+// waves per CU here, and the walk is a chain of dependent LDS reads that only more waves can hide: a low plane of
+// P0 words and, where needed, a high plane of P1 words; column c of lane l sits at [c * lanes + l] of each.
+struct NoPlane {};
+template <typename P0, typename P1>
+struct ColumnHistory {
+  P0 *lo;
+  P1 *hi;
+  uint32_t nl, ln;
+  static constexpr bool kTwo = !__is_same(P1, NoPlane);
+  __device__ __forceinline__ void put(uint32_t col, uint64_t v) const {
+    lo[col * nl + ln] = (P0)v;
+    if constexpr (kTwo) hi[col * nl + ln] = (P1)(v >> (8 * sizeof(P0)));
+  }
+  __device__ __forceinline__ uint64_t get(uint32_t col) const {
+    uint64_t v = lo[col * nl + ln];
+    if constexpr (kTwo) v |= (uint64_t)hi[col * nl + ln] << (8 * sizeof(P0));
+    return v;
+  }
+};
+
+template <typename P0, typename P1>
+__global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t nl = p.fast_lanes, ln = threadIdx.x;
+  using HistT = uint64_t;
+  ColumnHistory<P0, P1> hist;
+  hist.lo = (P0 *)lds;
+  hist.hi = (P1 *)(hist.lo + (size_t)p.max_len * nl);
+  hist.nl = nl, hist.ln = ln;
+  // run k of this lane: ops[k * nl + ln] = len << 2 | op
+  uint16_t *ops = (uint16_t *)((uint8_t *)lds + (((size_t)p.max_len * nl * (sizeof(P0) + (ColumnHistory<P0, P1>::kTwo ? sizeof(P1) : 0)) + 3u) & ~(size_t)3u));
+  const int e = p.e, sh = 2 * e, W = 2 * e + 1;
+  const uint32_t band = (1u << W) - 1u;
+  for (uint32_t base = blockIdx.x * nl; base < p.n_records; base += gridDim.x * nl) {
+    const uint32_t rec = base + ln;
+    if (ln >= nl || rec >= p.n_records) continue;
+    const uint32_t read = p.s_read[rec], misc = p.s_misc[rec];
+    const uint64_t cand = p.s_cand[rec];
+    const int end = (int16_t)(misc & 0xFFFFu), ed = (int)((misc >> 16) & 0xFFu);
+    const uint32_t dir = (misc >> 24) & 1u;
+    const uint64_t off = p.read_off[read];
+    const int L = (int)(p.read_off[read + 1] - off);
+    const uint8_t *fwd = p.bases + off;
+    const uint32_t tid = (uint32_t)(cand >> 32);
+    const uint64_t pat_abs = p.seq_off[tid] + (uint32_t)cand;
+    const uint8_t *pattern = p.ref_raw + pat_abs;
+    int start = end - L + 1;
+    bool punt = start < 0 || start > sh;  // (never: end lies in [L-1, L-1+2e])
+
+    // ---- the recurrence (src/align.c:303-338), one packed word per column ----
+    uint32_t B0 = 0, B1 = 0, B2 = 0, BW = 0;  // pattern window: three code bit planes + "not canonical"
+    for (int j = 0; j < sh; ++j) {
+      const uint32_t ch = pattern[j], pc = base_code(ch);
+      B0 |= (pc & 1u) << j, B1 |= ((pc >> 1) & 1u) << j, B2 |= ((pc >> 2) & 1u) << j;
+      BW |= (uint32_t)(ch != canonical_char(pc)) << j;
+    }
+    uint32_t vp = 0, vn = 0, ident = 1u;
+    // sixteen columns per pair of 16-byte loads; the next pair is requested before this one is used.
+    // pattern[c + 2e ..] has 64 bytes of slack behind the reference; a read chunk may run past the read (those
+    // columns are not walked).  On the reverse strand column c + q reads complement(fwd[L - 1 - c - q])
+    // (src/sequence_batch.h:90-98): the chunk is fetched from the read's far end and byte-reversed.
+    if (dir != 0 && (int64_t)off + L - 16 * ((L + 15) / 16) < 0) punt = true;  // would start in front of the batch's first read
+    auto text_chunk = [&](int c) -> uint4 {
+      return load_u128_unaligned(dir == 0 ? fwd + c : p.bases + ((int64_t)off + L - 16 - c));
+    };
+    uint4 pw_next = make_uint4(0, 0, 0, 0), tw_next = make_uint4(0, 0, 0, 0);
+    if (!punt && L > 0) pw_next = load_u128_unaligned(pattern + sh), tw_next = text_chunk(0);
+    for (int c = 0; c < L && !punt; c += 16) {
+      const uint4 pw = pw_next, r = tw_next;
+      if (c + 16 < L) pw_next = load_u128_unaligned(pattern + sh + c + 16), tw_next = text_chunk(c + 16);
+      const uint4 tw = dir == 0 ? r
+                                : make_uint4(__builtin_bswap32(r.w), __builtin_bswap32(r.z), __builtin_bswap32(r.y),
+                                             __builtin_bswap32(r.x));
+      // all sixteen columns are computed; those past the read only write history nobody looks at
+      // (LDS holds max_len rounded up to 16 columns) and are kept out of `ident`
+      const uint32_t live = L - c >= 16 ? 0xFFFFu : (1u << (L - c)) - 1u;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        {
+          const uint32_t pch = byte_of(pw, q), tch = byte_of(tw, q);
+          const uint32_t pc = base_code(pch);
+          uint32_t tc = base_code(tch);
+          if (dir == 0)
+            punt |= tch != canonical_char(tc);
+          else
+            tc = tc < 4u ? 3u - tc : 4u;
+          B0 |= (pc & 1u) << sh, B1 |= ((pc >> 1) & 1u) << sh, B2 |= ((pc >> 2) & 1u) << sh;
+          BW |= (uint32_t)(pch != canonical_char(pc)) << sh;
+          const uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
+          const uint32_t eq = ~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)) & band;  // Peq[text[col]]
+          uint32_t x = eq | vn;
+          const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+          const uint32_t hn = vp & d0;
+          const uint32_t hp = vn | ~(vp | d0);
+          x = d0 >> 1;
+          vn = x & hp;
+          vp = hn | ~(x | hp);
+          const uint32_t same = eq & ~BW;  // the characters themselves are equal
+          ident &= (same >> start) | (~live >> q);
+          if ((live >> q) & 1u)
+            hist.put((uint32_t)(c + q), (HistT)(d0 & band) | ((HistT)(hp & band) << W) | ((HistT)same << (2 * W)));
+          B0 >>= 1, B1 >>= 1, B2 >>= 1, BW >>= 1;
+        }
+      }
+    }
+
+    uint32_t n_ops = 0, n_md = 0;
+    uint8_t *md = p.t_md + (size_t)rec * p.md_cap;
+    auto push_op = [&](uint32_t op, uint32_t len) {
+      if (n_ops < p.ops_cap && n_ops < p.fast_ops && len < (1u << 14)) ops[n_ops * nl + ln] = (uint16_t)((len << 2) | op); else punt = true;
+      ++n_ops;
+    };
+    auto push_md = [&](uint32_t ch) {
+      if (n_md < p.md_cap) md[n_md] = (uint8_t)ch; else punt = true;
+      ++n_md;
+    };
+    auto push_number = [&](uint32_t v) {  // divisions by constants only (multiply + shift)
+      if (v >= 10000u) {
+        uint32_t div = 10000u;
+        while (v / div >= 10u) div *= 10u;
+        for (; div >= 10000u; div /= 10u) push_md('0' + (v / div) % 10u);
+        v %= 10000u;
+        push_md('0' + v / 1000u), push_md('0' + (v / 100u) % 10u), push_md('0' + (v / 10u) % 10u), push_md('0' + v % 10u);
+        return;
+      }
+      if (v >= 1000u) push_md('0' + v / 1000u);
+      if (v >= 100u) push_md('0' + (v / 100u) % 10u);
+      if (v >= 10u) push_md('0' + (v / 10u) % 10u);
+      push_md('0' + v % 10u);
+    };
+    bool broken = false;
+    if (!punt && (ident & 1u)) {  // src/align.c:294-300
+      push_op(kOpM, (uint32_t)L);
+      push_number((uint32_t)L);
+    } else if (!punt) {
+      // ---- walk back (src/align.c:340-440); pe == t + bit throughout ----
+      enum Move { MATCH, MISMATCH, INSERT, DELETE };
+      int bit = start, t = L - 1, n_err = 0;
+      auto classify = [&]() -> Move {
+        const HistT h = hist.get((uint32_t)t) >> bit;
+        const bool d = (uint32_t)h & 1u;
+        if (d && ((uint32_t)(h >> (2 * W)) & 1u)) return MATCH;
+        if (!d) return MISMATCH;
+        if ((uint32_t)(h >> W) & 1u) return INSERT;
+        return DELETE;
+      };
+      uint32_t cur_op = kOpS, cur_n = 1;
+      switch (classify()) {
+        case MATCH: --t, cur_op = kOpM; break;
+        case MISMATCH: --t, ++n_err; break;
+        case INSERT: --t, ++bit, ++n_err, ++start; break;
+        case DELETE: broken = true; break;
+      }
+      auto extend = [&](uint32_t op) {
+        if (cur_op == op) {
+          ++cur_n;
+        } else if (cur_op == kOpS) {
+          cur_op = op, cur_n += 1;
+        } else {
+          push_op(cur_op, cur_n);
+          cur_op = op, cur_n = 1;
+        }
+      };
+      while (!broken && !punt && t >= 0 && n_err != ed) {
+        if (bit < 0) {  // the reference's own guard; above the band it would read bits this pass does not keep
+          broken = true;
+          break;
+        }
+        if (bit > sh) {
+          punt = true;
+          break;
+        }
+        switch (classify()) {
+          case MATCH: --t, extend(kOpM); break;
+          case MISMATCH:
+            --t, ++n_err;
+            if (cur_op == kOpS) ++cur_n; else extend(kOpM);
+            break;
+          case INSERT:
+            --t, ++bit, ++n_err, ++start;
+            if (cur_op == kOpS) ++cur_n; else extend(kOpI);
+            break;
+          case DELETE: --bit, ++n_err, --start, extend(kOpD); break;
+        }
+      }
+      if (!broken && !punt) {
+        if (t >= 0) {
+          if (cur_op == kOpM || cur_op == kOpS)
+            cur_op = kOpM, cur_n += (uint32_t)(t + 1);
+          else
+            push_op(cur_op, cur_n), cur_op = kOpM, cur_n = (uint32_t)(t + 1);
+        }
+        if (cur_op == kOpS) broken = true; else push_op(cur_op, cur_n);
+      }
+      if (!broken && !punt) {
+        // ---- MD over pattern + start (src/align.c:501-544); runs were produced right to left ----
+        uint32_t run = 0, tp = 0;
+        int rp = start;
+        for (uint32_t k = n_ops; k-- > 0 && !punt;) {
+          const uint32_t o = ops[k * nl + ln], op = o & 3u, n = o >> 2;
+          if (op == kOpM) {
+            const int diag = rp - (int)tp;  // constant along the run
+            if (diag < 0 || diag > sh) {
+              punt = true;
+              break;
+            }
+            for (uint32_t i = 0; i < n; ++i, ++rp, ++tp) {
+              if ((uint32_t)(hist.get(tp) >> (2 * W + diag)) & 1u) {
+                ++run;
+              } else {
+                if (run) push_number(run), run = 0;
+                push_md(pattern[rp]);
+              }
+            }
+          } else if (op == kOpI) {
+            tp += n;
+          } else {
+            if (rp < 0) {
+              punt = true;
+              break;
+            }
+            if (run) push_number(run), run = 0;
+            push_md('^');
+            for (uint32_t i = 0; i < n; ++i, ++rp) push_md(pattern[rp]);
+          }
+        }
+        if (run) push_number(run);
+      }
+    }
+    if (punt) {
+      p.ovf_out[atomicAdd(&p.ctl[1], 1u)] = rec;
+      p.n_ops[rec] = 0, p.n_md[rec] = 0;
+      continue;
+    }
+    const uint32_t rank = rec - p.rec_begin[read];
+    uint16_t flag = (uint16_t)((dir ? 16u : 0u) | (rank ? 256u : 0u));
+    if (broken) flag |= kFlagBroken, start = 0, n_ops = 0, n_md = 0;
+    uint32_t *out_ops = p.t_ops + (size_t)rec * p.ops_cap;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+      const uint32_t o = ops[(n_ops - 1u - k) * nl + ln];
+      out_ops[k] = ((o >> 2) << 4) | (o & 3u);
+    }
+    p.flag[rec] = flag;
+    p.tid[rec] = tid;
+    p.pos0[rec] = (uint32_t)start + (uint32_t)cand;
+    p.nm[rec] = (uint8_t)ed;
+    p.n_ops[rec] = n_ops, p.n_md[rec] = n_md;
+    p.src_slot[rec] = 0u;
+  }
+}
+
 struct CompactParams {
   uint32_t n_records;
   const uint32_t *src_slot, *n_ops, *n_md, *cigar_off, *md_off;
@@ -624,6 +897,12 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     return FEM_ERR_UNSUPPORTED;
   }
   const uint32_t lds_bytes = lanes * words_per_lane * 4u;
+  // first-pass kernel: one packed word per column (three fields of 2e+1 bits) + the run list
+  const uint32_t hist_bytes = (3u * (2u * (uint32_t)in.e + 1u) + 7u) / 8u;  // 1, 2, 2, 3, 4, 5, 5, 6 for e = 0..7
+  const uint32_t fast_ops = std::min<uint32_t>(kOpsCap, 2u * (uint32_t)in.e + 2u);  // a sane walk opens <= 2 ed + 1 runs
+  const uint32_t fast_per_lane = max_len * hist_bytes + fast_ops * 2u;
+  const uint32_t fast_lanes = std::min<uint32_t>(64, (64u * 1024u - 4u) / fast_per_lane);
+  const uint32_t fast_lds = ((max_len * hist_bytes * fast_lanes + 3u) & ~3u) + fast_ops * 2u * fast_lanes;
   const uint32_t ops_cap = tiny ? 1u : kOpsCap, md_cap = tiny ? 2u : kMdCap;
   // longest possible walk: every step opens a run; the MD of a run never exceeds two characters per column
   const uint32_t o_ops_cap = 2 * max_len + 2 * (uint32_t)in.e + 8, o_md_cap = 8 * max_len + 128;
@@ -671,7 +950,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   p.queue = m.queue.as<uint32_t>(), p.ctl = m.ctl.as<uint32_t>();
   p.g_keys = m.t_md.as<uint64_t>();
   p.g_idx = (uint32_t *)(m.t_md.as<uint8_t>() + r1 * 8);
-  p.lanes = lanes, p.text_words = text_words, p.pat_words = pat_words, p.max_len = max_len;
+  p.lanes = lanes, p.text_words = text_words, p.pat_words = pat_words, p.max_len = max_len, p.fast_lanes = fast_lanes, p.fast_ops = fast_ops;
   p.t_ops = m.t_ops.as<uint32_t>(), p.t_md = m.t_md.as<uint8_t>(), p.ops_cap = ops_cap, p.md_cap = md_cap;
   p.ovf_queue = nullptr, p.ovf_out = m.ovf.as<uint32_t>(), p.src_slot = m.src_slot.as<uint32_t>();
   p.n_ops = m.n_ops.as<uint32_t>(), p.n_md = m.n_md.as<uint32_t>();
@@ -692,12 +971,20 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     hipLaunchKernelGGL(sort_kernel, dim3((uint32_t)n_cu * 4u), dim3(64), 0, stream, p);
     TAIL_TRY(hipGetLastError());
     TAIL_TRY(hipEventRecord(m.ev[1], stream));
-    const uint32_t blocks = std::min<uint32_t>((nr + lanes - 1) / lanes, (uint32_t)n_cu * 16u);
-    hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(64), lds_bytes, stream, p);
+    const uint32_t blocks = std::min<uint32_t>((nr + fast_lanes - 1) / fast_lanes, (uint32_t)n_cu * 32u);
+    switch (hist_bytes) {
+      case 1: hipLaunchKernelGGL((trace_fast_kernel<uint8_t, NoPlane>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+      case 2: hipLaunchKernelGGL((trace_fast_kernel<uint16_t, NoPlane>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+      case 3: hipLaunchKernelGGL((trace_fast_kernel<uint16_t, uint8_t>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+      case 4: hipLaunchKernelGGL((trace_fast_kernel<uint32_t, NoPlane>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+      case 5: hipLaunchKernelGGL((trace_fast_kernel<uint32_t, uint8_t>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+      default: hipLaunchKernelGGL((trace_fast_kernel<uint32_t, uint16_t>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
+    }
     TAIL_TRY(hipGetLastError());
     TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
     TAIL_TRY(hipStreamSynchronize(stream));
     n_overflow = h_ctl[1];
+    if (getenv("FEM_TAIL_DEBUG")) fprintf(stderr, "[tail] records %u, queued for ordering %u, overflow pass %u, lanes %u/%u\n", nr, h_ctl[0], n_overflow, fast_lanes, lanes);
     if (n_overflow) {  // records whose CIGAR or MD outgrew the first staging: once more, with room for any walk
       TAIL_TRY(m.o_ops.need((size_t)n_overflow * o_ops_cap * 4));
       TAIL_TRY(m.o_md.need((size_t)n_overflow * o_md_cap));
