@@ -817,6 +817,19 @@ void append_sam_line(std::string &o, const fem_tail_ref &ref, const char *name, 
   o.push_back('\n');
 }
 
+// Concatenate the threads' pieces into one malloc'd buffer (each piece copied by its own thread).
+int join_parts(const std::vector<std::string> &parts, int n_threads, char **text, uint64_t *text_len) {
+  std::vector<size_t> at(parts.size() + 1, 0);
+  for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].size();
+  char *buf = (char *)malloc(at.back() + 1);
+  if (!buf) return -4;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+  for (size_t i = 0; i < parts.size(); ++i) memcpy(buf + at[i], parts[i].data(), parts[i].size());
+  *text = buf;
+  *text_len = at.back();
+  return 0;
+}
+
 template <typename Emit>
 void process_read(int e, const fem_tail_ref &ref, const char *fwd, uint32_t len, std::vector<Hit> &hits, Tracer &tr,
                   std::string &rev, std::vector<uint32_t> &cigar, std::string &md, Emit &&emit) {
@@ -969,18 +982,7 @@ int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, co
                    });
     }
   }
-  size_t total = 0;
-  for (const std::string &p : parts) total += p.size();
-  char *buf = (char *)malloc(total + 1);
-  if (!buf) return -4;
-  size_t at = 0;
-  for (const std::string &p : parts) {
-    memcpy(buf + at, p.data(), p.size());
-    at += p.size();
-  }
-  *text = buf;
-  *text_len = total;
-  return 0;
+  return join_parts(parts, n_threads, text, text_len);
 }
 
 int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rv, int n_threads, char **text,
@@ -1020,18 +1022,7 @@ int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_
       }
     }
   }
-  size_t total = 0;
-  for (const std::string &p : parts) total += p.size();
-  char *buf = (char *)malloc(total + 1);
-  if (!buf) return -4;
-  size_t at = 0;
-  for (const std::string &p : parts) {
-    memcpy(buf + at, p.data(), p.size());
-    at += p.size();
-  }
-  *text = buf;
-  *text_len = total;
-  return 0;
+  return join_parts(parts, n_threads, text, text_len);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -275,12 +275,18 @@ int map_main(int argc, char **argv) {
     uint64_t n;
   };
   Channel<Text> to_write(4);
+  // FEM_STAGE_TIMES=1: busy seconds of each pipeline stage on stderr at the end (reader, device wait, SAM text, writer)
+  const char *st_env = getenv("FEM_STAGE_TIMES");
+  const bool stage_times = st_env && st_env[0] == '1';
+  double busy_read = 0, busy_wait = 0, busy_text = 0, busy_write = 0;
   std::thread writer([&] {
     for (;;) {
       Text t = to_write.pop();
       if (!t.p) break;
+      double t0 = real_time();
       fwrite(t.p, 1, t.n, out);
       free(t.p);
+      busy_write += real_time() - t0;
     }
   });
   // stage 1: one reader thread parses FASTQ into batches (src/input_queue.c:53-79)
@@ -294,7 +300,9 @@ int map_main(int argc, char **argv) {
       Batch *b = new Batch();
       b->id = id++;
       // batches are cut by bytes (~ batch_reads records of this file's shape); plain FASTQ is parsed by all threads
+      double t0 = real_time();
       int rc = ok ? fem_seqfile_read_bytes(f, batch_bytes, n_threads, &b->reads) : -1;
+      busy_read += real_time() - t0;
       if (rc != 0 && ok) fprintf(stderr, "Didn't reach the end of sequence file, which might be corrupted!");
       if (rc != 0 || b->reads.n == 0) {
         b->last = true;
@@ -335,10 +343,13 @@ int map_main(int argc, char **argv) {
     } else {  // default: the records come off the device, the host only renders text
       fem_batch_records rec;
       rc = fem_dev_fetch_records(devs[(size_t)f.gpu], f.slot, &rec);
+      busy_wait += real_time() - t0;
       if (!rc) {
+        double t1 = real_time();
         fem_record_view rv{rec.n_reads, rec.n_records, rec.rec_begin, rec.flag, rec.tid, rec.pos0, rec.nm,
                            rec.cigar_off, rec.cigar, rec.md_off, rec.md};
         fmt = fem_records_sam(&ref.view, &f.b->reads, &rv, n_threads, &text, &len);
+        busy_text += real_time() - t1;
         memcpy(stats, rec.stats, sizeof stats);
       }
     }
@@ -398,6 +409,9 @@ int map_main(int argc, char **argv) {
   reader.join();
   to_write.push(Text{nullptr, 0});
   writer.join();
+  if (stage_times)
+    fprintf(stderr, "[FEM] stage busy seconds: reader %.3f, device wait %.3f, SAM text %.3f, writer %.3f\n", busy_read,
+            busy_wait, busy_text, busy_write);
   fclose(out);
 
   // MappingStats reduction (src/FEM_map.c:200-212): across GPUs it is one RCCL all-reduce of 5 counters
