@@ -40,5 +40,18 @@ def test_device_reproduces_the_fixture(name):
         assert np.array_equal(o, want["cand_off"]) and np.array_equal(cand, want["cands"])
         assert np.array_equal(ed, want["v_ed"])
         assert np.array_equal(end[ed != 0xFF], want["v_end"][want["v_ed"] != 0xFF])
+        # the device mapping tail: same record text as the fixture's digest
+        rec = dev.fetch_records()
+        assert rec.n_records == int(want["n_records"][0])
+        ops = "MID"
+
+        def cigar(j):
+            return "".join("%d%s" % (c >> 4, ops[c & 0xF]) for c in rec.cigar[rec.cigar_off[j]:rec.cigar_off[j + 1]]) or "*"
+
+        sam = "".join("%d\t%d\t%d\t%d\t%s\t%d\t%s\n" % (
+            r, int(rec.flag[j]), int(rec.tid[j]), int(rec.pos0[j]) + 1, cigar(j), int(rec.nm[j]),
+            rec.md[rec.md_off[j]:rec.md_off[j + 1]].tobytes().decode())
+            for r in range(case["n_reads"]) for j in range(int(rec.rec_begin[r]), int(rec.rec_begin[r + 1])))
+        assert np.array_equal(np.frombuffer(hashlib.sha256(sam.encode()).digest(), np.uint8), want["records_sha256"])
     finally:
         dev.close()
