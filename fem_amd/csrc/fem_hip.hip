@@ -206,6 +206,9 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.dp_bits = take(n_groups * R * 8u);
   l.picked = take(n_groups * R * 16u);
   l.X = take(64u * 8u);  // scatter
+  // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
+  l.blk_bytes = max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;
+  l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;
     l.F = take(femk::bloom_slots((int)R) / 16u * 4u);  // bitmap: two bits per key slot

@@ -40,6 +40,7 @@ struct SeedLayout {
   uint32_t xcap, fcap, ccap; // capacities (entries) of X, F, A/B
   uint32_t smax, cmax, cw;
   uint32_t n_words;
+  uint32_t blk, blk_bytes;   // seed_fast_kernel: the raw characters of one block of reads (0 bytes: not staged)
   uint32_t wave_bytes;
 };
 
@@ -719,7 +720,7 @@ __device__ uint32_t select_seeds_dpp(const SeedParams &p, int S, const bool *str
 __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t ln = lane_id();
-  const uint32_t wave_in_block = threadIdx.x >> 6;
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and known to be
   const uint32_t waves_per_block = blockDim.x >> 6;
   uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
   uint32_t *pkw = (uint32_t *)(wbase + p.lay.pkw);

@@ -17,6 +17,7 @@ namespace femk {
 
 constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
+constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
 
 // char -> 2-bit code for four bases at once.  code: per byte 0..3; nflag: per byte 1 where the base is not
 // A/C/G/T in either case (src/utils.h:72).
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);  // selected seeds per strand
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
   const uint32_t ln = lane_id();
-  const uint32_t wave_in_block = threadIdx.x >> 6;
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and known to be
   const uint32_t waves_per_block = blockDim.x >> 6;
   uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
   uint32_t *pkw = (uint32_t *)(wbase + p.lay.pkw);
@@ -406,6 +407,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   unsigned long long *take_bits = (unsigned long long *)(wbase + p.lay.dp_bits);
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
+  uint8_t *blk_chars = wbase + p.lay.blk;
   if (HASH)
     for (uint32_t i = ln; i < bloom_slots(R) / 16u; i += kWave) bloom[i] = 0;
   const uint32_t smax = p.lay.smax;
@@ -420,16 +422,34 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
-  constexpr uint32_t kReadBlock = 16;
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
   uint32_t blk_begin = 0, blk_count = 0;  // lane 2*i + strand: entry of read r0 + i
   bool blk_mine = false;                   // false for reads left to the generic kernel (it writes their entries)
+  // The block's characters are contiguous: one coalesced copy into LDS pays the HBM latency once for the whole
+  // block instead of once per read (each read otherwise starts with a dependent, mostly line-missing load).
+  const bool staged = p.lay.blk_bytes != 0;
+  const uint64_t blk_base = p.read_off[r0];
+  if (staged) {
+    const uint32_t r_hi = r0 + kReadBlock < p.n_reads ? r0 + kReadBlock : p.n_reads;
+    const uint32_t nbytes = (uint32_t)(p.read_off[r_hi] - blk_base);  // <= kReadBlock * max_len
+    wave_sync_lds();  // the previous block's last reader is done
+#pragma unroll 1
+    for (uint32_t i = ln * 16u; i < nbytes + 16u; i += (uint32_t)kWave * 16u)  // 64 bytes of slack behind the batch's bases
+      *(uint4 *)(blk_chars + i) = load_u128_unaligned(p.bases + blk_base + i);
+    wave_sync_lds();
+  }
+  // four characters at any byte offset of the staged block
+  auto chars_at = [&](uint64_t off, uint32_t idx) -> uint32_t {
+    if (!staged) return load_u32_unaligned(p.bases + off + idx);
+    const uint32_t a = (uint32_t)(off - blk_base) + idx;
+    const uint32_t *w = (const uint32_t *)(blk_chars + (a & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
+  };
   for (uint32_t rb = 0; rb < kReadBlock && r0 + rb < p.n_reads; ++rb) {
     const uint32_t read = r0 + rb;
     STAMP_START(prof);
     const uint64_t off = p.read_off[read];
     const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
-    const uint8_t *seq = p.bases + off;
     const int S = (int)L - kK + 1;  // num_seeds_in_read
 
     // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
@@ -454,7 +474,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
         const uint32_t idx = b0 + 4u * ln;
         if (idx < L) {
           uint32_t code, nflag;
-          encode4(load_u32_unaligned(seq + idx), code, nflag);  // may run up to 3 bytes past the read: masked below
+          encode4(chars_at(off, idx), code, nflag);  // may run up to 3 bytes past the read: masked below
           const uint32_t nb = L - idx;
           const uint32_t keep = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
           nflag &= keep;
@@ -471,7 +491,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
           const uint32_t idx = b0 + 4u * ln;
           if (idx < L) {
             uint32_t code, nflag;
-            encode4(load_u32_unaligned(seq + idx), code, nflag);
+            encode4(chars_at(off, idx), code, nflag);
             const uint32_t nb = L - idx;
             nflag &= nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
             const uint32_t byte_addr = (idx >> 4) * 4u + (3u - ((idx >> 2) & 3u));
