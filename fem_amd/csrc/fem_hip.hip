@@ -22,6 +22,7 @@ namespace {
 
 constexpr int kSlots = 4;
 constexpr uint32_t kMaxReadLen = 1024;
+constexpr size_t kFrontPad = 16;  // kernels fetch a reverse-strand chunk from up to 15 bytes in front of a read
 constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;
 
 struct TimedLaunch {
@@ -31,10 +32,9 @@ struct TimedLaunch {
 
 struct Slot {
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // verification of the first half of a batch, overlapped with the seeding of the second
-  hipEvent_t ev_half = nullptr, ev_verified = nullptr;
   // inputs
-  uint8_t *d_bases = nullptr;
+  uint8_t *d_bases_alloc = nullptr;  // kFrontPad bytes of padding, then the batch's characters, then 64 bytes of slack
+  uint8_t *bases() const { return d_bases_alloc + 16; }
   size_t bases_cap = 0;
   uint64_t *d_off = nullptr;
   size_t off_cap = 0;
@@ -73,6 +73,7 @@ struct Slot {
   femt::Tail *tail = nullptr;  // device mapping tail (fem_dev_fetch_records), created on first use
 };
 
+// ctr[4] | arena_ctr[2] | stats[4]
 constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
 
 }  // namespace
@@ -90,6 +91,7 @@ struct fem_dev {
   uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
   // reference
   uint8_t *d_ref = nullptr;      // base codes
+  uint8_t *d_plane[3] = {nullptr, nullptr, nullptr};  // bit q of the codes, one bit per base (verify_kernel's windows)
   uint8_t *d_ref_raw = nullptr;  // the characters as uploaded (the traceback and MD compare and print them)
   uint64_t ref_bytes = 0;
   uint64_t *d_seq_off = nullptr;
@@ -99,8 +101,9 @@ struct fem_dev {
   std::vector<uint32_t> seq_len;
   Slot slot[kSlots];
   bool timing = false;
-  double t_ms[6] = {0, 0, 0, 0, 0, 0};
-  uint64_t t_n[6] = {0, 0, 0, 0, 0, 0};
+  int verify_blocks_per_cu = 0;  // resident 256-thread blocks of verify_kernel per CU (queried once)
+  double t_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t t_n[7] = {0, 0, 0, 0, 0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
@@ -207,7 +210,8 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.picked = take(n_groups * R * 16u);
   l.X = take(64u * 8u);  // scatter
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
-  l.blk_bytes = max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;
+  // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
+  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;
   l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;
@@ -319,10 +323,9 @@ int launch_batch(fem_dev *h, Slot &s) {
   unsigned long long *d_arena_ctr = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t));
   unsigned long long *d_stats = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
   HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlBytes, s.stream));
-  if (s.n_reads) HIP_TRY(h, hipMemsetAsync(s.d_nmap, 0, s.n_reads * sizeof(uint32_t), s.stream));
 
   femk::SeedParams sp{};
-  sp.bases = s.d_bases;
+  sp.bases = s.bases();
   sp.read_off = s.d_off;
   sp.n_reads = (uint32_t)s.n_reads;
   sp.read_begin = 0;
@@ -375,14 +378,18 @@ int launch_batch(fem_dev *h, Slot &s) {
   if (s.n_reads) {
     int rc;
     femk::VerifyParams vp{};
-    vp.bases = s.d_bases, vp.read_off = s.d_off;
-    vp.ref_codes = h->d_ref, vp.seq_off = h->d_seq_off;
-    vp.cand = s.d_cand, vp.cand_meta = s.d_meta, vp.cand_begin = s.d_begin, vp.cand_count = s.d_count;
+    vp.bases = s.bases(), vp.read_off = s.d_off;
+    vp.plane[0] = h->d_plane[0], vp.plane[1] = h->d_plane[1], vp.plane[2] = h->d_plane[2], vp.seq_off = h->d_seq_off;
+    vp.cand = s.d_cand, vp.cand_meta = s.d_meta;
     vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
-    vp.ed = s.d_ed, vp.end = s.d_end, vp.n_map = s.d_nmap, vp.stats = d_stats;
-    vp.first = nullptr, vp.last = d_ctr;
-    const uint32_t vgrid = (uint32_t)h->n_cu * 8u;
-    bool halves = false;
+    vp.ed = s.d_ed, vp.end = s.d_end;
+    // grid-stride kernel: exactly the blocks that are resident together, or the ones that start late set the makespan
+    if (h->verify_blocks_per_cu == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::verify_kernel, 256, 0) != hipSuccess || nb <= 0) nb = 4;
+      h->verify_blocks_per_cu = nb;
+    }
+    const uint32_t vgrid = (uint32_t)h->n_cu * (uint32_t)h->verify_blocks_per_cu;
     if (use_fast) {
       femk::SeedParams fp = sp;
       // long occurrence lists (dense index): the hash-join form of the kernel; short ones: lists in lanes only
@@ -407,26 +414,8 @@ int launch_batch(fem_dev *h, Slot &s) {
           default: launch_fast<10>(hash, g, b, lds_bytes, s.stream, q); break;
         }
       };
-      // Large batches are seeded in two halves: the (latency-bound) verification of the first half runs on a
-      // second stream while the second half is being seeded.  ctr[3] snapshots the candidate cursor in between.
-      const uint32_t n_all = (uint32_t)s.n_reads;
-      const uint32_t half = n_all >= (1u << 20) ? ((n_all / 2u) & ~15u) : n_all;
-      halves = half < n_all;
-      rc = timed(0, s.stream, [&] { launch_range(0, half); });
+      rc = timed(0, s.stream, [&] { launch_range(0, (uint32_t)s.n_reads); });
       if (rc) return rc;
-      if (halves) {
-        HIP_TRY(h, hipMemcpyAsync(d_ctr + 3, d_ctr, sizeof(uint32_t), hipMemcpyDeviceToDevice, s.stream));
-        HIP_TRY(h, hipEventRecord(s.ev_half, s.stream));
-        HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_half, 0));
-        femk::VerifyParams va = vp;
-        va.first = nullptr, va.last = d_ctr + 3;
-        rc = timed(1, s.stream2, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream2, va); });
-        if (rc) return rc;
-        HIP_TRY(h, hipEventRecord(s.ev_verified, s.stream2));
-        rc = timed(0, s.stream, [&] { launch_range(half, n_all); });
-        if (rc) return rc;
-        vp.first = d_ctr + 3;
-      }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the fast one queued
     }
     {
@@ -437,7 +426,14 @@ int launch_batch(fem_dev *h, Slot &s) {
     }
     rc = timed(1, s.stream, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
     if (rc) return rc;
-    if (halves) HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_verified, 0));
+    femk::CountParams cp{};
+    cp.cand_begin = s.d_begin, cp.cand_count = s.d_count, cp.ed = s.d_ed, cp.ctr = d_ctr;
+    cp.n_reads = (uint32_t)s.n_reads, cp.n_map = s.d_nmap, cp.stats = d_stats;
+    rc = timed(6, s.stream, [&] {
+      const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((cp.n_reads + 255u) / 256u, (uint32_t)h->n_cu * 8u));
+      hipLaunchKernelGGL(femk::count_mappings_kernel, dim3(blocks), dim3(256), 0, s.stream, cp);
+    });
+    if (rc) return rc;
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.mapped = true;
@@ -502,10 +498,7 @@ int fem_dev_open(int device, fem_dev **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
   for (int i = 0; i < kSlots; ++i) {
-    if (hipStreamCreateWithFlags(&h->slot[i].stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->slot[i].stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->slot[i].ev_half, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->slot[i].ev_verified, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->slot[i].stream, hipStreamNonBlocking) != hipSuccess) {
       delete h;
       return FEM_ERR_HIP;
     }
@@ -526,7 +519,7 @@ int fem_dev_close(fem_dev *h) {
   (void)hipDeviceSynchronize();
   for (auto &s : h->slot) {
     drain_timing(h, s);
-    for (void *p : {(void *)s.d_bases, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
+    for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
                     (void *)s.d_arena, (void *)s.d_slow})
       if (p) (void)hipFree(p);
@@ -534,15 +527,13 @@ int fem_dev_close(fem_dev *h) {
                     (void *)s.h_end})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
-    if (s.stream2) (void)hipStreamDestroy(s.stream2);
-    if (s.ev_half) (void)hipEventDestroy(s.ev_half);
-    if (s.ev_verified) (void)hipEventDestroy(s.ev_verified);
     delete s.tail;
     s.tail = nullptr;
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
-                  (void *)h->d_seq_len, (void *)h->d_nonempty})
+                  (void *)h->d_seq_len, (void *)h->d_nonempty, (void *)h->d_plane[0], (void *)h->d_plane[1],
+                  (void *)h->d_plane[2]})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -583,15 +574,17 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     h->seq_off[i] = total;
     total += seq_len[i];
   }
-  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len})
+  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_plane[0],
+                  (void *)h->d_plane[1], (void *)h->d_plane[2]})
     if (p) (void)hipFree(p);
   h->d_ref = nullptr, h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
+  h->d_plane[0] = h->d_plane[1] = h->d_plane[2] = nullptr;
   // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
-  HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 64));
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 128));
   HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 64));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_off, n_seq * sizeof(uint64_t)));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_len, n_seq * sizeof(uint32_t)));
-  HIP_TRY(h, hipMemset(h->d_ref + total, 4, 64));
+  HIP_TRY(h, hipMemset(h->d_ref + total, 4, 128));
   for (uint32_t i = 0; i < n_seq; ++i)
     if (seq_len[i]) HIP_TRY(h, hipMemcpy(h->d_ref + h->seq_off[i], seq[i], seq_len[i], hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_off, h->seq_off.data(), n_seq * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -600,6 +593,17 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
   HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 64));
   if (total) {
     hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, total);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+  }
+  {  // bit planes of the codes, 64 bases of slack (code 4) included
+    const uint64_t n_pb = (total + 64 + 7) / 8;
+    for (int q = 0; q < 3; ++q) {
+      HIP_TRY(h, hipMalloc((void **)&h->d_plane[q], n_pb + 16));
+      HIP_TRY(h, hipMemset(h->d_plane[q], 0, n_pb + 16));
+    }
+    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, n_pb, h->d_plane[0],
+                       h->d_plane[1], h->d_plane[2]);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipDeviceSynchronize());
   }
@@ -636,7 +640,7 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
   if (!reads || (reads->n_reads && (!reads->bases || !reads->offsets))) return fail(h, FEM_ERR_INVALID, "null read batch");
-  if (reads->n_reads > 0x7FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
+  if (reads->n_reads > 0x3FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^30 reads in one batch");
   Slot &s = h->slot[slot];
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -652,9 +656,9 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
       return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
     max_len = std::max<uint32_t>(max_len, (uint32_t)len);
   }
-  if ((rc = dev_realloc(h, &s.d_bases, &s.bases_cap, (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
-  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_bases, reads->bases + base0, n_bases, hipMemcpyHostToDevice, s.stream));
+  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), reads->bases + base0, n_bases, hipMemcpyHostToDevice, s.stream));
   if (base0 == 0) {
     HIP_TRY(h, hipMemcpyAsync(s.d_off, reads->offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
     HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -798,7 +802,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
   if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
   femt::TailInput in{};
-  in.bases = s.d_bases, in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
+  in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
@@ -832,12 +836,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
-  for (int i = 0; i < 6; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
+  for (int i = 0; i < 7; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
   return FEM_OK;
 }
 
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
-  if (!h || kernel < 0 || kernel > 5) return FEM_ERR_INVALID;
+  if (!h || kernel < 0 || kernel > 6) return FEM_ERR_INVALID;
   if (ms_total) *ms_total = h->t_ms[kernel];
   if (launches) *launches = h->t_n[kernel];
   return FEM_OK;

@@ -23,6 +23,9 @@ constexpr uint32_t kFlagCandOverflow = 1u;   // candidate output buffer too smal
 constexpr uint32_t kFlagArenaOverflow = 2u;  // global arena too small
 constexpr uint32_t kFlagTooLarge = 4u;       // a single group exceeds 2^31 entries
 constexpr uint32_t kInvalidMeta = 0xFFFFFFFFu;  // padding slot in the candidate arrays (skipped by verify_kernel)
+// bit 31 of a candidate's meta word: it belongs to a full group of 8 of its (read, strand) list, which the reference
+// sends through the 16-bit SSE lanes (src/align.c:12-13); batches hold < 2^30 reads, so the bit is free
+constexpr uint32_t kMeta16 = 0x80000000u;
 constexpr uint32_t kSlotChunk = 256u;           // candidate slots a wave reserves per atomic on the shared cursor
 constexpr uint32_t kFlagQueueOverflow = 8u;     // slow-read queue too small
 constexpr uint32_t kQueueChunk = 32u;           // queue entries a wave reserves per atomic
@@ -55,7 +58,7 @@ struct SeedParams {
   const uint32_t *seq_len;
   int32_t e, a, R, k, step, lg;
   uint64_t *cand;
-  uint32_t *cand_meta;  // read*2 + strand per candidate
+  uint32_t *cand_meta;  // per candidate: read*2 + strand, | kMeta16 when it sits in a full group of 8 of its list
   uint32_t cand_cap;
   uint32_t *cand_begin;  // [2*n_reads]
   uint32_t *cand_count;  // [2*n_reads]
@@ -396,7 +399,7 @@ __device__ void clip_and_emit(const SeedParams &p, uint32_t read, uint32_t stran
       wave_sync<GLOBAL>();
       for (uint32_t i = ln; i < kept; i += kWave) {
         p.cand[base + i] = tmp[i];
-        p.cand_meta[base + i] = read * 2u + strand;
+        p.cand_meta[base + i] = (read * 2u + strand) | (i < (kept & ~7u) ? kMeta16 : 0u);
       }
     }
   }
@@ -564,9 +567,9 @@ __device__ bool strand_small(const SeedParams &p, const Picked *pk /* [step][R] 
     if ((unsigned long long)base + n_out > p.cand_cap) {
       if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
     } else if (ok) {
-      uint32_t at = base + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
+      const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
       p.cand[at] = cv - e64;
-      p.cand_meta[at] = read * 2u + strand;
+      p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
     }
   }
   if (ln == 0) {
@@ -989,23 +992,17 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
 // verification: one lane per candidate (src/align.c:4-51, 102-277)
 // ---------------------------------------------------------------------------
 struct VerifyParams {
-  const uint8_t *bases;
+  const uint8_t *bases;       // 16 bytes of padding in front of the batch's characters, 64 behind
   const uint64_t *read_off;
-  const uint8_t *ref_codes;  // base codes 0..4, all sequences concatenated
+  const uint8_t *plane[3];    // bit planes of the base codes 0..4, all sequences concatenated (see verify_kernel)
   const uint64_t *seq_off;
   const uint64_t *cand;
   const uint32_t *cand_meta;
-  const uint32_t *cand_begin;
-  const uint32_t *cand_count;
-  const uint32_t *ctr;  // [0] = number of candidates produced by the seed kernels
-  const uint32_t *first;  // candidate range of this launch: [*first (0 if null), *last); lets the verification of one
-  const uint32_t *last;   // half of a batch overlap the seeding of the other half
+  const uint32_t *ctr;    // [0] = candidate slots handed out by the seed kernels, [1] = overflow flags
   uint32_t cand_cap;
   int32_t e;
   uint8_t *ed;
   int16_t *end;
-  uint32_t *n_map;             // per read: accepted mappings
-  unsigned long long *stats;   // [2] mappings, [3] mapped reads
 };
 
 __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p) {
@@ -1019,139 +1016,201 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
   return w;
 }
 
-// One column of the banded Myers recurrence (src/align.c:118-133).  pc = code of the reference base that enters
-// the band, tc = code of the read base.  B0..B2 are the bit planes of the pattern window (bit j = bit q of
-// code(pattern[col + j])), so Peq[tc] is a three-way XNOR instead of a five-entry table.
+// ---------------------------------------------------------------------------------------------------------
+// verify_candidates (src/align.c:4-51): one lane per candidate walks banded_edit_distance (src/align.c:102-147; the
+// 16-bit SSE form of :149-277 differs only in the word width, `wm`).
+// The kernel is bound by the number of divergent load instructions (every lane walks its own read and window), so
+// both sides are fetched in the widest units that hold them:
+//   * reference: three bit planes of the base codes (bit q of code(ref[i]) at bit i of plane q).  One unaligned
+//     16-byte load per plane covers the windows of six 16-column steps; Peq[c] for a column is a three-way XNOR of
+//     the planes, shifted;
+//   * read: 16 characters per load, decoded four at a time (SWAR), byte-reversed and complemented on the reverse
+//     strand (prepare_negative_sequence_at, src/sequence_batch.h:90-98).
+// Nothing is accumulated here: count_mappings_kernel derives the per-read counts and the counters afterwards (one
+// returning atomic per accepted candidate used to cost as much as everything else in this kernel together).
+// ---------------------------------------------------------------------------------------------------------
 struct MyersState {
-  uint32_t B0, B1, B2, VP, VN;
+  uint32_t VP, VN;
   int score;
 };
-__device__ __forceinline__ bool myers_column(MyersState &m, uint32_t pc, uint32_t tc, int e, uint32_t band, uint32_t wm) {
-  const int sh = 2 * e;
-  m.B0 |= (pc & 1u) << sh;
-  m.B1 |= ((pc >> 1) & 1u) << sh;
-  m.B2 |= ((pc >> 2) & 1u) << sh;
-  uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
-  uint32_t eq = ~((m.B0 ^ m0) | (m.B1 ^ m1) | (m.B2 ^ m2)) & band;  // Peq[text[col]]
+
+// char -> 2-bit code for four bases at once: code per byte 0..3 (0 where the base is not A/C/G/T), nflag per byte 0/1
+__device__ __forceinline__ void decode4(uint32_t chars, uint32_t complement, uint32_t &code, uint32_t &nflag) {
+  const uint32_t t = (chars >> 1) & 0x03030303u;    // A 0, C 1, G 3, T 2
+  const uint32_t c = t ^ ((t >> 1) & 0x01010101u);  // A 0, C 1, G 2, T 3
+  const uint32_t upper = chars & 0xDFDFDFDFu;
+  const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, c);
+  const uint32_t z = upper ^ expect;  // zero byte <=> one of ACGT in either case (src/utils.h:72)
+  nflag = ((((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) >> 7) & 0x01010101u;
+  code = (c ^ complement) & ~(nflag * 3u);  // complement = 0x03030303 on the reverse strand (3 - code); N stays N
+}
+
+// 32 bits of a 128-bit little-endian bit string starting at bit `at` (at + 32 <= 128)
+__device__ __forceinline__ uint32_t bits_at(const uint4 &w, uint32_t at) {
+  const uint32_t k = at >> 5;
+  const uint32_t lo = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
+  const uint32_t hi = k == 0 ? w.y : k == 1 ? w.z : w.w;  // unused when k == 3 (then at & 31 == 0 is required)
+  return __builtin_amdgcn_alignbit(hi, lo, at & 31u);
+}
+
+// One column (src/align.c:118-133).  B0..B2: the step's plane windows; m0..m2: the read base's code bits as masks;
+// j = column inside the step.
+__device__ __forceinline__ void myers_column(MyersState &m, uint32_t B0, uint32_t B1, uint32_t B2, uint32_t m0, uint32_t m1,
+                                             uint32_t m2, uint32_t j, uint32_t width, uint32_t wm) {
+  const uint32_t eq = __builtin_amdgcn_ubfe(~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)), j, width);  // Peq[text[col]] over the band
   uint32_t X = eq | m.VN;
-  uint32_t D0 = ((((X & m.VP) + m.VP) ^ m.VP) | X) & wm;
-  uint32_t HN = m.VP & D0;
-  uint32_t HP = (m.VN | ~(m.VP | D0)) & wm;
+  const uint32_t D0 = ((((X & m.VP) + m.VP) ^ m.VP) | X) & wm;
+  const uint32_t HN = m.VP & D0;
+  const uint32_t HP = (m.VN | ~(m.VP | D0)) & wm;
   X = D0 >> 1;
   m.VN = X & HP;
   m.VP = (HN | ~(X | HP)) & wm;
   m.score += 1 - (int)(D0 & 1u);
-  m.B0 >>= 1;
-  m.B1 >>= 1;
-  m.B2 >>= 1;
-  return m.score > 3 * e;  // src/align.c:128-130; the SSE lanes run on but end up rejected as well
 }
+
+constexpr int kStepsPerPlaneLoad = 6;  // 7 (bit offset) + 16 * 5 + 16 + 2 * 7 (band) bits <= 128
 
 __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   // a scratch buffer overflowed while seeding: slots may be unwritten, the host grows the buffer and re-runs the batch
   if (p.ctr[1] != 0) return;
-  const uint32_t total = min(*p.last, p.cand_cap);
-  const uint32_t from = p.first ? min(*p.first, total) : 0u;
+  const uint32_t total = min(p.ctr[0], p.cand_cap);
   const uint32_t stride = gridDim.x * blockDim.x;
   const int e = p.e;
-  const uint32_t top = 1u << (2 * e);
-  const uint32_t band = (top << 1) - 1u;
-  for (uint32_t i0 = from + blockIdx.x * blockDim.x; i0 < total; i0 += stride) {
-    uint32_t i = i0 + threadIdx.x;
-    bool active = i < total;
-    bool accepted = false, first_of_read = false;
-    uint32_t meta = active ? p.cand_meta[i] : kInvalidMeta;
+  const uint32_t width = 2u * (uint32_t)e + 1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const uint32_t meta = p.cand_meta[i];
     if (meta == kInvalidMeta) {
-      if (active) p.ed[i] = 0xFF, p.end[i] = 0;
-      active = false;
+      p.ed[i] = 0xFF, p.end[i] = 0;
+      continue;
     }
-    if (active) {
-      const uint32_t read = meta >> 1, strand = meta & 1u;
-      const uint64_t c = p.cand[i];
-      const uint8_t *pat = p.ref_codes + p.seq_off[(uint32_t)(c >> 32)] + (uint32_t)c;
-      const uint64_t off = p.read_off[read];
-      const int L = (int)(p.read_off[read + 1] - off);
-      const uint8_t *rd = p.bases + off;
-      // verify_candidates sends full groups of 8 through the 16-bit SSE lanes and the remainder through the
-      // 32-bit scalar routine (src/align.c:12-13); the word width is the only difference between the two.
-      const uint32_t rank = i - p.cand_begin[meta];
-      const uint32_t n_here = p.cand_count[meta];
-      const uint32_t wm = rank < (n_here & ~7u) ? 0xFFFFu : 0xFFFFFFFFu;
-      MyersState m{0, 0, 0, 0, 0, 0};
-      for (int j = 0; j < 2 * e; ++j) {  // prime the window with pattern[0 .. 2e)
-        uint32_t pc = pat[j];
-        m.B0 |= (pc & 1u) << j;
-        m.B1 |= ((pc >> 1) & 1u) << j;
-        m.B2 |= ((pc >> 2) & 1u) << j;
-      }
-      bool rejected = false;
-      // sixteen columns per step from one 16-byte load of reference codes and one of read characters (each lane
-      // walks its own window, so wide loads are what keeps the request count down); the loads of the next step
-      // are issued before this step's arithmetic
-      const int n_full = L & ~15;
-      const uint8_t *pp = pat + 2 * e;
-      uint4 pw = make_uint4(0, 0, 0, 0), rw = make_uint4(0, 0, 0, 0);
-      if (n_full > 0) {
-        pw = load_u128_unaligned(pp);
-        rw = load_u128_unaligned(strand == 0 ? rd : rd + L - 16);
-      }
-      for (int col = 0; col < n_full && !rejected; col += 16) {
-        const uint4 pw_cur = pw, rw_cur = rw;
-        if (col + 16 < n_full) {
-          pw = load_u128_unaligned(pp + col + 16);
-          rw = load_u128_unaligned(strand == 0 ? rd + col + 16 : rd + L - 32 - col);
+    const uint32_t read = (meta & ~kMeta16) >> 1, strand = meta & 1u;
+    const uint32_t wm = (meta & kMeta16) ? 0xFFFFu : 0xFFFFFFFFu;
+    const uint64_t c = p.cand[i];
+    const uint64_t pat = p.seq_off[(uint32_t)(c >> 32)] + (uint32_t)c;  // base index of pattern[0]
+    const uint64_t off = p.read_off[read];
+    const int L = (int)(p.read_off[read + 1] - off);
+    const uint8_t *rd = p.bases + off;
+    const uint32_t complement = strand ? 0x03030303u : 0u;
+    MyersState m{0, 0, 0};
+    bool rejected = false;
+    const int n_steps = (L + 15) >> 4;
+    // the reverse strand's chunk comes from the far end; the last, partial one may start in front of the read
+    auto text_chunk = [&](int col) { return load_u128_unaligned(strand == 0 ? rd + col : rd + (L - 16 - col)); };
+    auto plane_chunk = [&](int q, int col) { return load_u128_unaligned(p.plane[q] + ((pat + (uint32_t)col) >> 3)); };
+    uint4 rw = make_uint4(0, 0, 0, 0), P0 = rw, P1 = rw, P2 = rw, P0n = rw, P1n = rw, P2n = rw;
+    if (n_steps > 0) {
+      rw = text_chunk(0);
+      P0n = plane_chunk(0, 0), P1n = plane_chunk(1, 0), P2n = plane_chunk(2, 0);
+    }
+    const uint32_t pat_bit = (uint32_t)pat & 7u;
+    for (int step = 0; step < n_steps && !rejected; ++step) {
+      const int col = step << 4, sub = step % kStepsPerPlaneLoad;
+      const uint4 r = rw;
+      if (sub == 0) {  // loads of the next stretch are issued one stretch ahead, those of the next step one step ahead
+        P0 = P0n, P1 = P1n, P2 = P2n;
+        if (step + kStepsPerPlaneLoad < n_steps) {
+          const int nc = col + 16 * kStepsPerPlaneLoad;
+          P0n = plane_chunk(0, nc), P1n = plane_chunk(1, nc), P2n = plane_chunk(2, nc);
         }
-        const uint32_t pws[4] = {pw_cur.x, pw_cur.y, pw_cur.z, pw_cur.w};
-        const uint32_t rws[4] = {rw_cur.x, rw_cur.y, rw_cur.z, rw_cur.w};
+      }
+      if (step + 1 < n_steps) rw = text_chunk(col + 16);
+      // window of this step: pattern[col .. col + 16 + 2e), bit j <-> pattern[col + j]
+      const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat + 96 k) & 7 == pat & 7
+      const uint32_t b0 = bits_at(P0, wbit), b1 = bits_at(P1, wbit), b2 = bits_at(P2, wbit);
+      uint32_t cw[4], nw[4];
+      {
+        const uint32_t w0 = strand ? __builtin_bswap32(r.w) : r.x, w1 = strand ? __builtin_bswap32(r.z) : r.y;
+        const uint32_t w2 = strand ? __builtin_bswap32(r.y) : r.z, w3 = strand ? __builtin_bswap32(r.x) : r.w;
+        decode4(w0, complement, cw[0], nw[0]);
+        decode4(w1, complement, cw[1], nw[1]);
+        decode4(w2, complement, cw[2], nw[2]);
+        decode4(w3, complement, cw[3], nw[3]);
+      }
+      if (col + 16 <= L) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const uint32_t pc = (pws[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-          uint32_t tc;
-          if (strand == 0) {
-            tc = base_code((rws[q >> 2] >> (8 * (q & 3))) & 0xFFu);
-          } else {  // prepare_negative_sequence_at (src/sequence_batch.h:90-98): read backwards, complement
-            const int qq = 15 - q;
-            tc = base_code((rws[qq >> 2] >> (8 * (qq & 3))) & 0xFFu);
-            tc = tc < 4u ? 3u - tc : 4u;
-          }
-          (void)myers_column(m, pc, tc, e, band, wm);
+          const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)cw[q >> 2], 8 * (q & 3), 1);
+          const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)cw[q >> 2], 8 * (q & 3) + 1, 1);
+          const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)nw[q >> 2], 8 * (q & 3), 1);
+          myers_column(m, b0, b1, b2, m0, m1, m2, (uint32_t)q, width, wm);
         }
-        // the score along the band's lowest diagonal never decreases, so testing the early-reject threshold
-        // (src/align.c:128-130) once per step rejects exactly the candidates a per-column test would
-        rejected = m.score > 3 * e;
-      }
-      for (int col = n_full; col < L && !rejected; ++col) {  // up to fifteen trailing columns
-        uint32_t pc = pp[col];
-        uint32_t tc;
-        if (strand == 0) {
-          tc = base_code(rd[col]);
-        } else {
-          tc = base_code(rd[L - 1 - col]);
-          tc = tc < 4u ? 3u - tc : 4u;
-        }
-        rejected = myers_column(m, pc, tc, e, band, wm);
-      }
-      int score = m.score;
-      int best = score, endp = L - 1;
-      if (!rejected) {
-        for (int j = 0; j < 2 * e; ++j) {  // first strict minimum (src/align.c:135-146)
-          score += (int)((m.VP >> j) & 1u) - (int)((m.VN >> j) & 1u);
-          if (score < best) {
-            best = score;
-            endp = L + j;
-          }
+      } else {  // up to fifteen trailing columns
+        const uint64_t clo = ((uint64_t)cw[1] << 32) | cw[0], chi = ((uint64_t)cw[3] << 32) | cw[2];
+        const uint64_t nlo = ((uint64_t)nw[1] << 32) | nw[0], nhi = ((uint64_t)nw[3] << 32) | nw[2];
+        for (int q = 0; q < L - col; ++q) {
+          const uint32_t cb = (uint32_t)((q < 8 ? clo : chi) >> (8 * (q & 7)));
+          const uint32_t nb = (uint32_t)((q < 8 ? nlo : nhi) >> (8 * (q & 7)));
+          myers_column(m, b0, b1, b2, 0u - (cb & 1u), 0u - ((cb >> 1) & 1u), 0u - (nb & 1u), (uint32_t)q, width, wm);
         }
       }
-      accepted = !rejected && best <= e;
-      p.ed[i] = accepted ? (uint8_t)best : (uint8_t)0xFF;
-      p.end[i] = accepted ? (int16_t)endp : (int16_t)0;
-      if (accepted) first_of_read = atomicAdd(&p.n_map[read], 1u) == 0u;
+      // the score along the band's lowest diagonal never decreases, so testing the early-reject threshold
+      // (src/align.c:128-130) once per step rejects exactly the candidates a per-column test would
+      rejected = m.score > 3 * e;
     }
-    uint64_t m_acc = __ballot(accepted), m_first = __ballot(first_of_read);
-    if (lane_id() == 0) {
-      if (m_acc) atomicAdd(&p.stats[2], (unsigned long long)__popcll(m_acc));
-      if (m_first) atomicAdd(&p.stats[3], (unsigned long long)__popcll(m_first));
+    int score = m.score;
+    int best = score, endp = L - 1;
+    if (!rejected) {
+      for (int j = 0; j < 2 * e; ++j) {  // first strict minimum (src/align.c:135-146)
+        score += (int)((m.VP >> j) & 1u) - (int)((m.VN >> j) & 1u);
+        if (score < best) {
+          best = score;
+          endp = L + j;
+        }
+      }
     }
+    const bool accepted = !rejected && best <= e;
+    p.ed[i] = accepted ? (uint8_t)best : (uint8_t)0xFF;
+    p.end[i] = accepted ? (int16_t)endp : (int16_t)0;
+  }
+}
+
+// MappingStats after verification (src/map.c:37,48,51): accepted candidates per read -> n_map, their sum ->
+// "number of mapping", reads with at least one -> "number of mapped read".  One lane per read.
+struct CountParams {
+  const uint32_t *cand_begin, *cand_count;  // 2 * n_reads
+  const uint8_t *ed;
+  const uint32_t *ctr;
+  uint32_t n_reads;
+  uint32_t *n_map;
+  unsigned long long *stats;  // [2] mappings, [3] mapped reads
+};
+
+__global__ void __launch_bounds__(256) count_mappings_kernel(CountParams p) {
+  if (p.ctr[1] != 0) return;
+  // grid-stride with per-thread sums and ONE pair of atomics per block: atomics on a single address complete at
+  // roughly 10 ns each, so one pair per wave of reads would cost more than the rest of the batch's verification
+  __shared__ uint32_t part[2][4];
+  uint32_t mappings = 0, mapped = 0;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_reads; r += gridDim.x * blockDim.x) {
+    const uint2 b = *(const uint2 *)(p.cand_begin + 2u * r), cnt = *(const uint2 *)(p.cand_count + 2u * r);
+    uint32_t n = 0;
+    for (uint32_t i = b.x; i < b.x + cnt.x; ++i) n += (uint32_t)(p.ed[i] != 0xFFu);
+    for (uint32_t i = b.y; i < b.y + cnt.y; ++i) n += (uint32_t)(p.ed[i] != 0xFFu);
+    p.n_map[r] = n;
+    mappings += n, mapped += (uint32_t)(n > 0);
+  }
+  for (int d = 32; d >= 1; d >>= 1) mappings += __shfl_xor(mappings, d), mapped += __shfl_xor(mapped, d);
+  if (lane_id() == 0) part[0][threadIdx.x >> 6] = mappings, part[1][threadIdx.x >> 6] = mapped;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = part[0][0] + part[0][1] + part[0][2] + part[0][3], b = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    if (a) atomicAdd(&p.stats[2], (unsigned long long)a);
+    if (b) atomicAdd(&p.stats[3], (unsigned long long)b);
+  }
+}
+
+// bit q of code(text[i]) -> bit i of plane q; one thread per byte of the planes (eight bases)
+__global__ void ref_planes_kernel(const uint8_t *codes, uint64_t n_bytes, uint8_t *p0, uint8_t *p1, uint8_t *p2) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += stride) {
+    uint64_t w;
+    __builtin_memcpy(&w, codes + 8 * b, 8);
+    uint32_t o0 = 0, o1 = 0, o2 = 0;
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t c = (uint32_t)(w >> (8 * k)) & 0xFFu;
+      o0 |= (c & 1u) << k, o1 |= ((c >> 1) & 1u) << k, o2 |= ((c >> 2) & 1u) << k;
+    }
+    p0[b] = (uint8_t)o0, p1[b] = (uint8_t)o1, p2[b] = (uint8_t)o2;
   }
 }
 

@@ -650,9 +650,9 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
         if ((unsigned long long)base + n_out > p.cand_cap) {
           if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
         } else if (ok) {
-          const uint32_t at = base + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
+          const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
           p.cand[at] = cv - e64;
-          p.cand_meta[at] = read * 2u + strand;
+          p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
         }
       }
       if (ln == 2u * rb + strand) blk_begin = base, blk_count = n_out, blk_mine = true;

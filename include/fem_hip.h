@@ -148,7 +148,8 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
  * 1 = verify kernel, 2 = seed/filter kernel (generic form: the reads the fast
  * form queued, or every read when the fast form does not apply); of
  * fem_dev_fetch_records: 3 = ordering of the mappings, 4 = traceback + MD,
- * 5 = compaction (one entry per call, several kernels each). */
+ * 5 = compaction (one entry per call, several kernels each);
+ * 6 = per-read mapping counts + counters after verification. */
 int fem_dev_set_timing(fem_dev *h, int on);
 int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);
