@@ -209,6 +209,7 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.dp_bits = take(n_groups * R * 8u);
   l.picked = take(n_groups * R * 16u);
   l.X = take(64u * 8u);  // scatter
+  l.A = take(femk::kListScratchBytes);  // lists_in_lanes
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
   l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;

@@ -78,74 +78,123 @@ __device__ __forceinline__ uint64_t sort_into_lanes(bool mine, uint64_t v, uint6
   return ln < nF ? scatter[ln] : 0;
 }
 
+// wave-wide inclusive scans over the 64 lanes (DPP: row_shr 1/2/4/8, then row_bcast 15 and 31); zero is the identity
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+  x += dpp_or_zero<0x111, 0xF>(x), x += dpp_or_zero<0x112, 0xF>(x), x += dpp_or_zero<0x114, 0xF>(x);
+  x += dpp_or_zero<0x118, 0xF>(x), x += dpp_or_zero<0x142, 0xA>(x), x += dpp_or_zero<0x143, 0xC>(x);
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+  x = max(x, dpp_or_zero<0x111, 0xF>(x)), x = max(x, dpp_or_zero<0x112, 0xF>(x)), x = max(x, dpp_or_zero<0x114, 0xF>(x));
+  x = max(x, dpp_or_zero<0x118, 0xF>(x)), x = max(x, dpp_or_zero<0x142, 0xA>(x)), x = max(x, dpp_or_zero<0x143, 0xC>(x));
+  return x;
+}
+__device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t from_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane * 4u), (int)v);
+}
+
+// LDS scratch of lists_in_lanes (bytes, per wave)
+constexpr uint32_t kListEv = 0, kListEg = 68 * 8, kListOwn = kListEg + 68 * 4, kListMax = kListOwn + 64 * 4;
+constexpr uint32_t kListScratchBytes = kListMax + 4 * 8;
+
 // ---------------------------------------------------------------------------------------------------------
-// One strand whose 3*R selected seeds hold at most 64 occurrences: one occurrence per lane, everything else on
-// wave-uniform scalars (src/filter.c:80-131 as the closed form of SURVEY.md A.2, then :45-78 group by group).
-// Seeds live one per lane: lane lane0 + group*R + run.  Returns the number of candidates, left in cv.
+// One strand whose 3*R selected seeds hold `total` <= 64 occurrences: one occurrence per lane, vector work only —
+// the scalar unit is the busiest port of this kernel, so nothing here loops over lanes with readlane.
+// Seeds live one per lane (lane0 + group*R + run; `at` = exclusive prefix sum of their frequencies).
+//   1. entry lane i finds its seed (owner marks in LDS + prefix max), loads occ[lookup + i - at]   src/filter.c:89,106
+//   2. last run of each group: only values <= max of the other runs survive (LDS atomic max)        src/filter.c:85
+//   3. entries ranked by (group, value) — the order X of merge_candidate_locations — all pairs by rotation
+//   4. additional_qgram_filter as the reference states it: X[i] stays iff X[i+a] <= X[i] + e        src/filter.c:118-131
+//   5. per group, survivors (already sorted) are merged greedily into the candidates              src/filter.c:45-78
+// Returns the number of candidates (left in cv), 0xFFFFFFFF if they outgrow the wave.
 // ---------------------------------------------------------------------------------------------------------
 template <int R>
-__device__ uint32_t lists_in_lanes(const SeedParams &p, uint32_t lane0, uint64_t nonempty, uint32_t s_start,
-                                   uint32_t s_lo, uint32_t s_freq, uint32_t s_grp, uint32_t s_run, uint64_t *scatter,
-                                   uint64_t &cv) {
+__device__ uint32_t lists_in_lanes(const SeedParams &p, uint32_t lane0, uint32_t at, uint32_t total, uint32_t s_start,
+                                   uint32_t s_lo, uint32_t s_freq, uint8_t *ls, uint64_t *scatter, uint64_t &cv) {
   const uint32_t ln = lane_id();
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
   const uint64_t e64 = (uint64_t)p.e;
-  const uint64_t ne = (nonempty >> lane0) & ((1ull << kSeeds) - 1ull);
+  uint64_t *ev = (uint64_t *)(ls + kListEv);
+  uint32_t *eg = (uint32_t *)(ls + kListEg);
+  uint32_t *own = (uint32_t *)(ls + kListOwn);
+  unsigned long long *gmax = (unsigned long long *)(ls + kListMax);
+  // 1. expand the seeds' lists into entry lanes 0 .. total-1
+  own[ln] = 0;
+  if (ln < 4u) gmax[ln] = 0;
+  wave_sync_lds();
+  if (ln >= lane0 && ln < lane0 + kSeeds && s_freq > 0) own[at] = ln + 1u;  // at < total <= 64
+  wave_sync_lds();
+  const uint32_t owner = wave_scan_max(own[ln]);  // seeds come in lane order, so the last mark at or before i owns i
+  const bool have = ln < total;
+  const uint32_t src = have ? owner - 1u : lane0;
+  const uint32_t e_at = lane_pull(at, src), e_lo = lane_pull(s_lo, src), e_st = lane_pull(s_start, src);
+  const uint32_t within = src - lane0;
+  const uint32_t e_grp = within / (uint32_t)R, e_run = within % (uint32_t)R;
   bool valid = false;
   uint64_t v = 0;
-  uint32_t grp = 0, run = 0, at = 0;
-  for (uint64_t m = ne; m;) {
-    const int j = __builtin_ctzll(m) + (int)lane0;
-    m &= m - 1;
-    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
-    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
-    const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)s_grp, j);
-    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)s_run, j);
-    if (ln >= at && ln < at + f) {
-      const uint64_t o = p.occ[(uint64_t)lo + (ln - at)];
-      valid = (uint32_t)o >= st;  // src/filter.c:89,106
-      v = o - st;
-      grp = gj, run = rj;
+  if (have) {
+    const uint64_t o = p.occ[(uint64_t)e_lo + (ln - e_at)];
+    valid = (uint32_t)o >= e_st;  // src/filter.c:89,106
+    v = o - e_st;
+  }
+  // 2. last seed of each group
+  const bool is_last = valid && e_run == (uint32_t)(R - 1);
+  if (__ballot(is_last)) {
+    if (valid && !is_last) atomicMax(&gmax[e_grp], (unsigned long long)v + 1ull);  // 0 = no other run has a value
+    wave_sync_lds();
+    if (is_last) {
+      const unsigned long long mu = gmax[e_grp];
+      if (mu == 0 || v > mu - 1ull) valid = false;
     }
-    at += f;
   }
-  // last seed of each group: only values <= max of the other runs survive (src/filter.c:85)
-  for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
-    const bool is_last = valid && grp == g && run == (uint32_t)(R - 1);
-    if (!__ballot(is_last)) continue;
-    const uint64_t mu = __ballot(valid && grp == g && run != (uint32_t)(R - 1));
-    uint64_t max_u = 0;
-    for (uint64_t m = mu; m;) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint64_t x = readlane64(v, j);
-      max_u = x > max_u ? x : max_u;
-    }
-    if (is_last && (mu == 0 || v > max_u)) valid = false;
+  const uint32_t n_valid = (uint32_t)__popcll(__ballot(valid));
+  if (n_valid <= (uint32_t)p.a) return 0;
+  // 3. rank by (group, value, lane); dropped entries sort behind everything (group 3)
+  const uint32_t g = valid ? e_grp : 3u;
+  ev[ln] = v;
+  eg[ln] = have ? g : 3u;
+  if (ln < 4u) eg[64u + ln] = 3u;
+  wave_sync_lds();
+  uint32_t rank = 0;
+  for (uint32_t s = 1; s < total; ++s) {
+    uint32_t j = ln + s;
+    j = j >= total ? j - total : j;
+    j = have ? j : 0u;
+    const uint64_t vj = ev[j];
+    const uint32_t gj = eg[j];
+    rank += (uint32_t)(gj < g || (gj == g && (vj < v || (vj == v && j < ln))));
   }
-  // additional_qgram_filter (src/filter.c:118-131): >= a+1 values of the same group in [v, v+e]
-  const uint64_t vm = __ballot(valid);
-  if ((uint32_t)__popcll(vm) <= (uint32_t)p.a) return 0;
-  uint32_t cnt = 0;
-  for (uint64_t m = vm; m;) {
-    const int j = __builtin_ctzll(m);
-    m &= m - 1;
-    const uint64_t x = readlane64(v, j);
-    const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)grp, j);
-    cnt += (uint32_t)(gj == grp && x >= v && x <= v + e64);
-  }
-  const bool pass = valid && cnt > (uint32_t)p.a;
+  wave_sync_lds();
+  if (have) ev[rank] = v, eg[rank] = g;
+  wave_sync_lds();
+  // 4. X[i] stays iff X[i + a] exists in the same group and is <= X[i] + e
+  const uint32_t my_g = eg[ln];
+  const uint64_t my_v = ev[ln];
+  const uint32_t far = ln + (uint32_t)p.a;  // < 64 + 3: eg is padded with "dropped", ev's padding is never compared
+  const bool pass = ln < n_valid && eg[far] == my_g && ev[far] <= my_v + e64;
   if (!__ballot(pass)) return 0;
+  // 5. staged merge, group by group
   uint32_t nA = 0;
-  for (uint32_t g = 0; g < (uint32_t)kStep; ++g) {
-    const bool mine = pass && grp == g;
+  for (uint32_t grp = 0; grp < (uint32_t)kStep; ++grp) {
+    const bool mine = pass && my_g == grp;
     const uint64_t mf = __ballot(mine);
     const uint32_t nF = (uint32_t)__popcll(mf);
     if (nF == 0) continue;
-    const uint64_t fs = sort_into_lanes(mine, v, mf, nF, scatter);
-    nA = merge_group(cv, nA, fs, nF, e64);
-    if (nA == 0xFFFFFFFFu) return nA;
+    wave_sync_lds();
+    if (mine) scatter[__popcll(mf & ((1ull << ln) - 1ull))] = my_v;  // survivors are in ascending order already
+    wave_sync_lds();
+    const uint64_t fs = ln < nF ? scatter[ln] : 0;
+    if (nA == 0 && readlane64(fs, (int)nF - 1) <= readlane64(fs, 0) + e64) {
+      cv = ln == 0 ? fs : 0;  // everything within e of the first: the greedy rule keeps the first only
+      nA = 1;
+    } else {
+      nA = merge_group(cv, nA, fs, nF, e64);
+      if (nA == 0xFFFFFFFFu) return nA;
+    }
   }
   return nA;
 }
@@ -408,6 +457,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
   uint8_t *blk_chars = wbase + p.lay.blk;
+  uint8_t *list_scratch = wbase + p.lay.A;
   if (HASH)
     for (uint32_t i = ln; i < bloom_slots(R) / 16u; i += kWave) bloom[i] = 0;
   const uint32_t smax = p.lay.smax;
@@ -464,9 +514,9 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 
     bool strand_ok[2] = {true, true};
     uint32_t pre_g = 0;
-    uint32_t s_start = 0, s_lo = 0, s_freq = 0, s_grp = 0, s_run = 0;
+    uint32_t s_start = 0, s_lo = 0, s_freq = 0;
     uint64_t nonempty = 0;
-    uint32_t group_total[2 * kStep] = {0, 0, 0, 0, 0, 0}, strand_total[2] = {0, 0};
+    uint32_t strand_total[2] = {0, 0}, s_at = 0;
     if (!slow) {
       // ---- encode ----
       uint32_t any_n = 0;
@@ -555,32 +605,21 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
       pre_g = select_seeds_lanes<R>(p, S, strand_ok, sf, smax, dp_w, take_bits, s_start, s_lo, s_freq);
       // lane s = strand * kSeeds + group * R + run now holds that run's seed
-      if (ln < 2u * kSeeds) {
-        const uint32_t within = ln % kSeeds;
-        s_grp = within / (uint32_t)R, s_run = within % (uint32_t)R;
-        if (!strand_ok[ln / kSeeds]) s_freq = 0;
-      }
+      if (ln < 2u * kSeeds && !strand_ok[ln / kSeeds]) s_freq = 0;
       STAMP(prof, 2);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 2
       continue;
 #endif
       nonempty = __ballot(s_freq > 0);
-      // occurrences selected per (strand, group); a strand with <= 64 in total is done in registers, longer
-      // groups need the hash-join form (HASH) and its capacity
-      for (uint32_t g = 0; g < 2u * (uint32_t)kStep && !slow; ++g) {
-        uint32_t n_g = 0;
-        for (uint64_t m = (nonempty >> (g * (uint32_t)R)) & ((1ull << R) - 1ull); m;) {
-          const int j = __builtin_ctzll(m) + (int)(g * (uint32_t)R);
-          m &= m - 1;
-          const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-          n_g = f > 0x7fffffffu - n_g ? 0x7fffffffu : n_g + f;
-        }
-        group_total[g] = n_g;
-        slow = n_g > (HASH ? p.lay.xcap : (uint32_t)kWave);  // xcap = most occurrences of one group the table takes
-      }
-      for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
-        strand_total[strand] = group_total[strand * kStep] + group_total[strand * kStep + 1] + group_total[strand * kStep + 2];
-        if (!HASH) slow = strand_total[strand] > (uint32_t)kWave;
+      // occurrences selected per strand: an inclusive scan over the seed lanes (frequencies clamped so that the sum
+      // cannot wrap).  A strand with <= 64 in total is done in lanes; more needs the hash-join form (HASH).
+      {
+        const uint32_t incl = wave_scan_add(s_freq < 65u ? s_freq : 65u);
+        const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)kSeeds - 1);
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 2 * (int)kSeeds - 1);
+        strand_total[0] = mid, strand_total[1] = all - mid;
+        s_at = incl - (s_freq < 65u ? s_freq : 65u) - (ln >= kSeeds ? mid : 0u);
+        if (!HASH) slow = strand_total[0] > (uint32_t)kWave || strand_total[1] > (uint32_t)kWave;
       }
     }
 
@@ -592,11 +631,25 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
       if (!strand_ok[strand]) continue;
       if (strand_total[strand] <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
       const uint32_t lane0 = strand * kSeeds;
-      if (strand_total[strand] <= (uint32_t)kWave)
-        kepts[strand] = lists_in_lanes<R>(p, lane0, nonempty, s_start, s_lo, s_freq, s_grp, s_run, scatter, cvs[strand]);
-      else if (HASH)
-        kepts[strand] = lists_bloom_join<R>(p, lane0, &group_total[strand * kStep], s_start, s_lo, s_freq, scatter, bloom,
-                                            cvs[strand]);
+      if (strand_total[strand] <= (uint32_t)kWave) {
+        kepts[strand] = lists_in_lanes<R>(p, lane0, s_at, strand_total[strand], s_start, s_lo, s_freq, list_scratch, scatter,
+                                          cvs[strand]);
+      } else if (HASH) {
+        uint32_t group_total[kStep];  // xcap = most occurrences of one group the join takes
+        for (uint32_t g = 0; g < (uint32_t)kStep && !slow; ++g) {
+          uint32_t n_g = 0;
+          for (uint64_t m = (nonempty >> (lane0 + g * (uint32_t)R)) & ((1ull << R) - 1ull); m;) {
+            const int j = __builtin_ctzll(m) + (int)(lane0 + g * (uint32_t)R);
+            m &= m - 1;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+            n_g = f > 0x7fffffffu - n_g ? 0x7fffffffu : n_g + f;
+          }
+          group_total[g] = n_g;
+          slow = n_g > p.lay.xcap;
+        }
+        if (slow) break;
+        kepts[strand] = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cvs[strand]);
+      }
       if (kepts[strand] == 0xFFFFFFFFu) slow = true;
     }
 
