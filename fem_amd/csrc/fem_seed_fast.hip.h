@@ -673,13 +673,14 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 #if defined(FEM_ABLATE) && FEM_ABLATE == 4
     continue;
 #endif
+    // ---- "candidates before the filter": uint32 sum of the strand's three M[R][C-1] (src/filter.c:202), widened ----
+    {
+      const uint32_t t = pre_g + dpp_or_zero<0x111, 0xF>(pre_g) + dpp_or_zero<0x112, 0xF>(pre_g);  // lanes 2 and 5: strand sums
+      if (strand_ok[0]) pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)t, 2);
+      if (strand_ok[1]) pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)t, 5);
+    }
     // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
     for (uint32_t strand = 0; strand < 2u; ++strand) {
-      if (strand_ok[strand]) {
-        uint32_t pre = 0;  // uint32 sum of the groups' M[R][C-1] (src/filter.c:202)
-        for (int si = 0; si < kStep; ++si) pre += (uint32_t)__builtin_amdgcn_readlane((int)pre_g, (int)(strand * kStep) + si);
-        pre_sum += pre;
-      }
       const uint64_t cv = cvs[strand];
       bool ok = false;
       if (ln < kepts[strand]) {
