@@ -205,11 +205,11 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   };
   l.pkw = take(l.n_words * 4u);
   l.nkw = take(l.n_words * 4u);
-  l.sf = take(2u * l.smax * 8u);
+  l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 8u));  // reused for the strands' candidates once the seeds are selected
   l.dp_bits = take(n_groups * R * 8u);
-  l.picked = take(n_groups * R * 16u);
   l.X = take(64u * 8u);  // scatter
   l.A = take(femk::kListScratchBytes);  // lists_in_lanes
+  l.B = take(64u * 8u);                 // the block's begin/count entries
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
   l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;

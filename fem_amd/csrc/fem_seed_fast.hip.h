@@ -18,6 +18,7 @@ namespace femk {
 constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
 constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
+constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast kernel did not handle
 
 // char -> 2-bit code for four bases at once.  code: per byte 0..3; nflag: per byte 1 where the base is not
 // A/C/G/T in either case (src/utils.h:72).
@@ -357,14 +358,31 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
   constexpr uint32_t n_groups = 2u * (uint32_t)kStep;
   constexpr uint32_t kFill = 0xFFFFFFFFu;  // identity of min: lets the DPP move fold into v_min_u32
   const uint32_t per_pass = (uint32_t)kWave / W;
-  const uint32_t n_pass = (n_groups + per_pass - 1u) / per_pass;
   const uint32_t c = ln & (W - 1u), slot = ln / W;
   const uint32_t inf = p.inf32;
   uint32_t pre_mine = 0;
-  for (uint32_t ps = 0; ps < n_pass; ++ps) {
-    const uint32_t g = ps * per_pass + slot;
+  // A group whose seeds at column 0 of every row (seed 0, Lg, 2 Lg, ...) all have frequency 0 has a zero-cost
+  // selection: its minimum is 0, every seed the traceback takes has frequency 0 and the group contributes nothing
+  // (M[R][C-1] = 0 as well).  On a sparse index that is most groups away from the read's true locus; the DP runs
+  // for the others only, packed into as few passes as they need.
+  uint32_t live = 0;
+  {
+    const uint32_t tg = ln / (uint32_t)R, tr = ln % (uint32_t)R;
+    const bool t_in = ln < n_groups * (uint32_t)R && strand_ok[(tg / (uint32_t)kStep) & 1u];
+    const uint32_t t_idx = ((tg / (uint32_t)kStep) & 1u) * smax + tg % (uint32_t)kStep + (uint32_t)kStep * (uint32_t)kLg * tr;
+    const uint64_t zero = __ballot(t_in && sf[t_in ? t_idx : 0u].y == 0u);
+    const uint64_t full = (1ull << R) - 1ull;
+    const bool is_live = ln < n_groups && strand_ok[(ln / (uint32_t)kStep) & 1u] && ((zero >> (ln * (uint32_t)R)) & full) != full;
+    live = (uint32_t)__ballot(is_live);
+  }
+  uint32_t packed = 0, n_live = 0;  // group ids of the live groups, three bits each
+  for (uint32_t m = live; m; m &= m - 1u) packed |= (uint32_t)__builtin_ctz(m) << (3u * n_live++);
+  const uint32_t n_pass_live = (n_live + per_pass - 1u) / per_pass;
+  for (uint32_t ps = 0; ps < n_pass_live; ++ps) {
+    const uint32_t k = ps * per_pass + slot;
+    const uint32_t g = (packed >> (3u * k)) & 7u;
     const uint32_t strand = g / (uint32_t)kStep, si = g % (uint32_t)kStep;
-    const bool g_ok = g < n_groups && strand_ok[strand & 1u];
+    const bool g_ok = k < n_live;
     const uint32_t ncols = g_ok ? (uint32_t)((S - (int)si) / kStep - R * kLg + 1) : 0u;  // C - 1
     const bool in_seg = c < ncols;
     const uint2 *sfs = sf + (strand & 1u) * smax + si;
@@ -392,29 +410,28 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
     }
     // M[R][C-1] of group ln: last column of that group's segment, if it ran in this pass
     const uint32_t own_si = ln % (uint32_t)kStep;
-    const uint32_t own_ncols = (ln < n_groups && strand_ok[(ln / (uint32_t)kStep) & 1u])
-                                   ? (uint32_t)((S - (int)own_si) / kStep - R * kLg + 1) : 0u;
-    const uint32_t got = __shfl(M, (int)((ln % per_pass) * W + (own_ncols ? own_ncols - 1u : 0u)));
-    if (ln < n_groups && ln / per_pass == ps && own_ncols) pre_mine = got;
+    const bool own_live = ln < n_groups && ((live >> ln) & 1u);
+    const uint32_t own_k = (uint32_t)__popc(live & ((1u << (ln & 31u)) - 1u));  // slot index of group ln among the live ones
+    const uint32_t own_ncols = own_live ? (uint32_t)((S - (int)own_si) / kStep - R * kLg + 1) : 0u;
+    const uint32_t got = __shfl(M, (int)((own_k % per_pass) * W + (own_ncols ? own_ncols - 1u : 0u)));
+    if (own_live && own_k / per_pass == ps && own_ncols) pre_mine = got;
   }
   wave_sync_lds();
   // ---- traceback: lane (g, t) finds the seed taken at row R - t ----
   const uint32_t g = ln / (uint32_t)R, t = ln % (uint32_t)R;
-  const bool act = ln < n_groups * (uint32_t)R && strand_ok[(g / (uint32_t)kStep) & 1u];
+  const bool act = ln < n_groups * (uint32_t)R && ((live >> g) & 1u);
   const uint32_t g_c = act ? g : 0u;
   const uint32_t si = g_c % (uint32_t)kStep;
   const uint32_t ncols = (uint32_t)((S - (int)si) / kStep - R * kLg + 1);
-  const uint32_t pass_of = g_c / per_pass, slot_of = g_c % per_pass;
-  unsigned long long rows[R];
-#pragma unroll
-  for (int r = 1; r <= R; ++r) rows[r - 1] = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)];
+  const uint32_t k_c = (uint32_t)__popc(live & ((1u << g_c) - 1u));
+  const uint32_t pass_of = k_c / per_pass, slot_of = k_c % per_pass;
   int col = (int)ncols - 1;
   bool alive = act;
   uint32_t sidx = 0xFFFFFFFFu;
 #pragma unroll
   for (int r = R; r >= 1; --r) {
     if (alive && (uint32_t)(R - r) <= t) {
-      const unsigned long long seg = (rows[r - 1] >> (slot_of * W)) & ((2ull << col) - 1ull);
+      const unsigned long long seg = (take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W)) & ((2ull << col) - 1ull);
       if (seg == 0) {
         alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
       } else {
@@ -458,6 +475,8 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
   uint8_t *blk_chars = wbase + p.lay.blk;
   uint8_t *list_scratch = wbase + p.lay.A;
+  uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
+  uint64_t *cand_lds = (uint64_t *)(wbase + p.lay.sf);  // 2 x 64 candidates; the seed table's region holds at least that
   if (HASH)
     for (uint32_t i = ln; i < bloom_slots(R) / 16u; i += kWave) bloom[i] = 0;
   const uint32_t smax = p.lay.smax;
@@ -473,8 +492,9 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
-  uint32_t blk_begin = 0, blk_count = 0;  // lane 2*i + strand: entry of read r0 + i
-  bool blk_mine = false;                   // false for reads left to the generic kernel (it writes their entries)
+  // begin / count of the block's 2 * kReadBlock (read, strand) entries gather in LDS and go out in one vector store;
+  // kBlkSkip marks reads left to the generic kernel (it writes their entries)
+  blk_entries[ln] = make_uint2(kBlkSkip, 0u);
   // The block's characters are contiguous: one coalesced copy into LDS pays the HBM latency once for the whole
   // block instead of once per read (each read otherwise starts with a dependent, mostly line-missing load).
   const bool staged = p.lay.blk_bytes != 0;
@@ -506,7 +526,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
     bool shape_ok = S > 0 && R <= S / kStep;
     if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
     if (!shape_ok) {
-      if (ln / 2u == rb) blk_mine = true;  // both entries stay 0
+      if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // both entries stay 0
       continue;
     }
     const uint32_t widest = (uint32_t)(S / kStep - R * kLg + 1);  // columns of phase group 0
@@ -514,6 +534,7 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 
     bool strand_ok[2] = {true, true};
     uint32_t pre_g = 0;
+    unsigned long long pre_read = 0;
     uint32_t s_start = 0, s_lo = 0, s_freq = 0;
     uint64_t nonempty = 0;
     uint32_t strand_total[2] = {0, 0}, s_at = 0;
@@ -610,6 +631,14 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 #if defined(FEM_ABLATE) && FEM_ABLATE == 2
       continue;
 #endif
+      // "candidates before the filter": uint32 sum of the strand's three M[R][C-1] (src/filter.c:202), widened; added
+      // to the counter only once the read is known to stay in this kernel
+      {
+        const uint32_t t = pre_g + dpp_or_zero<0x111, 0xF>(pre_g) + dpp_or_zero<0x112, 0xF>(pre_g);  // lanes 2 and 5: strand sums
+        pre_read = 0;
+        if (strand_ok[0]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 2);
+        if (strand_ok[1]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 5);
+      }
       nonempty = __ballot(s_freq > 0);
       // occurrences selected per strand: an inclusive scan over the seed lanes (frequencies clamped so that the sum
       // cannot wrap).  A strand with <= 64 in total is done in lanes; more needs the hash-join form (HASH).
@@ -625,15 +654,17 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 
     STAMP(prof, 3);
     // ---- per strand: lists -> candidates (sorted, before the range clip) in lanes 0..kept-1 of cv ----
-    uint64_t cvs[2] = {0, 0};
+    // candidates of the two strands wait in LDS (over the seed table, which is dead by now) until both are known to
+    // fit: registers are what limits the waves per SIMD
     uint32_t kepts[2] = {0, 0};
     for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
       if (!strand_ok[strand]) continue;
       if (strand_total[strand] <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
       const uint32_t lane0 = strand * kSeeds;
       if (strand_total[strand] <= (uint32_t)kWave) {
-        kepts[strand] = lists_in_lanes<R>(p, lane0, s_at, strand_total[strand], s_start, s_lo, s_freq, list_scratch, scatter,
-                                          cvs[strand]);
+        uint64_t cv = 0;
+        kepts[strand] = lists_in_lanes<R>(p, lane0, s_at, strand_total[strand], s_start, s_lo, s_freq, list_scratch, scatter, cv);
+        cand_lds[strand * (uint32_t)kWave + ln] = cv;
       } else if (HASH) {
         uint32_t group_total[kStep];  // xcap = most occurrences of one group the join takes
         for (uint32_t g = 0; g < (uint32_t)kStep && !slow; ++g) {
@@ -648,7 +679,9 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
           slow = n_g > p.lay.xcap;
         }
         if (slow) break;
-        kepts[strand] = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cvs[strand]);
+        uint64_t cv = 0;
+        kepts[strand] = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cv);
+        cand_lds[strand * (uint32_t)kWave + ln] = cv;
       }
       if (kepts[strand] == 0xFFFFFFFFu) slow = true;
     }
@@ -673,15 +706,11 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
 #if defined(FEM_ABLATE) && FEM_ABLATE == 4
     continue;
 #endif
-    // ---- "candidates before the filter": uint32 sum of the strand's three M[R][C-1] (src/filter.c:202), widened ----
-    {
-      const uint32_t t = pre_g + dpp_or_zero<0x111, 0xF>(pre_g) + dpp_or_zero<0x112, 0xF>(pre_g);  // lanes 2 and 5: strand sums
-      if (strand_ok[0]) pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)t, 2);
-      if (strand_ok[1]) pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)t, 5);
-    }
     // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
+    pre_sum += pre_read;
+#pragma unroll 1
     for (uint32_t strand = 0; strand < 2u; ++strand) {
-      const uint64_t cv = cvs[strand];
+      const uint64_t cv = kepts[strand] ? cand_lds[strand * (uint32_t)kWave + ln] : 0;  // written by this same lane
       bool ok = false;
       if (ln < kepts[strand]) {
         const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
@@ -709,14 +738,17 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
           p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
         }
       }
-      if (ln == 2u * rb + strand) blk_begin = base, blk_count = n_out, blk_mine = true;
+      if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
       cand_sum += n_out;
     }
     STAMP(prof, 5);
   }
-  if (blk_mine) {
-    p.cand_begin[r0 * 2u + ln] = blk_begin;
-    p.cand_count[r0 * 2u + ln] = blk_count;
+  wave_sync_lds();
+  const uint2 entry = blk_entries[ln];
+  wave_sync_lds();
+  if (ln < 2u * kReadBlock && entry.x != kBlkSkip) {
+    p.cand_begin[r0 * 2u + ln] = entry.x;
+    p.cand_count[r0 * 2u + ln] = entry.y;
   }
   }
 #ifdef FEM_STAMPS
