@@ -458,8 +458,12 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
   return pre_mine;
 }
 
+// Register budget: the lean form (lists in lanes only) is bound by instruction issue and gains from every extra wave
+// per SIMD up to seven (72 VGPRs, a few cold values spilled); the hash-join form needs its registers.
+constexpr int lean_waves(int R, bool hash) { return hash ? 1 : R <= 6 ? 7 : 6; }
+
 template <int R, bool HASH>
-__global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_waves(R, HASH), 8))) seed_fast_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);  // selected seeds per strand
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
@@ -656,14 +660,18 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
     // ---- per strand: lists -> candidates (sorted, before the range clip) in lanes 0..kept-1 of cv ----
     // candidates of the two strands wait in LDS (over the seed table, which is dead by now) until both are known to
     // fit: registers are what limits the waves per SIMD
-    uint32_t kepts[2] = {0, 0};
+    uint32_t kept0 = 0, kept1 = 0;
     for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
-      if (!strand_ok[strand]) continue;
-      if (strand_total[strand] <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
+      // (selects, not array indexing: an array indexed by the loop variable ends up in scratch memory)
+      const bool s_ok = strand ? strand_ok[1] : strand_ok[0];
+      const uint32_t s_total = strand ? strand_total[1] : strand_total[0];
+      uint32_t kept = 0;
+      if (!s_ok) continue;
+      if (s_total <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
       const uint32_t lane0 = strand * kSeeds;
-      if (strand_total[strand] <= (uint32_t)kWave) {
+      if (s_total <= (uint32_t)kWave) {
         uint64_t cv = 0;
-        kepts[strand] = lists_in_lanes<R>(p, lane0, s_at, strand_total[strand], s_start, s_lo, s_freq, list_scratch, scatter, cv);
+        kept = lists_in_lanes<R>(p, lane0, s_at, s_total, s_start, s_lo, s_freq, list_scratch, scatter, cv);
         cand_lds[strand * (uint32_t)kWave + ln] = cv;
       } else if (HASH) {
         uint32_t group_total[kStep];  // xcap = most occurrences of one group the join takes
@@ -680,10 +688,11 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
         }
         if (slow) break;
         uint64_t cv = 0;
-        kepts[strand] = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cv);
+        kept = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cv);
         cand_lds[strand * (uint32_t)kWave + ln] = cv;
       }
-      if (kepts[strand] == 0xFFFFFFFFu) slow = true;
+      if (kept == 0xFFFFFFFFu) slow = true;
+      if (strand) kept1 = kept; else kept0 = kept;
     }
 
     if (slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
@@ -710,9 +719,10 @@ __global__ void __launch_bounds__(256) seed_fast_kernel(SeedParams p) {
     pre_sum += pre_read;
 #pragma unroll 1
     for (uint32_t strand = 0; strand < 2u; ++strand) {
-      const uint64_t cv = kepts[strand] ? cand_lds[strand * (uint32_t)kWave + ln] : 0;  // written by this same lane
+      const uint32_t kept = strand ? kept1 : kept0;
+      const uint64_t cv = kept ? cand_lds[strand * (uint32_t)kWave + ln] : 0;  // written by this same lane
       bool ok = false;
-      if (ln < kepts[strand]) {
+      if (ln < kept) {
         const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
         const uint32_t slen = p.seq_len[sq];
         ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
