@@ -458,9 +458,11 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
   return pre_mine;
 }
 
-// Register budget: the lean form (lists in lanes only) is bound by instruction issue and gains from every extra wave
-// per SIMD up to seven (72 VGPRs, a few cold values spilled); the hash-join form needs its registers.
-constexpr int lean_waves(int R, bool hash) { return hash ? 1 : R <= 6 ? 7 : 6; }
+// Register budget (measured): the lean form (lists in lanes only) is bound by instruction issue and gains from every
+// extra wave per SIMD up to seven (72 VGPRs, a few cold values spilled; eight loses).  The hash-join form wants
+// ~120-150 registers: with few seeds per group five waves (96 VGPRs) beat four, its LDS allows no more; with many
+// seeds per group the spills cost more than the fifth wave brings.
+constexpr int lean_waves(int R, bool hash) { return hash ? (R <= 6 ? 5 : 1) : R <= 6 ? 7 : 6; }
 
 template <int R, bool HASH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_waves(R, HASH), 8))) seed_fast_kernel(SeedParams p) {
