@@ -91,7 +91,8 @@ struct fem_dev {
   uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
   // reference
   uint8_t *d_ref = nullptr;      // base codes
-  uint8_t *d_plane[3] = {nullptr, nullptr, nullptr};  // bit q of the codes, one bit per base (verify_kernel's windows)
+  // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
+  uint8_t *d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
   uint8_t *d_ref_raw = nullptr;  // the characters as uploaded (the traceback and MD compare and print them)
   uint64_t ref_bytes = 0;
   uint64_t *d_seq_off = nullptr;
@@ -534,7 +535,7 @@ int fem_dev_close(fem_dev *h) {
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_nonempty, (void *)h->d_plane[0], (void *)h->d_plane[1],
-                  (void *)h->d_plane[2]})
+                  (void *)h->d_plane[2], (void *)h->d_plane[3]})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -576,13 +577,13 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     total += seq_len[i];
   }
   for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_plane[0],
-                  (void *)h->d_plane[1], (void *)h->d_plane[2]})
+                  (void *)h->d_plane[1], (void *)h->d_plane[2], (void *)h->d_plane[3]})
     if (p) (void)hipFree(p);
   h->d_ref = nullptr, h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
-  h->d_plane[0] = h->d_plane[1] = h->d_plane[2] = nullptr;
+  h->d_plane[0] = h->d_plane[1] = h->d_plane[2] = h->d_plane[3] = nullptr;
   // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
   HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 128));
-  HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 64));
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 128));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_off, n_seq * sizeof(uint64_t)));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_len, n_seq * sizeof(uint32_t)));
   HIP_TRY(h, hipMemset(h->d_ref + total, 4, 128));
@@ -591,7 +592,7 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
   HIP_TRY(h, hipMemcpy(h->d_seq_off, h->seq_off.data(), n_seq * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_len, h->seq_len.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_ref_raw, h->d_ref, total, hipMemcpyDeviceToDevice));
-  HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 64));
+  HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 128));
   if (total) {
     hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, total);
     HIP_TRY(h, hipGetLastError());
@@ -599,12 +600,12 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
   }
   {  // bit planes of the codes, 64 bases of slack (code 4) included
     const uint64_t n_pb = (total + 64 + 7) / 8;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 4; ++q) {
       HIP_TRY(h, hipMalloc((void **)&h->d_plane[q], n_pb + 16));
       HIP_TRY(h, hipMemset(h->d_plane[q], 0, n_pb + 16));
     }
-    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, n_pb, h->d_plane[0],
-                       h->d_plane[1], h->d_plane[2]);
+    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, h->d_ref_raw, n_pb,
+                       h->d_plane[0], h->d_plane[1], h->d_plane[2], h->d_plane[3]);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipDeviceSynchronize());
   }
@@ -805,6 +806,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   femt::TailInput in{};
   in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
+  for (int q = 0; q < 4; ++q) in.plane[q] = h->d_plane[q];
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
   femt::TailOutput t{};

@@ -1199,18 +1199,23 @@ __global__ void __launch_bounds__(256) count_mappings_kernel(CountParams p) {
   }
 }
 
-// bit q of code(text[i]) -> bit i of plane q; one thread per byte of the planes (eight bases)
-__global__ void ref_planes_kernel(const uint8_t *codes, uint64_t n_bytes, uint8_t *p0, uint8_t *p1, uint8_t *p2) {
+// bit q of code(text[i]) -> bit i of plane q (q = 0..2); plane 3: the character as uploaded is none of "ACGTN" (lower
+// case, IUPAC codes: it then equals no read character the device traceback compares it with).  One thread per byte of
+// the planes (eight bases).
+__global__ void ref_planes_kernel(const uint8_t *codes, const uint8_t *raw, uint64_t n_bytes, uint8_t *p0, uint8_t *p1,
+                                  uint8_t *p2, uint8_t *p3) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += stride) {
-    uint64_t w;
+    uint64_t w, r;
     __builtin_memcpy(&w, codes + 8 * b, 8);
-    uint32_t o0 = 0, o1 = 0, o2 = 0;
+    __builtin_memcpy(&r, raw + 8 * b, 8);
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
     for (int k = 0; k < 8; ++k) {
-      const uint32_t c = (uint32_t)(w >> (8 * k)) & 0xFFu;
+      const uint32_t c = (uint32_t)(w >> (8 * k)) & 0xFFu, ch = (uint32_t)(r >> (8 * k)) & 0xFFu;
       o0 |= (c & 1u) << k, o1 |= ((c >> 1) & 1u) << k, o2 |= ((c >> 2) & 1u) << k;
+      o3 |= (uint32_t)(ch != ((0x4E54474341ull >> (8u * c)) & 0xFFu)) << k;  // "ACGTN"[code]
     }
-    p0[b] = (uint8_t)o0, p1[b] = (uint8_t)o1, p2[b] = (uint8_t)o2;
+    p0[b] = (uint8_t)o0, p1[b] = (uint8_t)o1, p2[b] = (uint8_t)o2, p3[b] = (uint8_t)o3;
   }
 }
 

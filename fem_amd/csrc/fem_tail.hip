@@ -35,6 +35,7 @@ struct Params {
   uint32_t n_reads;
   const uint8_t *ref_raw;
   uint64_t ref_bytes;
+  const uint8_t *plane[4];
   const uint64_t *seq_off;
   const uint64_t *cand;
   const uint8_t *ed;
@@ -261,6 +262,27 @@ __device__ __forceinline__ uint32_t complement4(uint32_t chars) {
   const uint32_t nflag = ((((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) >> 7) & 0x01010101u;
   return __builtin_amdgcn_perm(0x4E4E4E4Eu /* "NNNN" */, 0x54474341u, (code ^ 0x03030303u) | (nflag << 2));
 }
+
+// four characters at once (SWAR): code per byte 0..3 (0 where the base is not A/C/G/T), complemented on the reverse
+// strand; nflag per byte 0/1 (not A/C/G/T in either case, src/utils.h:72); odd = 0x80 in the bytes that are none of "ACGTN"
+__device__ __forceinline__ void decode4(uint32_t chars, uint32_t complement, uint32_t &code, uint32_t &nflag, uint32_t &odd) {
+  const uint32_t t = (chars >> 1) & 0x03030303u;
+  const uint32_t c = t ^ ((t >> 1) & 0x01010101u);
+  const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, c);
+  const uint32_t z = (chars & 0xDFDFDFDFu) ^ expect;
+  nflag = ((((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) >> 7) & 0x01010101u;
+  code = (c ^ complement) & ~(nflag * 3u);
+  const uint32_t ze = chars ^ expect, zn = chars ^ 0x4E4E4E4Eu;
+  odd = (((ze & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ze) & (((zn & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zn) & 0x80808080u;
+}
+// 32 bits of a 128-bit little-endian bit string starting at bit `at` (at <= 96)
+__device__ __forceinline__ uint32_t bits_at(const uint4 &w, uint32_t at) {
+  const uint32_t k = at >> 5;
+  const uint32_t lo = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
+  const uint32_t hi = k == 0 ? w.y : k == 1 ? w.z : w.w;
+  return __builtin_amdgcn_alignbit(hi, lo, at & 31u);
+}
+constexpr int kStepsPerPlaneLoad = 6;  // 7 (bit offset) + 16 * 5 + 16 + 2 * 7 (band) bits <= 128
 
 struct LaneView {
   const uint32_t *text, *pat;
@@ -525,14 +547,6 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
 // a read with such characters is left to the general kernel.  So is every walk that leaves the band, and every
 // record whose CIGAR or MD outgrows the staging; the general kernel (trace_kernel) redoes those from scratch.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t canonical_char(uint32_t code) {  // "ACGTN"[code]
-  return (uint32_t)(0x4E54474341ull >> (8u * code)) & 0xFFu;
-}
-__device__ __forceinline__ uint32_t byte_of(const uint4 &w, int q) {  // q is a compile-time constant after unrolling
-  const uint32_t x = q < 4 ? w.x : q < 8 ? w.y : q < 12 ? w.z : w.w;
-  return (x >> (8 * (q & 3))) & 0xFFu;
-}
-
 // The packed column word (3 x (2e+1) bits) is kept in as few LDS bytes as hold it — LDS per block is what limits the
 // waves per CU here, and the walk is a chain of dependent LDS reads that only more waves can hide: a low plane of
 // P0 words and, where needed, a high plane of P1 words; column c of lane l sits at [c * lanes + l] of each.
@@ -584,61 +598,77 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
     bool punt = start < 0 || start > sh;  // (never: end lies in [L-1, L-1+2e])
 
     // ---- the recurrence (src/align.c:303-338), one packed word per column ----
-    uint32_t B0 = 0, B1 = 0, B2 = 0, BW = 0;  // pattern window: three code bit planes + "not canonical"
-    for (int j = 0; j < sh; ++j) {
-      const uint32_t ch = pattern[j], pc = base_code(ch);
-      B0 |= (pc & 1u) << j, B1 |= ((pc >> 1) & 1u) << j, B2 |= ((pc >> 2) & 1u) << j;
-      BW |= (uint32_t)(ch != canonical_char(pc)) << j;
+    // Sixteen columns per step.  Reference side: bit planes of the base codes plus the "none of ACGTN" plane; one
+    // unaligned 16-byte load per plane covers the windows pattern[col .. col + 16 + 2e) of six steps.  Read side: 16
+    // characters per load, decoded four at a time; on the reverse strand the chunk comes from the read's far end,
+    // byte-reversed and complemented (src/sequence_batch.h:90-98; the batch's characters have 16 bytes of padding
+    // in front).  Loads are issued one step (text) / one stretch (planes) ahead of their use.
+    const uint32_t complement = dir ? 0x03030303u : 0u;
+    auto text_chunk = [&](int c) { return load_u128_unaligned(dir == 0 ? fwd + c : fwd + (L - 16 - c)); };
+    auto plane_chunk = [&](int q, int c) { return load_u128_unaligned(p.plane[q] + ((pat_abs + (uint32_t)c) >> 3)); };
+    const uint32_t pat_bit = (uint32_t)pat_abs & 7u;
+    const int n_steps = (L + 15) >> 4;
+    uint32_t vp = 0, vn = 0, ident = 1u, odd_text = 0;
+    uint4 rw = make_uint4(0, 0, 0, 0), W0 = rw, W1 = rw, W2 = rw, W3 = rw, W0n = rw, W1n = rw, W2n = rw, W3n = rw;
+    if (n_steps > 0) {
+      rw = text_chunk(0);
+      W0n = plane_chunk(0, 0), W1n = plane_chunk(1, 0), W2n = plane_chunk(2, 0), W3n = plane_chunk(3, 0);
     }
-    uint32_t vp = 0, vn = 0, ident = 1u;
-    // sixteen columns per pair of 16-byte loads; the next pair is requested before this one is used.
-    // pattern[c + 2e ..] has 64 bytes of slack behind the reference; a read chunk may run past the read (those
-    // columns are not walked).  On the reverse strand column c + q reads complement(fwd[L - 1 - c - q])
-    // (src/sequence_batch.h:90-98): the chunk is fetched from the read's far end and byte-reversed.
-    if (dir != 0 && (int64_t)off + L - 16 * ((L + 15) / 16) < 0) punt = true;  // would start in front of the batch's first read
-    auto text_chunk = [&](int c) -> uint4 {
-      return load_u128_unaligned(dir == 0 ? fwd + c : p.bases + ((int64_t)off + L - 16 - c));
+    auto column = [&](uint32_t col, uint32_t q, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t bw, uint32_t m0, uint32_t m1,
+                      uint32_t m2) {
+      const uint32_t eq = __builtin_amdgcn_ubfe(~((b0 ^ m0) | (b1 ^ m1) | (b2 ^ m2)), q, (uint32_t)W);  // Peq[text[col]]
+      uint32_t x = eq | vn;
+      const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+      const uint32_t hn = vp & d0;
+      const uint32_t hp = vn | ~(vp | d0);
+      x = d0 >> 1;
+      vn = x & hp;
+      vp = hn | ~(x | hp);
+      const uint32_t same = eq & ~__builtin_amdgcn_ubfe(bw, q, (uint32_t)W);  // the characters themselves are equal
+      ident &= same >> start;
+      hist.put(col + q, (HistT)(d0 & band) | ((HistT)(hp & band) << W) | ((HistT)same << (2 * W)));
     };
-    uint4 pw_next = make_uint4(0, 0, 0, 0), tw_next = make_uint4(0, 0, 0, 0);
-    if (!punt && L > 0) pw_next = load_u128_unaligned(pattern + sh), tw_next = text_chunk(0);
-    for (int c = 0; c < L && !punt; c += 16) {
-      const uint4 pw = pw_next, r = tw_next;
-      if (c + 16 < L) pw_next = load_u128_unaligned(pattern + sh + c + 16), tw_next = text_chunk(c + 16);
-      const uint4 tw = dir == 0 ? r
-                                : make_uint4(__builtin_bswap32(r.w), __builtin_bswap32(r.z), __builtin_bswap32(r.y),
-                                             __builtin_bswap32(r.x));
-      // all sixteen columns are computed; those past the read only write history nobody looks at
-      // (LDS holds max_len rounded up to 16 columns) and are kept out of `ident`
-      const uint32_t live = L - c >= 16 ? 0xFFFFu : (1u << (L - c)) - 1u;
+    for (int step = 0; step < n_steps; ++step) {
+      const int col = step << 4, sub = step % kStepsPerPlaneLoad;
+      const uint4 r = rw;
+      if (sub == 0) {
+        W0 = W0n, W1 = W1n, W2 = W2n, W3 = W3n;
+        if (step + kStepsPerPlaneLoad < n_steps) {
+          const int nc = col + 16 * kStepsPerPlaneLoad;
+          W0n = plane_chunk(0, nc), W1n = plane_chunk(1, nc), W2n = plane_chunk(2, nc), W3n = plane_chunk(3, nc);
+        }
+      }
+      if (step + 1 < n_steps) rw = text_chunk(col + 16);
+      const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat_abs + 96 k) & 7 == pat_abs & 7
+      const uint32_t b0 = bits_at(W0, wbit), b1 = bits_at(W1, wbit), b2 = bits_at(W2, wbit), bw = bits_at(W3, wbit);
+      const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
+                             dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
+      const int ncol = L - col < 16 ? L - col : 16;
+      uint32_t cw[4], nw[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        {
-          const uint32_t pch = byte_of(pw, q), tch = byte_of(tw, q);
-          const uint32_t pc = base_code(pch);
-          uint32_t tc = base_code(tch);
-          if (dir == 0)
-            punt |= tch != canonical_char(tc);
-          else
-            tc = tc < 4u ? 3u - tc : 4u;
-          B0 |= (pc & 1u) << sh, B1 |= ((pc >> 1) & 1u) << sh, B2 |= ((pc >> 2) & 1u) << sh;
-          BW |= (uint32_t)(pch != canonical_char(pc)) << sh;
-          const uint32_t m0 = 0u - (tc & 1u), m1 = 0u - ((tc >> 1) & 1u), m2 = 0u - ((tc >> 2) & 1u);
-          const uint32_t eq = ~((B0 ^ m0) | (B1 ^ m1) | (B2 ^ m2)) & band;  // Peq[text[col]]
-          uint32_t x = eq | vn;
-          const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
-          const uint32_t hn = vp & d0;
-          const uint32_t hp = vn | ~(vp | d0);
-          x = d0 >> 1;
-          vn = x & hp;
-          vp = hn | ~(x | hp);
-          const uint32_t same = eq & ~BW;  // the characters themselves are equal
-          ident &= (same >> start) | (~live >> q);
-          if ((live >> q) & 1u)
-            hist.put((uint32_t)(c + q), (HistT)(d0 & band) | ((HistT)(hp & band) << W) | ((HistT)same << (2 * W)));
-          B0 >>= 1, B1 >>= 1, B2 >>= 1, BW >>= 1;
+      for (int k = 0; k < 4; ++k) {
+        uint32_t odd;
+        decode4(w[k], complement, cw[k], nw[k], odd);
+        const int nb = ncol - 4 * k;  // characters of this word that belong to the read
+        odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
+      }
+      if (ncol == 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          column((uint32_t)col, (uint32_t)q, b0, b1, b2, bw, (uint32_t)__builtin_amdgcn_sbfe((int)cw[q >> 2], 8 * (q & 3), 1),
+                 (uint32_t)__builtin_amdgcn_sbfe((int)cw[q >> 2], 8 * (q & 3) + 1, 1),
+                 (uint32_t)__builtin_amdgcn_sbfe((int)nw[q >> 2], 8 * (q & 3), 1));
+      } else {  // up to fifteen trailing columns
+        const uint64_t clo = ((uint64_t)cw[1] << 32) | cw[0], chi = ((uint64_t)cw[3] << 32) | cw[2];
+        const uint64_t nlo = ((uint64_t)nw[1] << 32) | nw[0], nhi = ((uint64_t)nw[3] << 32) | nw[2];
+        for (int q = 0; q < ncol; ++q) {
+          const uint32_t cb = (uint32_t)((q < 8 ? clo : chi) >> (8 * (q & 7)));
+          const uint32_t nb = (uint32_t)((q < 8 ? nlo : nhi) >> (8 * (q & 7)));
+          column((uint32_t)col, (uint32_t)q, b0, b1, b2, bw, 0u - (cb & 1u), 0u - ((cb >> 1) & 1u), 0u - (nb & 1u));
         }
       }
     }
+    if (dir == 0 && odd_text) punt = true;  // a read character outside "ACGTN": character equality is not code equality
 
     uint32_t n_ops = 0, n_md = 0;
     uint8_t *md = p.t_md + (size_t)rec * p.md_cap;
@@ -670,33 +700,16 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       push_number((uint32_t)L);
     } else if (!punt) {
       // ---- walk back (src/align.c:340-440); pe == t + bit throughout ----
-      enum Move { MATCH, MISMATCH, INSERT, DELETE };
       int bit = start, t = L - 1, n_err = 0;
-      auto classify = [&]() -> Move {
-        const HistT h = hist.get((uint32_t)t) >> bit;
-        const bool d = (uint32_t)h & 1u;
-        if (d && ((uint32_t)(h >> (2 * W)) & 1u)) return MATCH;
-        if (!d) return MISMATCH;
-        if ((uint32_t)(h >> W) & 1u) return INSERT;
-        return DELETE;
-      };
       uint32_t cur_op = kOpS, cur_n = 1;
-      switch (classify()) {
-        case MATCH: --t, cur_op = kOpM; break;
-        case MISMATCH: --t, ++n_err; break;
-        case INSERT: --t, ++bit, ++n_err, ++start; break;
-        case DELETE: broken = true; break;
+      {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
+        const HistT h = hist.get((uint32_t)t) >> bit;
+        const bool d = (uint32_t)h & 1u, same = (uint32_t)(h >> (2 * W)) & 1u, horiz = (uint32_t)(h >> W) & 1u;
+        if (d && same) --t, cur_op = kOpM;
+        else if (!d) --t, ++n_err;
+        else if (horiz) --t, ++bit, ++n_err, ++start;
+        else broken = true;  // assert(1 == 0)
       }
-      auto extend = [&](uint32_t op) {
-        if (cur_op == op) {
-          ++cur_n;
-        } else if (cur_op == kOpS) {
-          cur_op = op, cur_n += 1;
-        } else {
-          push_op(cur_op, cur_n);
-          cur_op = op, cur_n = 1;
-        }
-      };
       while (!broken && !punt && t >= 0 && n_err != ed) {
         if (bit < 0) {  // the reference's own guard; above the band it would read bits this pass does not keep
           broken = true;
@@ -706,17 +719,22 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
           punt = true;
           break;
         }
-        switch (classify()) {
-          case MATCH: --t, extend(kOpM); break;
-          case MISMATCH:
-            --t, ++n_err;
-            if (cur_op == kOpS) ++cur_n; else extend(kOpM);
-            break;
-          case INSERT:
-            --t, ++bit, ++n_err, ++start;
-            if (cur_op == kOpS) ++cur_n; else extend(kOpI);
-            break;
-          case DELETE: --bit, ++n_err, --start, extend(kOpD); break;
+        const HistT h = hist.get((uint32_t)t) >> bit;
+        const bool d = (uint32_t)h & 1u, same = (uint32_t)(h >> (2 * W)) & 1u, horiz = (uint32_t)(h >> W) & 1u;
+        const bool is_match = d && same, is_ins = d && !same && horiz, is_del = d && !same && !horiz;  // else: mismatch
+        const uint32_t op = is_del ? kOpD : is_ins ? kOpI : kOpM;
+        const bool absorbed = cur_op == kOpS && !is_match && !is_del;  // read-end errors pile up in the pseudo-run
+        t -= (int)!is_del;
+        bit += (int)is_ins - (int)is_del;
+        start += (int)is_ins - (int)is_del;
+        n_err += (int)!is_match;
+        if (absorbed || op == cur_op) {
+          ++cur_n;
+        } else if (cur_op == kOpS) {
+          cur_op = op, cur_n += 1;  // S(n) followed by op(1) ends up as op(1 + n)
+        } else {
+          push_op(cur_op, cur_n);
+          cur_op = op, cur_n = 1;
         }
       }
       if (!broken && !punt) {
@@ -942,6 +960,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   Params p{};
   p.bases = in.bases, p.read_off = in.read_off, p.n_reads = n;
   p.ref_raw = in.ref_raw, p.ref_bytes = in.ref_bytes, p.seq_off = in.seq_off;
+  for (int q = 0; q < 4; ++q) p.plane[q] = in.plane[q];
   p.cand = in.cand, p.ed = in.ed, p.end = in.end, p.cand_begin = in.cand_begin, p.cand_count = in.cand_count;
   p.e = in.e, p.n_records = nr;
   p.rec_begin = m.rec_begin.as<uint32_t>();
