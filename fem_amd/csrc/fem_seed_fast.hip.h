@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   unsigned long long pre_sum = 0, cand_sum = 0;
   SlotChunk chunk;   // candidate slots
   SlotChunk qchunk;  // slow-read queue entries
-  Prof prof;
+  [[maybe_unused]] Prof prof;
 
   const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t n_waves = gridDim.x * waves_per_block;

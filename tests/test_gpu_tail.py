@@ -109,3 +109,32 @@ def test_empty_and_unmapped(dev):
     want, got = run_both(dev, seqs, reads, e=3)
     assert_same_records(want, got)
     assert got.n_records == 0
+
+
+def test_device_tail_equals_host_tail_at_scale(dev):
+    # 300 k reads of the bench workload's shape (C2-like: 5 Mbp, 100 bp, e=3): too many for the oracle's traceback in
+    # a test, so the device records are compared with libfemhost's mapping tail — a second, independent
+    # implementation that the CPU suite pins against the oracle (tests/test_host.py)
+    from fem_amd import host
+    n = 300_000
+    text, off, lens = host.synth_reference(2, [5_000_000], threads=8)
+    bases, offs = host.synth_reads(2, text, off, lens, n, 100, 3, threads=8)
+    dev.upload_reference([text[:5_000_000]])
+    dev.build_index(12, 3, fetch=False)
+    dev.stage_reads(bases, offs)
+    dev.map_staged(e=3)
+    res = dev.fetch()
+    got = dev.fetch_records()
+    tref = host.TailReference(text, off, lens)
+    want = host.tail_records(3, tref, bases, offs, res.cand_begin, res.cand_count, res.cand, res.ed, res.end, threads=8)
+    assert got.n_records == int(res.stats[4]) and got.n_records > 200_000
+    assert np.array_equal(got.rec_begin, want.rec_off)
+    assert np.array_equal(got.flag, want.flag) and np.array_equal(got.tid, want.tid)
+    assert np.array_equal(got.pos0, want.pos0) and np.array_equal(got.nm, want.nm)
+    assert np.array_equal(got.cigar_off, want.cigar_off) and np.array_equal(got.cigar, want.cigar)
+    assert np.array_equal(got.md_off, want.md_off) and np.array_equal(got.md, want.md)
+    # size-independent properties: read bases consumed by every CIGAR, NM within the threshold
+    ops, lens_ = got.cigar & 0xF, got.cigar >> 4
+    consumed = np.add.reduceat(np.where(ops != 2, lens_, 0), got.cigar_off[:-1].astype(np.int64))
+    assert np.mean(consumed == 100) > 0.999  # the 'S' fold can move read-end bases into a deletion (src/align.c:466-469)
+    assert got.nm.max() <= 3
