@@ -457,7 +457,7 @@ __device__ int trace_record(const LaneView &v, const uint8_t *pattern, int64_t a
   return start;
 }
 
-template <bool OVERFLOW_PASS>
+// General form of the traceback: redoes the records the first pass queued (p.ovf_queue, p.ctl[1] of them).
 __global__ void __launch_bounds__(64) trace_kernel(Params p) {
   extern __shared__ uint32_t lds[];
   const uint32_t nl = p.lanes, ln = threadIdx.x;
@@ -465,11 +465,11 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
   uint32_t *pat_w = text_w + p.text_words * nl;
   uint32_t *d0_w = pat_w + p.pat_words * nl;
   uint32_t *hp_w = d0_w + p.max_len * nl;
-  const uint32_t n_items = OVERFLOW_PASS ? p.ctl[1] : p.n_records;
+  const uint32_t n_items = p.ctl[1];
   for (uint32_t base = blockIdx.x * nl; base < n_items; base += gridDim.x * nl) {
     const uint32_t item = base + ln;
     if (ln >= nl || item >= n_items) continue;
-    const uint32_t rec = OVERFLOW_PASS ? p.ovf_queue[item] : item;
+    const uint32_t rec = p.ovf_queue[item];
     const uint32_t read = p.s_read[rec], misc = p.s_misc[rec];
     const uint64_t cand = p.s_cand[rec];
     const int end = (int16_t)(misc & 0xFFFFu), ed = (int)((misc >> 16) & 0xFFu);
@@ -517,12 +517,7 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
     st.ops_cap = p.ops_cap, st.md_cap = p.md_cap;
     int start = trace_record(v, pattern, -(int64_t)pat_abs, (int64_t)p.ref_bytes - 1 - (int64_t)pat_abs, L, p.e, ed, end, st);
     if (st.overflow) {
-      if (!OVERFLOW_PASS) {
-        p.ovf_out[atomicAdd(&p.ctl[1], 1u)] = rec;
-        p.n_ops[rec] = 0, p.n_md[rec] = 0;
-        continue;
-      }
-      atomicAdd(&p.ctl[2], 1u);  // cannot happen: the second staging holds the longest possible walk
+      atomicAdd(&p.ctl[2], 1u);  // cannot happen: this staging holds the longest possible walk
       start = -1;
     }
     const uint32_t rank = rec - p.rec_begin[read];
@@ -533,7 +528,7 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
     p.pos0[rec] = (uint32_t)start + (uint32_t)cand;  // src/align.c:80
     p.nm[rec] = (uint8_t)ed;
     p.n_ops[rec] = st.n_ops, p.n_md[rec] = st.n_md;
-    p.src_slot[rec] = OVERFLOW_PASS ? item + 1u : 0u;
+    p.src_slot[rec] = item + 1u;
   }
 }
 
@@ -1011,7 +1006,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
       q.ovf_queue = m.ovf.as<uint32_t>();
       q.t_ops = m.o_ops.as<uint32_t>(), q.t_md = m.o_md.as<uint8_t>(), q.ops_cap = o_ops_cap, q.md_cap = o_md_cap;
       const uint32_t b2 = std::min<uint32_t>((n_overflow + lanes - 1) / lanes, (uint32_t)n_cu * 16u);
-      hipLaunchKernelGGL(trace_kernel<true>, dim3(b2), dim3(64), lds_bytes, stream, q);
+      hipLaunchKernelGGL(trace_kernel, dim3(b2), dim3(64), lds_bytes, stream, q);
       TAIL_TRY(hipGetLastError());
     }
   } else {
