@@ -495,6 +495,88 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t n_waves = gridDim.x * waves_per_block;
 
+  // ---- lists -> candidates -> clip + emit for ONE read whose selected seeds sit in the lanes (lane strand * kSeeds +
+  //      group * R + run).  Returns false if the read has to go to the generic kernel (nothing emitted then). ----
+  auto finish_read = [&](uint32_t read, uint32_t rb, uint32_t L, const bool (&strand_ok)[2], uint32_t s_start, uint32_t s_lo,
+                         uint32_t s_freq, uint32_t s_at, uint32_t total0, uint32_t total1, uint64_t nonempty,
+                         unsigned long long pre_read) -> bool {
+    // candidates of the two strands wait in LDS (over the seed table, which is dead by now) until both are known to
+    // fit: registers are what limits the waves per SIMD
+    uint32_t kept0 = 0, kept1 = 0;
+    bool slow = false;
+    for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
+      // (selects, not array indexing: an array indexed by the loop variable ends up in scratch memory)
+      const bool s_ok = strand ? strand_ok[1] : strand_ok[0];
+      const uint32_t s_total = strand ? total1 : total0;
+      uint32_t kept = 0;
+      if (!s_ok) continue;
+      if (s_total <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
+      const uint32_t lane0 = strand * kSeeds;
+      if (s_total <= (uint32_t)kWave) {
+        uint64_t cv = 0;
+        kept = lists_in_lanes<R>(p, lane0, s_at, s_total, s_start, s_lo, s_freq, list_scratch, scatter, cv);
+        cand_lds[strand * (uint32_t)kWave + ln] = cv;
+      } else if (HASH) {
+        uint32_t group_total[kStep];  // xcap = most occurrences of one group the join takes
+        for (uint32_t g = 0; g < (uint32_t)kStep && !slow; ++g) {
+          uint32_t n_g = 0;
+          for (uint64_t m = (nonempty >> (lane0 + g * (uint32_t)R)) & ((1ull << R) - 1ull); m;) {
+            const int j = __builtin_ctzll(m) + (int)(lane0 + g * (uint32_t)R);
+            m &= m - 1;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+            n_g = f > 0x7fffffffu - n_g ? 0x7fffffffu : n_g + f;
+          }
+          group_total[g] = n_g;
+          slow = n_g > p.lay.xcap;
+        }
+        if (slow) break;
+        uint64_t cv = 0;
+        kept = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cv);
+        cand_lds[strand * (uint32_t)kWave + ln] = cv;
+      }
+      if (kept == 0xFFFFFFFFu) slow = true;
+      if (strand) kept1 = kept; else kept0 = kept;
+    }
+    if (slow) return false;
+    // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
+    pre_sum += pre_read;
+#pragma unroll 1
+    for (uint32_t strand = 0; strand < 2u; ++strand) {
+      const uint32_t kept = strand ? kept1 : kept0;
+      const uint64_t cv = kept ? cand_lds[strand * (uint32_t)kWave + ln] : 0;  // written by this same lane
+      bool ok = false;
+      if (ln < kept) {
+        const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
+        const uint32_t slen = p.seq_len[sq];
+        ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+      }
+      const uint64_t mo = __ballot(ok);
+      const uint32_t n_out = (uint32_t)__popcll(mo);
+      uint32_t base = 0;
+      if (n_out > 0) {
+        if (n_out <= chunk.left) {
+          base = chunk.next;
+          chunk.next += n_out, chunk.left -= n_out;
+        } else {
+          pad_chunk(p, chunk);
+          if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+          base = bcast0(base);
+          chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+        }
+        if ((unsigned long long)base + n_out > p.cand_cap) {
+          if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+        } else if (ok) {
+          const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
+          p.cand[at] = cv - e64;
+          p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
+        }
+      }
+      if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
+      cand_sum += n_out;
+    }
+    return true;
+  };
+
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
@@ -659,44 +741,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     }
 
     STAMP(prof, 3);
-    // ---- per strand: lists -> candidates (sorted, before the range clip) in lanes 0..kept-1 of cv ----
-    // candidates of the two strands wait in LDS (over the seed table, which is dead by now) until both are known to
-    // fit: registers are what limits the waves per SIMD
-    uint32_t kept0 = 0, kept1 = 0;
-    for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
-      // (selects, not array indexing: an array indexed by the loop variable ends up in scratch memory)
-      const bool s_ok = strand ? strand_ok[1] : strand_ok[0];
-      const uint32_t s_total = strand ? strand_total[1] : strand_total[0];
-      uint32_t kept = 0;
-      if (!s_ok) continue;
-      if (s_total <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
-      const uint32_t lane0 = strand * kSeeds;
-      if (s_total <= (uint32_t)kWave) {
-        uint64_t cv = 0;
-        kept = lists_in_lanes<R>(p, lane0, s_at, s_total, s_start, s_lo, s_freq, list_scratch, scatter, cv);
-        cand_lds[strand * (uint32_t)kWave + ln] = cv;
-      } else if (HASH) {
-        uint32_t group_total[kStep];  // xcap = most occurrences of one group the join takes
-        for (uint32_t g = 0; g < (uint32_t)kStep && !slow; ++g) {
-          uint32_t n_g = 0;
-          for (uint64_t m = (nonempty >> (lane0 + g * (uint32_t)R)) & ((1ull << R) - 1ull); m;) {
-            const int j = __builtin_ctzll(m) + (int)(lane0 + g * (uint32_t)R);
-            m &= m - 1;
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-            n_g = f > 0x7fffffffu - n_g ? 0x7fffffffu : n_g + f;
-          }
-          group_total[g] = n_g;
-          slow = n_g > p.lay.xcap;
-        }
-        if (slow) break;
-        uint64_t cv = 0;
-        kept = lists_bloom_join<R>(p, lane0, group_total, s_start, s_lo, s_freq, scatter, bloom, cv);
-        cand_lds[strand * (uint32_t)kWave + ln] = cv;
-      }
-      if (kept == 0xFFFFFFFFu) slow = true;
-      if (strand) kept1 = kept; else kept0 = kept;
-    }
-
+    if (!slow) slow = !finish_read(read, rb, L, strand_ok, s_start, s_lo, s_freq, s_at, strand_total[0], strand_total[1], nonempty, pre_read);
     if (slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
       if (qchunk.left == 0) {
         uint32_t base = 0;
@@ -711,47 +756,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       }
       ++qchunk.next, --qchunk.left;
       continue;
-    }
-
-    STAMP(prof, 4);
-#if defined(FEM_ABLATE) && FEM_ABLATE == 4
-    continue;
-#endif
-    // ---- remove_out_ranged_candidates (src/filter.c:133-144) + hand-over to the verify kernel ----
-    pre_sum += pre_read;
-#pragma unroll 1
-    for (uint32_t strand = 0; strand < 2u; ++strand) {
-      const uint32_t kept = strand ? kept1 : kept0;
-      const uint64_t cv = kept ? cand_lds[strand * (uint32_t)kWave + ln] : 0;  // written by this same lane
-      bool ok = false;
-      if (ln < kept) {
-        const uint32_t sq = (uint32_t)(cv >> 32), pos = (uint32_t)cv;
-        const uint32_t slen = p.seq_len[sq];
-        ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
-      }
-      const uint64_t mo = __ballot(ok);
-      const uint32_t n_out = (uint32_t)__popcll(mo);
-      uint32_t base = 0;
-      if (n_out > 0) {
-        if (n_out <= chunk.left) {
-          base = chunk.next;
-          chunk.next += n_out, chunk.left -= n_out;
-        } else {
-          pad_chunk(p, chunk);
-          if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
-          base = bcast0(base);
-          chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
-        }
-        if ((unsigned long long)base + n_out > p.cand_cap) {
-          if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
-        } else if (ok) {
-          const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
-          p.cand[at] = cv - e64;
-          p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
-        }
-      }
-      if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
-      cand_sum += n_out;
     }
     STAMP(prof, 5);
   }
