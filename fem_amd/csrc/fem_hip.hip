@@ -209,11 +209,16 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 8u));  // reused for the strands' candidates once the seeds are selected
   l.dp_bits = take(n_groups * R * 8u);
   l.X = take(64u * 8u);  // scatter
-  l.A = take(femk::kListScratchBytes);  // lists_in_lanes
-  l.B = take(64u * 8u);                 // the block's begin/count entries
+  // lists_in_lanes' scratch; flush_small lays its own over [sf, dp_bits, X, A], which has to be long enough for it
+  {
+    const uint32_t so_far = o - l.sf;
+    l.A = take(std::max(femk::kListScratchBytes, femk::kFlushScratchBytes > so_far ? femk::kFlushScratchBytes - so_far : 0u));
+  }
+  l.B = take(2u * femk::kReadBlock * 8u);  // the block's begin/count entries
+  if (!hash) l.F = take(femk::kQueueBytes);  // queue of small reads' seeds
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
-  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 48u : 0u;
+  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 32u : 0u;
   l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;

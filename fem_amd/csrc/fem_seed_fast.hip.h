@@ -19,6 +19,15 @@ constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
 constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
 constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast kernel did not handle
+// Small reads (lean form): a read whose strands select at most kSmallStrand occurrences each is not finished on its own
+// — its non-empty seeds wait in an LDS queue and a whole batch of reads is finished in one pass over the lanes
+// (flush_small).  Queue entry: lookup[h] and start | frequency << 10 | tag << 17, tag = read-in-block << 7 | strand << 6 |
+// group << 4 | run.
+constexpr uint32_t kSmallStrand = 16, kQueueSeeds = 64;
+constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u;  // seeds + the reads' lengths
+// LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
+constexpr uint32_t kFlEv = 0, kFlSv = 512, kFlMax = 1056, kFlFirst = 1568, kFlNval = 1824, kFlLen = 2080, kFlLast = 2336,
+                   kFlSlotN = 2592, kFlSlotFirst = 2720, kFlSlotLast = 2848, kFlushScratchBytes = 2976;
 
 // char -> 2-bit code for four bases at once.  code: per byte 0..3; nflag: per byte 1 where the base is not
 // A/C/G/T in either case (src/utils.h:72).
@@ -458,11 +467,12 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
   return pre_mine;
 }
 
-// Register budget (measured): the lean form (lists in lanes only) is bound by instruction issue and gains from every
-// extra wave per SIMD up to seven (72 VGPRs, a few cold values spilled; eight loses).  The hash-join form wants
-// ~120-150 registers: with few seeds per group five waves (96 VGPRs) beat four, its LDS allows no more; with many
-// seeds per group the spills cost more than the fifth wave brings.
-constexpr int lean_waves(int R, bool hash) { return hash ? (R <= 6 ? 5 : 1) : R <= 6 ? 7 : 6; }
+// Register budget (measured): the lean form is bound by instruction issue and gains from every extra wave per SIMD as
+// long as nothing hot is spilled: six waves (80 VGPRs) with the batched small-read path, whose flush needs more live
+// values than the rest (seven waves spill into the read loop and lose 20 %).  The hash-join form wants ~120-150
+// registers: with few seeds per group five waves (96 VGPRs) beat four, its LDS allows no more; with many seeds per
+// group the spills cost more than the fifth wave brings.
+constexpr int lean_waves(int R, bool hash) { return hash ? (R <= 6 ? 5 : 1) : 6; }
 
 template <int R, bool HASH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_waves(R, HASH), 8))) seed_fast_kernel(SeedParams p) {
@@ -497,7 +507,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 
   // ---- lists -> candidates -> clip + emit for ONE read whose selected seeds sit in the lanes (lane strand * kSeeds +
   //      group * R + run).  Returns false if the read has to go to the generic kernel (nothing emitted then). ----
-  auto finish_read = [&](uint32_t read, uint32_t rb, uint32_t L, const bool (&strand_ok)[2], uint32_t s_start, uint32_t s_lo,
+  auto finish_read = [&](uint32_t read, uint32_t rb, uint32_t L, bool ok0, bool ok1, uint32_t s_start, uint32_t s_lo,
                          uint32_t s_freq, uint32_t s_at, uint32_t total0, uint32_t total1, uint64_t nonempty,
                          unsigned long long pre_read) -> bool {
     // candidates of the two strands wait in LDS (over the seed table, which is dead by now) until both are known to
@@ -506,7 +516,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     bool slow = false;
     for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
       // (selects, not array indexing: an array indexed by the loop variable ends up in scratch memory)
-      const bool s_ok = strand ? strand_ok[1] : strand_ok[0];
+      const bool s_ok = strand ? ok1 : ok0;
       const uint32_t s_total = strand ? total1 : total0;
       uint32_t kept = 0;
       if (!s_ok) continue;
@@ -577,6 +587,135 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     return true;
   };
 
+  // ---- small-read batch (lean form only) ----
+  uint32_t *q_lo = (uint32_t *)(wbase + p.lay.F), *q_info = q_lo + kQueueSeeds, *q_len = q_info + kQueueSeeds;
+  uint8_t *fl = wbase + p.lay.sf;
+  uint32_t q_seeds = 0, q_entries = 0, q_flushed = 0;  // seeds / occurrences queued; seeds the last flush took
+  // Finishes every queued read at once: one occurrence per lane over all of them, segments = (read, strand, group).
+  // Same steps as lists_in_lanes, per segment.  A (read, strand) whose survivors lie in one group and within e of
+  // the first gets that first value as its only candidate (what the staged greedy merge of src/filter.c:45-78 leaves);
+  // anything else marks its read "complex": returned as a bit mask, the caller replays those reads one by one.
+  auto flush_small = [&](uint32_t r0) -> uint32_t {
+    if (q_seeds == 0) return 0u;
+    uint64_t *ev = (uint64_t *)(fl + kFlEv), *sv = (uint64_t *)(fl + kFlSv);
+    unsigned long long *gmax = (unsigned long long *)(fl + kFlMax);
+    uint32_t *own = (uint32_t *)(fl + kFlFirst), *firstp = own, *nval = (uint32_t *)(fl + kFlNval);
+    uint32_t *slen = (uint32_t *)(fl + kFlLen), *lastp = (uint32_t *)(fl + kFlLast);
+    uint32_t *slot_n = (uint32_t *)(fl + kFlSlotN), *slot_first = (uint32_t *)(fl + kFlSlotFirst);
+    uint32_t *slot_last = (uint32_t *)(fl + kFlSlotLast);
+    const uint32_t n_seeds = q_seeds, total = q_entries;
+    q_flushed = n_seeds;
+    q_seeds = 0, q_entries = 0;
+    uint32_t lo = 0, info = 0, f = 0;
+    if (ln < n_seeds) lo = q_lo[ln], info = q_info[ln], f = (info >> 10) & 127u;
+    const uint32_t at = wave_scan_add(f) - f;
+    own[ln] = 0, gmax[ln] = 0, nval[ln] = 0, slen[ln] = 0, lastp[ln] = 0;
+    if (ln < 32u) slot_n[ln] = 0;
+    wave_sync_lds();
+    if (ln < n_seeds) own[at] = ln + 1u;
+    wave_sync_lds();
+    const uint32_t owner = wave_scan_max(own[ln]);
+    const bool have = ln < total;
+    const uint32_t src = have ? owner - 1u : 0u;
+    const uint32_t e_at = lane_pull(at, src), e_lo = lane_pull(lo, src), e_info = lane_pull(info, src);
+    const uint32_t e_st = e_info & 1023u, tag = e_info >> 17, run = tag & 15u;
+    const uint32_t seg_tag = have ? tag >> 4 : 0xFFFFu;  // read-in-block << 3 | strand << 2 | group
+    bool valid = false;
+    uint64_t v = ~0ull;  // dropped entries sort behind everything
+    if (have) {
+      const uint64_t o = p.occ[(uint64_t)e_lo + (ln - e_at)];
+      valid = (uint32_t)o >= e_st;  // src/filter.c:89,106
+      if (valid) v = o - e_st;
+    }
+    // segments are runs of equal tags: dense id, first lane
+    const uint32_t prev_tag = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)seg_tag, 0x138, 0xF, 0xF, false);  // wave_shr:1
+    const bool is_start = have && (ln == 0 || prev_tag != seg_tag);
+    const uint32_t seg = have ? wave_scan_add((uint32_t)is_start) - 1u : 63u;
+    const uint32_t seg_start = wave_scan_max(is_start ? ln : 0u);
+    wave_sync_lds();  // own[] is read; its words become firstp[]
+    firstp[ln] = 0xFFFFFFFFu;
+    // last seed of each group: only values <= max of the other runs survive (src/filter.c:85)
+    const bool is_last = run == (uint32_t)(R - 1);
+    if (valid && !is_last) atomicMax(&gmax[seg], (unsigned long long)v + 1ull);
+    if (have) atomicAdd(&slen[seg], 1u);
+    wave_sync_lds();
+    if (valid && is_last) {
+      const unsigned long long mu = gmax[seg];
+      if (mu == 0 || v > mu - 1ull) valid = false, v = ~0ull;
+    }
+    if (valid) atomicAdd(&nval[seg], 1u);
+    ev[ln] = v;
+    wave_sync_lds();
+    const uint32_t my_len = have ? slen[seg] : 0u, my_nval = have ? nval[seg] : 0u;
+    // rank inside the segment by (value, lane)
+    const uint32_t pos = ln - seg_start;
+    uint32_t rank = 0;
+    for (uint32_t s_ = 1; __ballot(s_ < my_len); ++s_) {
+      const bool act = s_ < my_len;
+      uint32_t j = pos + s_;
+      j = (j >= my_len ? j - my_len : j) + seg_start;
+      const uint64_t vj = ev[act ? j : ln];
+      rank += (uint32_t)(act && (vj < v || (vj == v && j < ln)));
+    }
+    wave_sync_lds();
+    if (have) sv[seg_start + rank] = v;
+    wave_sync_lds();
+    // additional_qgram_filter on the sorted order (lane = sorted position): X[i] stays iff X[i+a] <= X[i] + e
+    const bool pass = have && pos + (uint32_t)p.a < my_nval && sv[ln + (uint32_t)p.a] <= sv[ln] + e64;
+    if (pass) atomicMin(&firstp[seg], ln), atomicMax(&lastp[seg], ln);
+    wave_sync_lds();
+    if (is_start && firstp[seg] != 0xFFFFFFFFu) {  // one lane per segment with survivors reports to its (read, strand)
+      const uint32_t slot = seg_tag >> 2;
+      atomicAdd(&slot_n[slot], 1u);
+      slot_first[slot] = firstp[seg], slot_last[slot] = lastp[seg];
+    }
+    wave_sync_lds();
+    // ---- (read, strand) lanes: candidate, clip, emit ----
+    const uint32_t n_grp = ln < 32u ? slot_n[ln] : 0u;
+    uint64_t cv = 0;
+    bool simple = false;
+    if (n_grp == 1u) {
+      cv = sv[slot_first[ln]];
+      simple = sv[slot_last[ln]] <= cv + e64;
+    }
+    const uint32_t cm = (uint32_t)__ballot(n_grp >= 2u || (n_grp == 1u && !simple));  // complex (read, strand) slots
+    const bool read_complex = ln < 32u && ((cm >> (ln & ~1u)) & 3u);
+    bool ok = false;
+    if (n_grp == 1u && simple && !read_complex) {
+      const uint32_t sq = (uint32_t)(cv >> 32), cpos = (uint32_t)cv;
+      const uint32_t slen_ref = p.seq_len[sq], L = q_len[ln >> 1];
+      ok = cpos >= (uint32_t)p.e && cpos + L + (uint32_t)p.e < slen_ref;  // src/filter.c:133-144
+    }
+    const uint64_t mo = __ballot(ok);
+    const uint32_t n_out = (uint32_t)__popcll(mo);
+    if (n_out > 0) {
+      uint32_t base;
+      if (n_out <= chunk.left) {
+        base = chunk.next;
+        chunk.next += n_out, chunk.left -= n_out;
+      } else {
+        pad_chunk(p, chunk);
+        base = 0;
+        if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+        base = bcast0(base);
+        chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+      }
+      if ((unsigned long long)base + n_out > p.cand_cap) {
+        if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+      } else if (ok) {
+        const uint32_t at_ = base + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
+        p.cand[at_] = cv - e64;
+        p.cand_meta[at_] = (r0 + (ln >> 1)) * 2u + (ln & 1u);  // a list of one: never a full group of 8
+        blk_entries[ln] = make_uint2(at_, 1u);
+      }
+      cand_sum += n_out;
+    }
+    // reads with a complex slot, one bit per read of the block
+    uint32_t reads = 0;
+    for (uint32_t m = cm; m; m &= m - 1u) reads |= 1u << ((uint32_t)__builtin_ctz(m) >> 1);
+    return reads;
+  };
+
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
@@ -603,11 +742,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     const uint32_t *w = (const uint32_t *)(blk_chars + (a & ~3u));
     return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
   };
-  for (uint32_t rb = 0; rb < kReadBlock && r0 + rb < p.n_reads; ++rb) {
+  // One extra turn after the block's last read flushes the queue of small reads; flush_small and finish_read are
+  // called from one place each (they are large, and inlined).
+  for (uint32_t rb = 0;; ++rb) {
+    const bool tail_turn = rb >= kReadBlock || r0 + rb >= p.n_reads;
     const uint32_t read = r0 + rb;
+    uint32_t L = 0;
+    bool slow = false, selected = false;  // selected: seeds are in the lanes (or the read is `slow`)
+    bool strand_ok[2] = {true, true};
+    uint32_t pre_g = 0;
+    unsigned long long pre_read = 0;
+    uint32_t s_start = 0, s_lo = 0, s_freq = 0;
+    uint64_t nonempty = 0;
+    uint32_t strand_total[2] = {0, 0}, s_at = 0;
+    if (!tail_turn) do {
     STAMP_START(prof);
     const uint64_t off = p.read_off[read];
-    const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
+    L = (uint32_t)(p.read_off[read + 1] - off);
     const int S = (int)L - kK + 1;  // num_seeds_in_read
 
     // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
@@ -615,17 +766,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
     if (!shape_ok) {
       if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // both entries stay 0
-      continue;
+      break;
     }
     const uint32_t widest = (uint32_t)(S / kStep - R * kLg + 1);  // columns of phase group 0
-    bool slow = widest > (uint32_t)kWave || (uint32_t)S > smax;
-
-    bool strand_ok[2] = {true, true};
-    uint32_t pre_g = 0;
-    unsigned long long pre_read = 0;
-    uint32_t s_start = 0, s_lo = 0, s_freq = 0;
-    uint64_t nonempty = 0;
-    uint32_t strand_total[2] = {0, 0}, s_at = 0;
+    slow = widest > (uint32_t)kWave || (uint32_t)S > smax;
+    selected = true;
     if (!slow) {
       // ---- encode ----
       uint32_t any_n = 0;
@@ -672,7 +817,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       wave_sync_lds();
       STAMP(prof, 0);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 0
-      continue;
+      selected = false;
+      break;
 #endif
 
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
@@ -707,7 +853,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       wave_sync_lds();
       STAMP(prof, 1);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 1
-      continue;
+      selected = false;
+      break;
 #endif
 
       // ---- seed selection ----
@@ -717,7 +864,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       if (ln < 2u * kSeeds && !strand_ok[ln / kSeeds]) s_freq = 0;
       STAMP(prof, 2);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 2
-      continue;
+      selected = false;
+      break;
 #endif
       // "candidates before the filter": uint32 sum of the strand's three M[R][C-1] (src/filter.c:202), widened; added
       // to the counter only once the read is known to stay in this kernel
@@ -740,9 +888,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       }
     }
 
+    } while (false);
     STAMP(prof, 3);
-    if (!slow) slow = !finish_read(read, rb, L, strand_ok, s_start, s_lo, s_freq, s_at, strand_total[0], strand_total[1], nonempty, pre_read);
-    if (slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
+    // small read: its seeds wait in the queue (those of the strands that can pass the filter at all: >= a+1 occurrences)
+    const bool small = !HASH && selected && !slow && strand_total[0] <= kSmallStrand && strand_total[1] <= kSmallStrand;
+    const uint32_t skip0 = strand_total[0] <= (uint32_t)p.a ? 1u : 0u, skip1 = strand_total[1] <= (uint32_t)p.a ? 1u : 0u;
+    const bool mine = small && s_freq > 0 && !(ln < kSeeds ? skip0 : skip1);
+    const uint64_t mm = __ballot(mine);
+    const uint32_t n_push = (uint32_t)__popcll(mm), n_occ = (skip0 ? 0u : strand_total[0]) + (skip1 ? 0u : strand_total[1]);
+    uint32_t replay = 0;  // queued reads flush_small left aside, one bit per read of the block
+    if (!HASH && (tail_turn || (small && (q_seeds + n_push > kQueueSeeds || q_entries + n_occ > (uint32_t)kWave))))
+      replay = flush_small(r0);
+    // reads finished on their own: the replayed ones (their seeds go back into the lanes), then this one if it is not small
+    bool direct = selected && !slow && !small;
+    while (replay || direct) {
+      uint32_t f_read = read, f_rb = rb, f_len = L, f_start = s_start, f_lo = s_lo, f_freq = s_freq, f_at = s_at;
+      uint32_t f_t0 = strand_total[0], f_t1 = strand_total[1];
+      uint64_t f_ne = nonempty;
+      unsigned long long f_pre = pre_read;
+      bool f_ok0 = strand_ok[0], f_ok1 = strand_ok[1];
+      const bool is_replay = replay != 0;
+      if (is_replay) {
+        uint32_t *r_lo = (uint32_t *)(fl + 2048u), *r_info = r_lo + 64;  // behind finish_read's candidate staging
+        f_rb = (uint32_t)__builtin_ctz(replay);
+        replay &= replay - 1u;
+        r_lo[ln] = 0, r_info[ln] = 0;
+        wave_sync_lds();
+        if (ln < q_flushed) {
+          const uint32_t qi = q_info[ln], tag = qi >> 17;
+          if ((tag >> 7) == f_rb) {
+            const uint32_t target = ((tag >> 6) & 1u) * kSeeds + ((tag >> 4) & 3u) * (uint32_t)R + (tag & 15u);
+            r_lo[target] = q_lo[ln], r_info[target] = qi;
+          }
+        }
+        wave_sync_lds();
+        const uint32_t inf = r_info[ln];
+        f_lo = r_lo[ln], f_start = inf & 1023u, f_freq = (inf >> 10) & 127u;
+        wave_sync_lds();
+        const uint32_t incl = wave_scan_add(f_freq);
+        f_t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)kSeeds - 1);
+        f_t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 2 * (int)kSeeds - 1) - f_t0;
+        f_at = incl - f_freq - (ln >= kSeeds ? f_t0 : 0u);
+        f_read = r0 + f_rb, f_len = q_len[f_rb], f_ne = __ballot(f_freq > 0), f_pre = 0;  // (counted when it was queued)
+        f_ok0 = f_ok1 = true;  // strands that were gated out queued no seeds
+      } else {
+        direct = false;
+      }
+      // (a replayed read cannot fail: it holds at most 2 * kSmallStrand occurrences)
+      if (!finish_read(f_read, f_rb, f_len, f_ok0, f_ok1, f_start, f_lo, f_freq, f_at, f_t0, f_t1, f_ne, f_pre) && !is_replay) slow = true;
+    }
+    if (tail_turn) break;
+    if (small) {
+      if (mine) {
+        const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
+        const uint32_t within = ln % kSeeds;
+        const uint32_t tag = (rb << 7) | ((ln / kSeeds) << 6) | ((within / (uint32_t)R) << 4) | (within % (uint32_t)R);
+        q_lo[at_] = s_lo;
+        q_info[at_] = s_start | (s_freq << 10) | (tag << 17);
+      }
+      if (ln == 0) q_len[rb] = L;
+      if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
+      q_seeds += n_push, q_entries += n_occ;
+      pre_sum += pre_read;
+      wave_sync_lds();
+    } else if (selected && slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
       if (qchunk.left == 0) {
         uint32_t base = 0;
         if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
@@ -755,7 +964,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         atomicOr(&p.ctr[1], kFlagQueueOverflow);
       }
       ++qchunk.next, --qchunk.left;
-      continue;
     }
     STAMP(prof, 5);
   }
