@@ -23,8 +23,8 @@ constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast 
 // — its non-empty seeds wait in an LDS queue and a whole batch of reads is finished in one pass over the lanes
 // (flush_small).  Queue entry: lookup[h] and start | frequency << 10 | tag << 17, tag = read-in-block << 7 | strand << 6 |
 // group << 4 | run.
-constexpr uint32_t kSmallStrand = 16, kQueueSeeds = 64;
-constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u;  // seeds + the reads' lengths
+constexpr uint32_t kSmallStrand = 12, kQueueSeeds = 64;
+constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u + kReadBlock * 8u;  // seeds, the reads' lengths and pre-filter counts
 // LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
 constexpr uint32_t kFlEv = 0, kFlSv = 512, kFlMax = 1056, kFlFirst = 1568, kFlNval = 1824, kFlLen = 2080, kFlLast = 2336,
                    kFlSlotN = 2592, kFlSlotFirst = 2720, kFlSlotLast = 2848, kFlushScratchBytes = 2976;
@@ -587,16 +587,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     return true;
   };
 
+  // hands a read to the generic kernel (nothing has been emitted for it)
+  auto queue_slow = [&](uint32_t read) {
+    if (qchunk.left == 0) {
+      uint32_t base = 0;
+      if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
+      qchunk.next = bcast0(base);
+      qchunk.left = kQueueChunk;
+    }
+    if (qchunk.next < p.slow_cap) {
+      if (ln == 0) p.slow_queue[qchunk.next] = read;
+    } else if (ln == 0) {
+      atomicOr(&p.ctr[1], kFlagQueueOverflow);
+    }
+    ++qchunk.next, --qchunk.left;
+  };
+
   // ---- small-read batch (lean form only) ----
   uint32_t *q_lo = (uint32_t *)(wbase + p.lay.F), *q_info = q_lo + kQueueSeeds, *q_len = q_info + kQueueSeeds;
   uint8_t *fl = wbase + p.lay.sf;
-  uint32_t q_seeds = 0, q_entries = 0, q_flushed = 0;  // seeds / occurrences queued; seeds the last flush took
+  unsigned long long *q_pre = (unsigned long long *)(q_len + kReadBlock);
+  uint32_t q_seeds = 0, q_entries = 0;  // seeds / occurrences queued
   // Finishes every queued read at once: one occurrence per lane over all of them, segments = (read, strand, group).
   // Same steps as lists_in_lanes, per segment.  A (read, strand) whose survivors lie in one group and within e of
   // the first gets that first value as its only candidate (what the staged greedy merge of src/filter.c:45-78 leaves);
-  // anything else marks its read "complex": returned as a bit mask, the caller replays those reads one by one.
-  auto flush_small = [&](uint32_t r0) -> uint32_t {
-    if (q_seeds == 0) return 0u;
+  // anything else sends its read to the generic kernel.
+  auto flush_small = [&](uint32_t r0) {
+    if (q_seeds == 0) return;
     uint64_t *ev = (uint64_t *)(fl + kFlEv), *sv = (uint64_t *)(fl + kFlSv);
     unsigned long long *gmax = (unsigned long long *)(fl + kFlMax);
     uint32_t *own = (uint32_t *)(fl + kFlFirst), *firstp = own, *nval = (uint32_t *)(fl + kFlNval);
@@ -604,7 +621,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     uint32_t *slot_n = (uint32_t *)(fl + kFlSlotN), *slot_first = (uint32_t *)(fl + kFlSlotFirst);
     uint32_t *slot_last = (uint32_t *)(fl + kFlSlotLast);
     const uint32_t n_seeds = q_seeds, total = q_entries;
-    q_flushed = n_seeds;
     q_seeds = 0, q_entries = 0;
     uint32_t lo = 0, info = 0, f = 0;
     if (ln < n_seeds) lo = q_lo[ln], info = q_info[ln], f = (info >> 10) & 127u;
@@ -710,10 +726,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       }
       cand_sum += n_out;
     }
-    // reads with a complex slot, one bit per read of the block
-    uint32_t reads = 0;
-    for (uint32_t m = cm; m; m &= m - 1u) reads |= 1u << ((uint32_t)__builtin_ctz(m) >> 1);
-    return reads;
+    // reads with a complex slot go to the generic kernel, which starts them over (rare: survivors in two phase groups,
+    // or further apart than e)
+    for (uint32_t m = cm; m;) {
+      const uint32_t rb_c = (uint32_t)__builtin_ctz(m) >> 1;
+      m &= ~(3u << (2u * rb_c));
+      const unsigned long long pv = q_pre[rb_c];  // the generic kernel counts the read again
+      pre_sum -= ((unsigned long long)bcast0((uint32_t)(pv >> 32)) << 32) | bcast0((uint32_t)pv);
+      if (ln / 2u == rb_c) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+      queue_slow(r0 + rb_c);
+    }
   };
 
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
@@ -746,6 +768,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   // called from one place each (they are large, and inlined).
   for (uint32_t rb = 0;; ++rb) {
     const bool tail_turn = rb >= kReadBlock || r0 + rb >= p.n_reads;
+    // the queue is flushed while no read is in flight: before a read that might not fit any more, and at the block's end
+    if (!HASH && (tail_turn || q_entries > (uint32_t)kWave - 2u * kSmallStrand)) flush_small(r0);
+    if (tail_turn) break;
     const uint32_t read = r0 + rb;
     uint32_t L = 0;
     bool slow = false, selected = false;  // selected: seeds are in the lanes (or the read is `slow`)
@@ -755,7 +780,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     uint32_t s_start = 0, s_lo = 0, s_freq = 0;
     uint64_t nonempty = 0;
     uint32_t strand_total[2] = {0, 0}, s_at = 0;
-    if (!tail_turn) do {
+    do {
     STAMP_START(prof);
     const uint64_t off = p.read_off[read];
     L = (uint32_t)(p.read_off[read + 1] - off);
@@ -896,48 +921,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     const bool mine = small && s_freq > 0 && !(ln < kSeeds ? skip0 : skip1);
     const uint64_t mm = __ballot(mine);
     const uint32_t n_push = (uint32_t)__popcll(mm), n_occ = (skip0 ? 0u : strand_total[0]) + (skip1 ? 0u : strand_total[1]);
-    uint32_t replay = 0;  // queued reads flush_small left aside, one bit per read of the block
-    if (!HASH && (tail_turn || (small && (q_seeds + n_push > kQueueSeeds || q_entries + n_occ > (uint32_t)kWave))))
-      replay = flush_small(r0);
-    // reads finished on their own: the replayed ones (their seeds go back into the lanes), then this one if it is not small
-    bool direct = selected && !slow && !small;
-    while (replay || direct) {
-      uint32_t f_read = read, f_rb = rb, f_len = L, f_start = s_start, f_lo = s_lo, f_freq = s_freq, f_at = s_at;
-      uint32_t f_t0 = strand_total[0], f_t1 = strand_total[1];
-      uint64_t f_ne = nonempty;
-      unsigned long long f_pre = pre_read;
-      bool f_ok0 = strand_ok[0], f_ok1 = strand_ok[1];
-      const bool is_replay = replay != 0;
-      if (is_replay) {
-        uint32_t *r_lo = (uint32_t *)(fl + 2048u), *r_info = r_lo + 64;  // behind finish_read's candidate staging
-        f_rb = (uint32_t)__builtin_ctz(replay);
-        replay &= replay - 1u;
-        r_lo[ln] = 0, r_info[ln] = 0;
-        wave_sync_lds();
-        if (ln < q_flushed) {
-          const uint32_t qi = q_info[ln], tag = qi >> 17;
-          if ((tag >> 7) == f_rb) {
-            const uint32_t target = ((tag >> 6) & 1u) * kSeeds + ((tag >> 4) & 3u) * (uint32_t)R + (tag & 15u);
-            r_lo[target] = q_lo[ln], r_info[target] = qi;
-          }
-        }
-        wave_sync_lds();
-        const uint32_t inf = r_info[ln];
-        f_lo = r_lo[ln], f_start = inf & 1023u, f_freq = (inf >> 10) & 127u;
-        wave_sync_lds();
-        const uint32_t incl = wave_scan_add(f_freq);
-        f_t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)kSeeds - 1);
-        f_t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 2 * (int)kSeeds - 1) - f_t0;
-        f_at = incl - f_freq - (ln >= kSeeds ? f_t0 : 0u);
-        f_read = r0 + f_rb, f_len = q_len[f_rb], f_ne = __ballot(f_freq > 0), f_pre = 0;  // (counted when it was queued)
-        f_ok0 = f_ok1 = true;  // strands that were gated out queued no seeds
-      } else {
-        direct = false;
-      }
-      // (a replayed read cannot fail: it holds at most 2 * kSmallStrand occurrences)
-      if (!finish_read(f_read, f_rb, f_len, f_ok0, f_ok1, f_start, f_lo, f_freq, f_at, f_t0, f_t1, f_ne, f_pre) && !is_replay) slow = true;
-    }
-    if (tail_turn) break;
     if (small) {
       if (mine) {
         const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
@@ -946,24 +929,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         q_lo[at_] = s_lo;
         q_info[at_] = s_start | (s_freq << 10) | (tag << 17);
       }
-      if (ln == 0) q_len[rb] = L;
+      if (ln == 0) q_len[rb] = L, q_pre[rb] = pre_read;
       if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
       q_seeds += n_push, q_entries += n_occ;
       pre_sum += pre_read;
       wave_sync_lds();
-    } else if (selected && slow) {  // hand the whole read to the generic kernel (nothing has been emitted for it)
-      if (qchunk.left == 0) {
-        uint32_t base = 0;
-        if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
-        qchunk.next = bcast0(base);
-        qchunk.left = kQueueChunk;
-      }
-      if (qchunk.next < p.slow_cap) {
-        if (ln == 0) p.slow_queue[qchunk.next] = read;
-      } else if (ln == 0) {
-        atomicOr(&p.ctr[1], kFlagQueueOverflow);
-      }
-      ++qchunk.next, --qchunk.left;
+    } else if (selected) {
+      if (!slow) slow = !finish_read(read, rb, L, strand_ok[0], strand_ok[1], s_start, s_lo, s_freq, s_at, strand_total[0], strand_total[1], nonempty, pre_read);
+      if (slow) queue_slow(read);
     }
     STAMP(prof, 5);
   }
