@@ -89,6 +89,7 @@ struct fem_dev {
   uint64_t n_occ = 0;
   int32_t k = 0, step = 0;
   uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
+  uint32_t *d_multi = nullptr;     // folded filter of the buckets with two or more entries (same condition)
   // reference
   uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
@@ -351,6 +352,7 @@ int launch_batch(fem_dev *h, Slot &s) {
 
   sp.n_seq = h->n_seq;
   sp.nonempty = h->d_nonempty;
+  sp.multi = h->d_multi;
   sp.slow_queue = s.d_slow, sp.slow_cap = s.slow_cap;
   sp.work_queue = nullptr;
   const int R = p.e + 1 + p.a;
@@ -451,14 +453,19 @@ int launch_batch(fem_dev *h, Slot &s) {
 // After the index is resident: for sparse indexes build the bucket non-empty bitmap the fast seed kernel tests first.
 int refresh_nonempty(fem_dev *h) {
   if (h->d_nonempty) (void)hipFree(h->d_nonempty);
-  h->d_nonempty = nullptr;
+  if (h->d_multi) (void)hipFree(h->d_multi);
+  h->d_nonempty = nullptr, h->d_multi = nullptr;
   const uint64_t n_buckets = h->n_lookup - 1;
-  if (h->n_occ >= n_buckets) return FEM_OK;  // dense index: nearly every bucket is non-empty, the test would not pay
-  const uint64_t words = n_buckets / 32 + 2;
+  // dense index: nearly every bucket is non-empty, the tests would not pay.  (Fewer than 2^31 entries also keeps bit
+  // 31 of a lookup value free: the fast seed kernel tags deferred lookups with it.)
+  if (h->n_occ >= n_buckets || h->n_occ >= 0x80000000ull) return FEM_OK;
+  const uint64_t words = n_buckets / 32 + 2, multi_words = ((uint64_t)femk::kMultiMask + 1) / 32;
   HIP_TRY(h, hipMalloc((void **)&h->d_nonempty, words * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_multi, multi_words * sizeof(uint32_t)));
   HIP_TRY(h, hipMemset(h->d_nonempty, 0, words * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemset(h->d_multi, 0, multi_words * sizeof(uint32_t)));
   hipLaunchKernelGGL(femk::nonempty_bitmap_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, n_buckets,
-                     h->d_nonempty);
+                     h->d_nonempty, h->d_multi);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());
   return FEM_OK;
@@ -539,7 +546,7 @@ int fem_dev_close(fem_dev *h) {
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
-                  (void *)h->d_seq_len, (void *)h->d_nonempty, (void *)h->d_plane[0], (void *)h->d_plane[1],
+                  (void *)h->d_seq_len, (void *)h->d_nonempty, (void *)h->d_multi, (void *)h->d_plane[0], (void *)h->d_plane[1],
                   (void *)h->d_plane[2], (void *)h->d_plane[3]})
     if (p) (void)hipFree(p);
   delete h;

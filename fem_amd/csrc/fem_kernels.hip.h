@@ -71,6 +71,11 @@ struct SeedParams {
   // one bit per hash bucket, set iff the bucket is non-empty (2 MiB for k = 12: stays in each XCD's L2).  Sparse
   // indexes only (nullptr otherwise): most of the 2*(L-k+1) lookups per read then never touch the 64 MiB table.
   const uint32_t *nonempty;
+  // Folded filter over the buckets with two or more entries: bit (h & kMultiMask) is set if ANY bucket with that
+  // residue holds >= 2.  A non-empty bucket whose bit is clear has frequency exactly 1 — all the seed-selection DP
+  // needs; lookup[h] is then fetched only for the few such seeds that end up selected.  256 KiB: it stays in L2 next
+  // to the 2 MiB non-empty bitmap (a full second bitmap would not).
+  const uint32_t *multi;
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries
@@ -1219,17 +1224,21 @@ __global__ void ref_planes_kernel(const uint8_t *codes, const uint8_t *raw, uint
   }
 }
 
-// bit h of `bits` = (lookup[h+1] != lookup[h]); one lane per bucket, one ballot per 64 buckets
-__global__ void nonempty_bitmap_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *bits) {
+constexpr uint32_t kMultiMask = (1u << 21) - 1u;  // bits of the folded "two or more entries" filter
+
+// bit h of `bits` = (lookup[h+1] != lookup[h]); one lane per bucket, one ballot per 64 buckets.
+// Buckets with two or more entries also set their bit in the folded filter `multi` (zeroed by the caller).
+__global__ void nonempty_bitmap_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *bits, uint32_t *multi) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t h0 = (uint64_t)blockIdx.x * blockDim.x; h0 < n_buckets; h0 += stride) {
     const uint64_t h = h0 + threadIdx.x;
-    const bool set = h < n_buckets && lookup[h + 1] != lookup[h];
-    const uint64_t m = __ballot(set);
+    const uint32_t f = h < n_buckets ? lookup[h + 1] - lookup[h] : 0u;
+    const uint64_t m = __ballot(f != 0u);
     if ((threadIdx.x & 63u) == 0 && h < n_buckets) {  // h is a multiple of 64 here; the array has two spare words
       bits[h >> 5] = (uint32_t)m;
       bits[(h >> 5) + 1] = (uint32_t)(m >> 32);
     }
+    if (f >= 2u) atomicOr(&multi[((uint32_t)h & kMultiMask) >> 5], 1u << (h & 31u));
   }
 }
 

@@ -17,6 +17,7 @@ namespace femk {
 
 constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
+constexpr uint32_t kDeferredLookup = 0x80000000u;  // a seed table entry holds the seed's hash, not lookup[h] (frequency 1)
 constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
 constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast kernel did not handle
 // Small reads (lean form): a read whose strands select at most kSmallStrand occurrences each is not finished on its own
@@ -847,6 +848,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 #endif
 
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
+      // The DP of phase group si only ever looks at its first G - Lg + 1 seeds, G = (S - si) / step (row r spans columns
+      // c + (r-1) Lg, c < C - 1): seeds behind the last one any group uses are not looked up.
+      int last_used = 0;
+      for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
       for (int j0 = 0; j0 < S; j0 += kWave) {
         const int j = j0 + (int)ln;
         if (j < S) {
@@ -860,17 +865,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
           // (lookup[h], frequency) per seed.  With the non-empty bitmap (sparse index) an empty bucket costs one
           // L2-resident bit test instead of a 64 MiB-table access; its lookup[h] is never used (frequency 0).
           uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
-          bool need_f = strand_ok[0], need_r = strand_ok[1];
+          const int jr = S - 1 - j;
+          bool need_f = strand_ok[0] && j <= last_used, need_r = strand_ok[1] && jr <= last_used;
           if (!HASH && p.nonempty) {
-            need_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
-            need_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
+            const bool ne_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
+            const bool ne_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
+            // non-empty: frequency 1 unless the folded filter says "maybe more"; only then the table is read now
+            need_f = ne_f && ((p.multi[(hf & kMultiMask) >> 5] >> (hf & 31u)) & 1u);
+            need_r = ne_r && ((p.multi[(hr & kMultiMask) >> 5] >> (hr & 31u)) & 1u);
+            if (ne_f && !need_f) qf = make_uint2(hf | kDeferredLookup, (hf | kDeferredLookup) + 1u);
+            if (ne_r && !need_r) qr = make_uint2(hr | kDeferredLookup, (hr | kDeferredLookup) + 1u);
           }
-          if (need_f) {
-            __builtin_memcpy(&qf, p.lookup + hf, 8);  // plain load: `nt` was measured 40 % slower here
-          }
-          if (need_r) {
-            __builtin_memcpy(&qr, p.lookup + hr, 8);
-          }
+          if (need_f) __builtin_memcpy(&qf, p.lookup + hf, 8);  // plain load: `nt` was measured 40 % slower here
+          if (need_r) __builtin_memcpy(&qr, p.lookup + hr, 8);
           if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
           if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
         }
@@ -887,6 +894,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       pre_g = select_seeds_lanes<R>(p, S, strand_ok, sf, smax, dp_w, take_bits, s_start, s_lo, s_freq);
       // lane s = strand * kSeeds + group * R + run now holds that run's seed
       if (ln < 2u * kSeeds && !strand_ok[ln / kSeeds]) s_freq = 0;
+      // selected seeds whose table lookup was deferred (frequency 1 known from the filters): fetch lookup[h] now
+      if (!HASH && s_freq != 0 && (s_lo & kDeferredLookup)) s_lo = p.lookup[s_lo & ~kDeferredLookup];
       STAMP(prof, 2);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 2
       selected = false;
