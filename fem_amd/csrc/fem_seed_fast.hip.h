@@ -438,15 +438,30 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
   int col = (int)ncols - 1;
   bool alive = act;
   uint32_t sidx = 0xFFFFFFFFu;
+  if (W <= 32u) {  // a group's take bits fit one word (every read up to ~170 bases): 32-bit arithmetic
 #pragma unroll
-  for (int r = R; r >= 1; --r) {
-    if (alive && (uint32_t)(R - r) <= t) {
-      const unsigned long long seg = (take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W)) & ((2ull << col) - 1ull);
-      if (seg == 0) {
-        alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
-      } else {
-        col = 63 - __builtin_clzll(seg);
-        if ((uint32_t)(R - r) == t) sidx = si + (uint32_t)kStep * (uint32_t)(col + (r - 1) * kLg);
+    for (int r = R; r >= 1; --r) {
+      if (alive && (uint32_t)(R - r) <= t) {
+        const uint32_t seg = (uint32_t)(take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W)) & ((2u << col) - 1u);
+        if (seg == 0) {
+          alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
+        } else {
+          col = 31 - __builtin_clz(seg);
+          if ((uint32_t)(R - r) == t) sidx = si + (uint32_t)kStep * (uint32_t)(col + (r - 1) * kLg);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = R; r >= 1; --r) {
+      if (alive && (uint32_t)(R - r) <= t) {
+        const unsigned long long seg = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] & ((2ull << col) - 1ull);  // one group per pass
+        if (seg == 0) {
+          alive = false;
+        } else {
+          col = 63 - __builtin_clzll(seg);
+          if ((uint32_t)(R - r) == t) sidx = si + (uint32_t)kStep * (uint32_t)(col + (r - 1) * kLg);
+        }
       }
     }
   }
