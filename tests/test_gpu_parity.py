@@ -126,3 +126,32 @@ def test_high_copy_repeat_takes_the_arena_path(dev):
     assert np.diff(want.cand_off.astype(np.int64)).max() > 600
     assert want.pre.max() > 3 * 512
     assert_same(want, got)
+
+
+def test_short_tandem_repeats_survive_in_several_phase_groups(dev):
+    # units of 4, 5 and 7 bases: a read inside such a stretch matches at shifts that are no multiple of the step, so
+    # its survivors sit in two or three phase groups, a few bases apart — few occurrences (a "small" read for the
+    # batched path of the fast kernel) but more than one candidate to merge: those reads are handed to the generic kernel
+    rng = np.random.default_rng(12)
+    parts = []
+    for unit_len in (4, 5, 7, 4, 5, 7, 11):
+        parts.append(util.rand_seq(rng, int(rng.integers(3000, 6000))))
+        unit = util.rand_seq(rng, unit_len)
+        parts.append(unit * (260 // unit_len))
+    parts.append(util.rand_seq(rng, 4000))
+    seqs = [b"".join(parts)]
+    starts, at = [], 0
+    for i, part in enumerate(parts):
+        if i % 2 == 1:
+            starts.append((at, len(part)))
+        at += len(part)
+    reads = []
+    for s, n in starts:  # reads inside, and straddling the borders of, every repeat stretch
+        for off in (-60, -20, 0, 7, 31, n - 100, n - 80, n - 40):
+            r = seqs[0][s + off:s + off + 100]
+            reads += [r, util.revcomp(r), util.mutate(rng, r + seqs[0][s + off + 100:s + off + 103], 2)[:100]]
+    reads += util.make_reads(rng, seqs, 200, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert_same(want, got)
+    per_strand = np.diff(want.cand_off.astype(np.int64))
+    assert (per_strand >= 2).sum() > 10, "fixture must contain reads with several candidates per strand"
