@@ -780,51 +780,92 @@ struct SeqRoundTrip {
 };
 const SeqRoundTrip kSeqText;
 
-// One SAM line: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL NM MD (src/align.c:546-632)
-void append_sam_line(std::string &o, const fem_tail_ref &ref, const char *name, size_t name_len, const Record &rec,
-                     const uint32_t *cigar, size_t n_cigar, const char *md, size_t n_md, bool primary, const char *fwd,
-                     uint32_t len, const char *qual) {
-  o.append(name, name_len);
-  o.push_back('\t');
-  append_uint(o, rec.flag);
-  o.push_back('\t');
-  o.append(ref.names + ref.name_off[rec.tid], ref.name_off[rec.tid + 1] - ref.name_off[rec.tid]);
-  o.push_back('\t');
-  append_uint(o, rec.pos0 + 1u);
-  o += "\t255\t";
-  if (n_cigar == 0) o.push_back('*');
-  for (size_t i = 0; i < n_cigar; ++i) {
-    append_uint(o, cigar[i] >> 4);
-    o.push_back("MIDNSHP=XB"[cigar[i] & 0xf]);
+// Growable text buffer of one formatting thread: records are written through a raw pointer after one capacity check.
+struct TextBuf {
+  char *p = nullptr;
+  size_t n = 0, cap = 0;
+  bool failed = false;
+  bool room(size_t extra) {
+    if (n + extra <= cap) return true;
+    const size_t want = std::max(cap + cap / 2, n + extra + (size_t)(1u << 20));
+    char *q = (char *)realloc(p, want);
+    if (!q) {
+      failed = true;
+      return false;
+    }
+    p = q, cap = want;
+    return true;
   }
-  o += "\t*\t0\t0\t";
-  if (primary && len > 0) {  // only the primary record carries SEQ/QUAL (src/align.c:83-88)
-    const size_t at = o.size();
-    o.resize(at + len);
-    for (uint32_t i = 0; i < len; ++i) o[at + i] = kSeqText.t[(unsigned char)fwd[i]];  // original read (src/align.c:79)
-    o.push_back('\t');
-    if (qual)
-      o.append(qual, len);
-    else
-      o.push_back('*');
-  } else {
-    o += "*\t*";
-  }
-  o += "\tNM:i:";
-  append_uint(o, rec.nm);
-  o += "\tMD:Z:";
-  o.append(md, n_md);
-  o.push_back('\n');
+};
+
+inline char *put_uint(char *w, unsigned v) {
+  char tmp[12];
+  int k = 0;
+  do {
+    tmp[k++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (k) *w++ = tmp[--k];
+  return w;
+}
+inline char *put_str(char *w, const char *s, size_t n) {
+  memcpy(w, s, n);
+  return w + n;
 }
 
-// Concatenate the threads' pieces into one malloc'd buffer (each piece copied by its own thread).
-int join_parts(const std::vector<std::string> &parts, int n_threads, char **text, uint64_t *text_len) {
+// One SAM line: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL NM MD (src/align.c:546-632)
+void append_sam_line(TextBuf &o, const fem_tail_ref &ref, const char *name, size_t name_len, const Record &rec,
+                     const uint32_t *cigar, size_t n_cigar, const char *md, size_t n_md, bool primary, const char *fwd,
+                     uint32_t len, const char *qual) {
+  const size_t rname_len = (size_t)(ref.name_off[rec.tid + 1] - ref.name_off[rec.tid]);
+  if (!o.room(name_len + rname_len + 2 * (size_t)len + n_md + 11 * n_cigar + 96)) return;
+  char *w = o.p + o.n;
+  w = put_str(w, name, name_len);
+  *w++ = '\t';
+  w = put_uint(w, rec.flag);
+  *w++ = '\t';
+  w = put_str(w, ref.names + ref.name_off[rec.tid], rname_len);
+  *w++ = '\t';
+  w = put_uint(w, rec.pos0 + 1u);
+  w = put_str(w, "\t255\t", 5);
+  if (n_cigar == 0) *w++ = '*';
+  for (size_t i = 0; i < n_cigar; ++i) {
+    w = put_uint(w, cigar[i] >> 4);
+    *w++ = "MIDNSHP=XB"[cigar[i] & 0xf];
+  }
+  w = put_str(w, "\t*\t0\t0\t", 7);
+  if (primary && len > 0) {  // only the primary record carries SEQ/QUAL (src/align.c:83-88)
+    for (uint32_t i = 0; i < len; ++i) w[i] = kSeqText.t[(unsigned char)fwd[i]];  // original read (src/align.c:79)
+    w += len;
+    *w++ = '\t';
+    if (qual)
+      w = put_str(w, qual, len);
+    else
+      *w++ = '*';
+  } else {
+    w = put_str(w, "*\t*", 3);
+  }
+  w = put_str(w, "\tNM:i:", 6);
+  w = put_uint(w, rec.nm);
+  w = put_str(w, "\tMD:Z:", 6);
+  w = put_str(w, md, n_md);
+  *w++ = '\n';
+  o.n = (size_t)(w - o.p);
+}
+
+// Concatenate the threads' pieces into one malloc'd buffer (each piece copied by its own thread); frees the pieces.
+int join_parts(std::vector<TextBuf> &parts, int n_threads, char **text, uint64_t *text_len) {
   std::vector<size_t> at(parts.size() + 1, 0);
-  for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].size();
-  char *buf = (char *)malloc(at.back() + 1);
-  if (!buf) return -4;
+  bool failed = false;
+  for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].n, failed = failed || parts[i].failed;
+  char *buf = failed ? nullptr : (char *)malloc(at.back() + 1);
+  if (buf) {
 #pragma omp parallel for num_threads(n_threads) schedule(static, 1)
-  for (size_t i = 0; i < parts.size(); ++i) memcpy(buf + at[i], parts[i].data(), parts[i].size());
+    for (size_t i = 0; i < parts.size(); ++i)
+      if (parts[i].n) memcpy(buf + at[i], parts[i].p, parts[i].n);
+  }
+  for (TextBuf &t : parts) free(t.p);
+  if (!buf) return -4;
   *text = buf;
   *text_len = at.back();
   return 0;
@@ -957,11 +998,11 @@ int fem_tail_sam(int32_t e, const fem_tail_ref *ref, const fem_seqset *reads, co
   if (in->n_reads > reads->n) return -1;
   if (n_threads < 1) n_threads = 1;
   const uint64_t n = in->n_reads;
-  std::vector<std::string> parts((size_t)n_threads);
+  std::vector<TextBuf> parts((size_t)n_threads);
 #pragma omp parallel num_threads(n_threads)
   {
     const int t = omp_get_thread_num(), nt = omp_get_num_threads();
-    std::string &o = parts[(size_t)t];
+    TextBuf &o = parts[(size_t)t];
     const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
     std::vector<Hit> hits;
     Tracer tr;
@@ -991,11 +1032,11 @@ int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_
   if (rv->n_reads > reads->n) return -1;
   if (n_threads < 1) n_threads = 1;
   const uint64_t n = rv->n_reads;
-  std::vector<std::string> parts((size_t)n_threads);
+  std::vector<TextBuf> parts((size_t)n_threads);
 #pragma omp parallel num_threads(n_threads)
   {
     const int t = omp_get_thread_num(), nt = omp_get_num_threads();
-    std::string &o = parts[(size_t)t];
+    TextBuf &o = parts[(size_t)t];
     // threads take contiguous read ranges holding about the same number of records
     const uint64_t total = rv->rec_begin[n];
     auto cut = [&](uint64_t k) -> uint64_t {
@@ -1005,7 +1046,7 @@ int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_
       return (uint64_t)(std::lower_bound(rv->rec_begin, rv->rec_begin + n, (uint32_t)target) - rv->rec_begin);
     };
     const uint64_t lo = cut((uint64_t)t), hi = cut((uint64_t)t + 1);
-    if (hi > lo) o.reserve((size_t)((rv->rec_begin[hi] - rv->rec_begin[lo]) * 300ull));
+    if (hi > lo) (void)o.room((size_t)((rv->rec_begin[hi] - rv->rec_begin[lo]) * 260ull));
     for (uint64_t r = lo; r < hi; ++r) {
       const uint32_t b = rv->rec_begin[r], e_ = rv->rec_begin[r + 1];
       if (b == e_) continue;  // unmapped reads produce no record (src/map.c:50)
