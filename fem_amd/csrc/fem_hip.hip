@@ -208,18 +208,27 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   l.pkw = take(l.n_words * 4u);
   l.nkw = take(l.n_words * 4u);
   l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 8u));  // reused for the strands' candidates once the seeds are selected
-  l.dp_bits = take(n_groups * R * 8u);
-  l.X = take(64u * 8u);  // scatter
-  // lists_in_lanes' scratch; flush_small lays its own over [sf, dp_bits, X, A], which has to be long enough for it
-  {
+  l.dp_bits = take(std::max(n_groups, femk::kGroupQueue) * R * 8u);  // one ballot per (pass, row); up to kGroupQueue passes
+  if (hash) {
+    l.X = take(64u * 8u);                 // scatter
+    l.A = take(femk::kListScratchBytes);  // lists_in_lanes
+  } else {
+    // lean form: no per-read list phase; flush_small lays its scratch over the seed table and what follows it
     const uint32_t so_far = o - l.sf;
-    l.A = take(std::max(femk::kListScratchBytes, femk::kFlushScratchBytes > so_far ? femk::kFlushScratchBytes - so_far : 0u));
+    l.X = l.A = take(femk::kFlushScratchBytes > so_far ? femk::kFlushScratchBytes - so_far : 0u);
   }
   l.B = take(2u * femk::kReadBlock * 8u);  // the block's begin/count entries
-  if (!hash) l.F = take(femk::kQueueBytes);  // queue of small reads' seeds
+  if (!hash) {
+    l.F = take(femk::kQueueBytes);  // queue of small reads' seeds
+    // queue of live phase groups: a read may add all six of its groups, each with G - Lg + 1 words
+    const uint32_t g0 = l.smax / (uint32_t)femk::kStep;
+    const uint32_t n_used = g0 > (uint32_t)femk::kLg ? g0 - (uint32_t)femk::kLg + 1u : 1u;
+    l.gq_cap = std::max(384u, n_groups * n_used);
+    l.gq = take(l.gq_cap * 4u + femk::kGroupQueue * 16u + 2u * 32u * 4u);
+  }
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
-  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 32u : 0u;
+  l.blk_bytes = 0;  // (staging a block's characters helped by ~4 %, but its LDS costs a wave per SIMD with the group queue)
   l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;

@@ -44,6 +44,7 @@ struct SeedLayout {
   uint32_t smax, cmax, cw;
   uint32_t n_words;
   uint32_t blk, blk_bytes;   // seed_fast_kernel: the raw characters of one block of reads (0 bytes: not staged)
+  uint32_t gq, gq_cap;       // seed_fast_kernel, lean form: queue of live phase groups (rows of gq_cap words, then descriptors)
   uint32_t wave_bytes;
 };
 

@@ -17,13 +17,14 @@ namespace femk {
 
 constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
-constexpr uint32_t kDeferredLookup = 0x80000000u;  // a seed table entry holds the seed's hash, not lookup[h] (frequency 1)
 constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
 constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast kernel did not handle
 // Small reads (lean form): a read whose strands select at most kSmallStrand occurrences each is not finished on its own
 // — its non-empty seeds wait in an LDS queue and a whole batch of reads is finished in one pass over the lanes
 // (flush_small).  Queue entry: lookup[h] and start | frequency << 10 | tag << 17, tag = read-in-block << 7 | strand << 6 |
 // group << 4 | run.
+// Live phase groups (lean form) wait as well: up to kGroupQueue of them, from several reads, are selected at once.
+constexpr uint32_t kGroupQueue = 12;
 constexpr uint32_t kSmallStrand = 12, kQueueSeeds = 64;
 constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u + kReadBlock * 8u;  // seeds, the reads' lengths and pre-filter counts
 // LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
@@ -754,6 +755,137 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     }
   };
 
+  // ---- lean form: queue of live phase groups ----
+  // gq_row: per group its G - Lg + 1 seeds as hash << 8 | frequency (< 255); gq_desc: (first word, words, DP columns,
+  // tag = read-in-block << 3 | strand << 2 | phase).  Totals per (read, strand) slot behind the descriptors.
+  uint32_t *gq_row = (uint32_t *)(wbase + p.lay.gq);
+  uint4 *gq_desc = (uint4 *)(gq_row + p.lay.gq_cap);
+  uint32_t *slot_total = (uint32_t *)(gq_desc + kGroupQueue), *slot_pre = slot_total + 32;
+  uint32_t gq_groups = 0, gq_entries = 0, gq_maxcols = 0, gq_reads = 0;
+  constexpr uint32_t kGroups = kGroupQueue * (uint32_t)R <= (uint32_t)kWave ? kGroupQueue : (uint32_t)kWave / (uint32_t)R;  // one traceback lane per (group, row)
+  static_assert(kGroups >= 2u * (uint32_t)kStep, "a read's six groups must fit the queue");
+  // Selects the seeds of every queued group at once — the DP of select_seeds_lanes with the groups of several reads in
+  // the lanes, the traceback with one lane per (group, row) — and hands each read's seeds to the small-read queue
+  // (flushing that when it is full, and at the end of the block).  Reads with more than 64 occurrences go to the
+  // generic kernel.
+  auto select_flush = [&](uint32_t r0, bool tail) {
+    const uint32_t K = gq_groups, reads = gq_reads;
+    const uint32_t W = gq_maxcols <= 16u ? 16u : gq_maxcols <= 32u ? 32u : 64u;
+    const uint32_t per_pass = (uint32_t)kWave / W;
+    uint32_t g_start = 0, g_lo = 0, g_freq = 0, g_tag = 0;  // lane k * R + run: that run's seed of group k
+    gq_groups = 0, gq_entries = 0, gq_maxcols = 0, gq_reads = 0;
+    if (K) {
+      constexpr uint32_t kFill = 0xFFFFFFFFu;
+      const uint32_t inf = p.inf32;
+      if (ln < 32u) slot_total[ln] = 0, slot_pre[ln] = 0;
+      wave_sync_lds();
+      const uint32_t c = ln & (W - 1u), slot = ln / W;
+      for (uint32_t ps = 0; ps * per_pass < K; ++ps) {
+        const uint32_t k = ps * per_pass + slot;
+        const bool g_ok = k < K;
+        const uint4 d = gq_desc[g_ok ? k : 0u];
+        const uint32_t ncols = g_ok ? d.z : 0u;
+        const bool in_seg = c < ncols;
+        const uint32_t *row = gq_row + d.x + (in_seg ? c : 0u);
+        uint32_t f[R];
+#pragma unroll
+        for (int r = 1; r <= R; ++r) f[r - 1] = row[(r - 1) * kLg] & 255u;
+        uint32_t M = 0;  // M[0][c] = 0
+#pragma unroll
+        for (int r = 1; r <= R; ++r) {
+          const uint32_t v = M + f[r - 1];
+          uint32_t x = in_seg ? v : kFill;
+          x = dpp_min_step<0x111, 0xF>(x, kFill);  // row_shr:1
+          x = dpp_min_step<0x112, 0xF>(x, kFill);  // row_shr:2
+          x = dpp_min_step<0x114, 0xF>(x, kFill);  // row_shr:4
+          x = dpp_min_step<0x118, 0xF>(x, kFill);  // row_shr:8
+          if (W > 16u) x = dpp_min_step<0x142, 0xA>(x, kFill);  // row_bcast:15 into rows 1 and 3
+          if (W > 32u) x = dpp_min_step<0x143, 0xC>(x, kFill);  // row_bcast:31 into rows 2 and 3
+          uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp((int)kFill, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
+          ex = (c == 0 || ex > inf) ? inf : ex;  // M[r][0] = (uint32)occurrence_table_size
+          const bool take = in_seg && v < ex;    // strict: ties go horizontal (src/filter.c:20)
+          M = take ? v : ex;
+          const unsigned long long bits = __ballot(take);
+          if (ln == 0) take_bits[ps * (uint32_t)R + (uint32_t)(r - 1)] = bits;
+        }
+        // M[R][C-1]: uint32 sum per (read, strand) as the reference forms it (src/filter.c:202)
+        if (in_seg && c == ncols - 1u) atomicAdd(&slot_pre[d.w >> 2], M);
+      }
+      wave_sync_lds();
+      // ---- traceback: lane (k, t) finds the seed taken at row R - t ----
+      const uint32_t k = ln / (uint32_t)R, t = ln % (uint32_t)R;
+      const bool act = k < K;
+      const uint4 d = gq_desc[act ? k : 0u];
+      const uint32_t pass_of = k / per_pass, slot_of = k % per_pass;
+      int col = (int)d.z - 1;
+      bool alive = act;
+      uint32_t idx = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = R; r >= 1; --r) {
+        if (alive && (uint32_t)(R - r) <= t) {
+          const unsigned long long row_bits = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W);
+          const unsigned long long seg = row_bits & ((2ull << col) - 1ull);
+          if (seg == 0) {
+            alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
+          } else {
+            col = 63 - __builtin_clzll(seg);
+            if ((uint32_t)(R - r) == t) idx = (uint32_t)(col + (r - 1) * kLg);
+          }
+        }
+      }
+      const bool have = alive && idx != 0xFFFFFFFFu;
+      const uint32_t word = gq_row[d.x + (have ? idx : 0u)];
+      const uint32_t start = have ? (d.w & 3u) + (uint32_t)kStep * idx : 0u, hash = have ? word >> 8 : 0u;
+      const uint32_t freq = have ? word & 255u : 0u;
+      // qsort(compare_seed): stable by ascending frequency; traceback order t breaks ties
+      uint32_t rank = 0;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t fu = (uint32_t)__shfl((int)freq, (int)(k * (uint32_t)R) + u);
+        rank += (uint32_t)(fu < freq || (fu == freq && (uint32_t)u < t));
+      }
+      const int dst = (int)((k * (uint32_t)R + rank) * 4u);
+      g_start = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)start);
+      g_freq = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)freq);
+      const uint32_t g_hash = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)hash);
+      if (!act) g_start = 0, g_freq = 0;
+      g_tag = (d.w << 4) | t;  // read << 7 | strand << 6 | phase << 4 | run
+      if (g_freq) {
+        g_lo = p.lookup[g_hash];
+        atomicAdd(&slot_total[d.w >> 2], g_freq);
+      }
+      wave_sync_lds();
+    }
+    // ---- read by read into the small-read queue ----
+    for (uint32_t todo = reads;;) {
+      const bool more = todo != 0;
+      const uint32_t rb = more ? (uint32_t)__builtin_ctz(todo) : 0u;
+      const uint32_t t0 = more ? bcast0(slot_total[2u * rb]) : 0u, t1 = more ? bcast0(slot_total[2u * rb + 1u]) : 0u;
+      const bool stays = t0 <= (uint32_t)kWave && t1 <= (uint32_t)kWave && t0 + t1 <= (uint32_t)kWave;
+      const uint32_t use0 = t0 > (uint32_t)p.a ? t0 : 0u, use1 = t1 > (uint32_t)p.a ? t1 : 0u;  // strands that can pass the filter
+      if ((more && stays && q_entries + use0 + use1 > (uint32_t)kWave) || (!more && tail)) flush_small(r0);
+      if (!more) break;
+      todo &= todo - 1u;
+      if (!stays) {  // (nothing has been emitted or counted for it)
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+        queue_slow(r0 + rb);
+        continue;
+      }
+      const unsigned long long pre_read = (unsigned long long)bcast0(slot_pre[2u * rb]) + bcast0(slot_pre[2u * rb + 1u]);
+      pre_sum += pre_read;
+      if (ln == 0) q_pre[rb] = pre_read;
+      const bool mine = g_freq > 0 && (g_tag >> 7) == rb && (((g_tag >> 6) & 1u) ? use1 : use0) != 0u;
+      const uint64_t mm = __ballot(mine);
+      if (mine) {
+        const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
+        q_lo[at_] = g_lo;
+        q_info[at_] = g_start | (g_freq << 10) | (g_tag << 17);
+      }
+      q_seeds += (uint32_t)__popcll(mm), q_entries += use0 + use1;
+      wave_sync_lds();
+    }
+  };
+
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
@@ -784,11 +916,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   // called from one place each (they are large, and inlined).
   for (uint32_t rb = 0;; ++rb) {
     const bool tail_turn = rb >= kReadBlock || r0 + rb >= p.n_reads;
-    // the queue is flushed while no read is in flight: before a read that might not fit any more, and at the block's end
-    if (!HASH && (tail_turn || q_entries > (uint32_t)kWave - 2u * kSmallStrand)) flush_small(r0);
-    if (tail_turn) break;
     const uint32_t read = r0 + rb;
+    uint64_t off = 0;
     uint32_t L = 0;
+    if (!tail_turn) off = p.read_off[read], L = (uint32_t)(p.read_off[read + 1] - off);
+    const int S = (int)L - kK + 1;  // num_seeds_in_read
+    if (!HASH) {
+      // the queues are flushed while no read is in flight: before a read whose six groups might not fit, and at the
+      // block's end
+      const uint32_t g0 = S > 0 ? (uint32_t)S / (uint32_t)kStep : 0u;
+      const uint32_t worst = 2u * (uint32_t)kStep * (g0 > (uint32_t)kLg ? g0 - (uint32_t)kLg + 1u : 1u);
+      if (tail_turn || gq_groups + 2u * (uint32_t)kStep > kGroups || gq_entries + worst > p.lay.gq_cap) select_flush(r0, tail_turn);
+    }
+    if (tail_turn) break;
     bool slow = false, selected = false;  // selected: seeds are in the lanes (or the read is `slow`)
     bool strand_ok[2] = {true, true};
     uint32_t pre_g = 0;
@@ -798,10 +938,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     uint32_t strand_total[2] = {0, 0}, s_at = 0;
     do {
     STAMP_START(prof);
-    const uint64_t off = p.read_off[read];
-    L = (uint32_t)(p.read_off[read + 1] - off);
-    const int S = (int)L - kK + 1;  // num_seeds_in_read
-
     // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
     bool shape_ok = S > 0 && R <= S / kStep;
     if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
@@ -865,6 +1001,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
       // The DP of phase group si only ever looks at its first G - Lg + 1 seeds, G = (S - si) / step (row r spans columns
       // c + (r-1) Lg, c < C - 1): seeds behind the last one any group uses are not looked up.
+      uint32_t big_freq = 0;  // lean form: some bucket holds more than the group queue's 8-bit field takes
       int last_used = 0;
       for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
       for (int j0 = 0; j0 < S; j0 += kWave) {
@@ -882,19 +1019,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
           uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
           const int jr = S - 1 - j;
           bool need_f = strand_ok[0] && j <= last_used, need_r = strand_ok[1] && jr <= last_used;
-          if (!HASH && p.nonempty) {
-            const bool ne_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
-            const bool ne_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
-            // non-empty: frequency 1 unless the folded filter says "maybe more"; only then the table is read now
-            need_f = ne_f && ((p.multi[(hf & kMultiMask) >> 5] >> (hf & 31u)) & 1u);
-            need_r = ne_r && ((p.multi[(hr & kMultiMask) >> 5] >> (hr & 31u)) & 1u);
-            if (ne_f && !need_f) qf = make_uint2(hf | kDeferredLookup, (hf | kDeferredLookup) + 1u);
-            if (ne_r && !need_r) qr = make_uint2(hr | kDeferredLookup, (hr | kDeferredLookup) + 1u);
+          if (!HASH) {
+            // lean form: (hash, frequency).  Empty buckets (bitmap) have 0, non-empty ones outside the folded filter
+            // exactly 1; only the others read the table now.  lookup[h] itself is fetched for the selected seeds only.
+            uint32_t ff = 0, fr = 0;
+            if (p.nonempty) {
+              const bool ne_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
+              const bool ne_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
+              need_f = ne_f && ((p.multi[(hf & kMultiMask) >> 5] >> (hf & 31u)) & 1u);
+              need_r = ne_r && ((p.multi[(hr & kMultiMask) >> 5] >> (hr & 31u)) & 1u);
+              ff = ne_f ? 1u : 0u, fr = ne_r ? 1u : 0u;
+            }
+            if (need_f) {
+              __builtin_memcpy(&qf, p.lookup + hf, 8);  // plain load: `nt` was measured 40 % slower here
+              ff = qf.y - qf.x;
+            }
+            if (need_r) {
+              __builtin_memcpy(&qr, p.lookup + hr, 8);
+              fr = qr.y - qr.x;
+            }
+            big_freq |= (uint32_t)(ff > 254u || fr > 254u);
+            if (strand_ok[0]) sf[j] = make_uint2(hf, ff);
+            if (strand_ok[1]) sf[smax + (uint32_t)jr] = make_uint2(hr, fr);
+          } else {
+            if (need_f) __builtin_memcpy(&qf, p.lookup + hf, 8);
+            if (need_r) __builtin_memcpy(&qr, p.lookup + hr, 8);
+            if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
+            if (strand_ok[1]) sf[smax + (uint32_t)jr] = make_uint2(qr.x, qr.y - qr.x);
           }
-          if (need_f) __builtin_memcpy(&qf, p.lookup + hf, 8);  // plain load: `nt` was measured 40 % slower here
-          if (need_r) __builtin_memcpy(&qr, p.lookup + hr, 8);
-          if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
-          if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
         }
       }
       wave_sync_lds();
@@ -903,14 +1055,54 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       selected = false;
       break;
 #endif
+      if (!HASH) {
+        if (__any(big_freq != 0)) {  // a bucket too full for the group queue's field: the generic kernel takes the read
+          slow = true;
+          break;
+        }
+        // A group with a zero-cost selection contributes nothing (its minimum is 0: whatever the traceback takes has no
+        // occurrences, and M[R][C-1] = 0).  Sufficient test on columns 0 and 1 of every row: rows 1..s free at column 0
+        // and rows s+1..R free at column 1 for some s.  The other groups are queued.
+        uint32_t live = 0;
+        {
+          const uint32_t tg = ln / (uint32_t)R, tr = ln % (uint32_t)R;
+          const uint32_t t_strand = (tg / (uint32_t)kStep) & 1u, t_si = tg % (uint32_t)kStep;
+          const bool t_in = ln < 2u * kSeeds && strand_ok[t_strand];
+          const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
+          const uint2 *t_sf = sf + t_strand * smax + t_si + (uint32_t)(kStep * kLg) * tr;
+          const uint64_t z0 = __ballot(t_in && t_sf[0].y == 0u), z1 = __ballot(t_in && t_cols > 1u && t_sf[t_in ? kStep : 0].y == 0u);
+          const uint32_t full = (1u << R) - 1u;
+          const uint32_t a0 = (uint32_t)(z0 >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z1 >> (ln * (uint32_t)R)) & full;
+          const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
+          const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
+          const bool g_in = ln < 2u * (uint32_t)kStep && strand_ok[(ln / (uint32_t)kStep) & 1u];
+          live = (uint32_t)__ballot(g_in && !(from1 <= free0));
+        }
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
+        if (ln == 0) q_len[rb] = L;
+        if (live) gq_reads |= 1u << rb;
+        for (uint32_t m = live; m; m &= m - 1u) {
+          const uint32_t g = (uint32_t)__builtin_ctz(m), g_strand = g / (uint32_t)kStep, g_si = g % (uint32_t)kStep;
+          const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1), n_used = ncols + (uint32_t)((R - 1) * kLg);
+          const uint2 *src = sf + g_strand * smax + g_si;
+          for (uint32_t i = ln; i < n_used; i += (uint32_t)kWave) {
+            const uint2 q = src[(uint32_t)kStep * i];
+            gq_row[gq_entries + i] = (q.x << 8) | q.y;
+          }
+          if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries, n_used, ncols, (rb << 3) | (g_strand << 2) | g_si);
+          gq_entries += n_used, ++gq_groups;
+          gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
+        }
+        wave_sync_lds();
+        selected = false;
+        break;
+      }
 
       // ---- seed selection ----
       const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
       pre_g = select_seeds_lanes<R>(p, S, strand_ok, sf, smax, dp_w, take_bits, s_start, s_lo, s_freq);
       // lane s = strand * kSeeds + group * R + run now holds that run's seed
       if (ln < 2u * kSeeds && !strand_ok[ln / kSeeds]) s_freq = 0;
-      // selected seeds whose table lookup was deferred (frequency 1 known from the filters): fetch lookup[h] now
-      if (!HASH && s_freq != 0 && (s_lo & kDeferredLookup)) s_lo = p.lookup[s_lo & ~kDeferredLookup];
       STAMP(prof, 2);
 #if defined(FEM_ABLATE) && FEM_ABLATE == 2
       selected = false;
@@ -939,29 +1131,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 
     } while (false);
     STAMP(prof, 3);
-    // small read: its seeds wait in the queue (those of the strands that can pass the filter at all: >= a+1 occurrences)
-    const bool small = !HASH && selected && !slow && strand_total[0] <= kSmallStrand && strand_total[1] <= kSmallStrand;
-    const uint32_t skip0 = strand_total[0] <= (uint32_t)p.a ? 1u : 0u, skip1 = strand_total[1] <= (uint32_t)p.a ? 1u : 0u;
-    const bool mine = small && s_freq > 0 && !(ln < kSeeds ? skip0 : skip1);
-    const uint64_t mm = __ballot(mine);
-    const uint32_t n_push = (uint32_t)__popcll(mm), n_occ = (skip0 ? 0u : strand_total[0]) + (skip1 ? 0u : strand_total[1]);
-    if (small) {
-      if (mine) {
-        const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
-        const uint32_t within = ln % kSeeds;
-        const uint32_t tag = (rb << 7) | ((ln / kSeeds) << 6) | ((within / (uint32_t)R) << 4) | (within % (uint32_t)R);
-        q_lo[at_] = s_lo;
-        q_info[at_] = s_start | (s_freq << 10) | (tag << 17);
-      }
-      if (ln == 0) q_len[rb] = L, q_pre[rb] = pre_read;
-      if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
-      q_seeds += n_push, q_entries += n_occ;
-      pre_sum += pre_read;
-      wave_sync_lds();
-    } else if (selected) {
+    if (selected) {
       if (!slow) slow = !finish_read(read, rb, L, strand_ok[0], strand_ok[1], s_start, s_lo, s_freq, s_at, strand_total[0], strand_total[1], nonempty, pre_read);
-      if (slow) queue_slow(read);
     }
+    if (slow) queue_slow(read);
     STAMP(prof, 5);
   }
   wave_sync_lds();
