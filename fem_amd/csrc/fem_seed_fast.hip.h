@@ -1004,48 +1004,81 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       uint32_t big_freq = 0;  // lean form: some bucket holds more than the group queue's 8-bit field takes
       int last_used = 0;
       for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
-      for (int j0 = 0; j0 < S; j0 += kWave) {
-        const int j = j0 + (int)ln;
-        if (j < S) {
-          const uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
-          const uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
-          const uint32_t hf = (uint32_t)(pw >> (64 - 2 * kK - sh)) & kHashMask;
-          uint32_t nm = 0;
-          if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
-          uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);  // reversed complement, pair order restored below
-          const uint32_t hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-          // (lookup[h], frequency) per seed.  With the non-empty bitmap (sparse index) an empty bucket costs one
-          // L2-resident bit test instead of a 64 MiB-table access; its lookup[h] is never used (frequency 0).
-          uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
-          const int jr = S - 1 - j;
-          bool need_f = strand_ok[0] && j <= last_used, need_r = strand_ok[1] && jr <= last_used;
-          if (!HASH) {
-            // lean form: (hash, frequency).  Empty buckets (bitmap) have 0, non-empty ones outside the folded filter
-            // exactly 1; only the others read the table now.  lookup[h] itself is fetched for the selected seeds only.
-            uint32_t ff = 0, fr = 0;
-            if (p.nonempty) {
-              const bool ne_f = need_f && ((p.nonempty[hf >> 5] >> (hf & 31u)) & 1u);
-              const bool ne_r = need_r && ((p.nonempty[hr >> 5] >> (hr & 31u)) & 1u);
-              need_f = ne_f && ((p.multi[(hf & kMultiMask) >> 5] >> (hf & 31u)) & 1u);
-              need_r = ne_r && ((p.multi[(hr & kMultiMask) >> 5] >> (hr & 31u)) & 1u);
-              ff = ne_f ? 1u : 0u, fr = ne_r ? 1u : 0u;
+      // hash of seed j and of its reverse-strand partner S-1-j (bit-reversed complement: no second encode)
+      auto seed_hashes = [&](int j, uint32_t &hf, uint32_t &hr) {
+        const uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
+        const uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
+        hf = (uint32_t)(pw >> (64 - 2 * kK - sh)) & kHashMask;
+        uint32_t nm = 0;
+        if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
+        const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);  // pair order restored below
+        hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+      };
+      if (!HASH) {
+        // lean form: (hash, frequency) per seed.  Empty buckets (bitmap) have 0, non-empty ones outside the folded
+        // filter exactly 1; only the others read the table.  lookup[h] itself is fetched for the selected seeds only.
+        // Two rounds of 64 seeds go through the three dependent levels together (bit tests, filter tests, table
+        // reads): the phase is latency-bound, and this halves its chain per read.
+        for (int j0 = 0; j0 < S; j0 += 2 * kWave) {
+          uint32_t hf[2], hr[2], ff[2] = {0, 0}, fr[2] = {0, 0};
+          bool in[2], nf[2], nr[2];
+          uint32_t wf[2], wr[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int j = j0 + u * kWave + (int)ln;
+            in[u] = j < S;
+            hf[u] = hr[u] = 0;
+            if (in[u]) seed_hashes(j, hf[u], hr[u]);
+            nf[u] = in[u] && strand_ok[0] && j <= last_used;
+            nr[u] = in[u] && strand_ok[1] && S - 1 - j <= last_used;
+          }
+          if (p.nonempty) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              wf[u] = nf[u] ? p.nonempty[hf[u] >> 5] : 0u;
+              wr[u] = nr[u] ? p.nonempty[hr[u] >> 5] : 0u;
             }
-            if (need_f) {
-              __builtin_memcpy(&qf, p.lookup + hf, 8);  // plain load: `nt` was measured 40 % slower here
-              ff = qf.y - qf.x;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              nf[u] = (wf[u] >> (hf[u] & 31u)) & 1u, nr[u] = (wr[u] >> (hr[u] & 31u)) & 1u;
+              ff[u] = nf[u] ? 1u : 0u, fr[u] = nr[u] ? 1u : 0u;
             }
-            if (need_r) {
-              __builtin_memcpy(&qr, p.lookup + hr, 8);
-              fr = qr.y - qr.x;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              wf[u] = nf[u] ? p.multi[(hf[u] & kMultiMask) >> 5] : 0u;
+              wr[u] = nr[u] ? p.multi[(hr[u] & kMultiMask) >> 5] : 0u;
             }
-            big_freq |= (uint32_t)(ff > 254u || fr > 254u);
-            if (strand_ok[0]) sf[j] = make_uint2(hf, ff);
-            if (strand_ok[1]) sf[smax + (uint32_t)jr] = make_uint2(hr, fr);
-          } else {
-            if (need_f) __builtin_memcpy(&qf, p.lookup + hf, 8);
-            if (need_r) __builtin_memcpy(&qr, p.lookup + hr, 8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) nf[u] = (wf[u] >> (hf[u] & 31u)) & 1u, nr[u] = (wr[u] >> (hr[u] & 31u)) & 1u;
+          }
+          uint2 tf[2], tr[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            tf[u] = tr[u] = make_uint2(0u, 0u);
+            if (nf[u]) __builtin_memcpy(&tf[u], p.lookup + hf[u], 8);  // plain load: `nt` was measured 40 % slower here
+            if (nr[u]) __builtin_memcpy(&tr[u], p.lookup + hr[u], 8);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int j = j0 + u * kWave + (int)ln;
+            if (nf[u]) ff[u] = tf[u].y - tf[u].x;
+            if (nr[u]) fr[u] = tr[u].y - tr[u].x;
+            big_freq |= (uint32_t)(ff[u] > 254u || fr[u] > 254u);
+            if (in[u] && strand_ok[0]) sf[j] = make_uint2(hf[u], ff[u]);
+            if (in[u] && strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(hr[u], fr[u]);
+          }
+        }
+      } else {
+        for (int j0 = 0; j0 < S; j0 += kWave) {
+          const int j = j0 + (int)ln;
+          if (j < S) {
+            uint32_t hf, hr;
+            seed_hashes(j, hf, hr);
+            uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
+            if (strand_ok[0] && j <= last_used) __builtin_memcpy(&qf, p.lookup + hf, 8);
+            if (strand_ok[1] && S - 1 - j <= last_used) __builtin_memcpy(&qr, p.lookup + hr, 8);
             if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
-            if (strand_ok[1]) sf[smax + (uint32_t)jr] = make_uint2(qr.x, qr.y - qr.x);
+            if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
           }
         }
       }
