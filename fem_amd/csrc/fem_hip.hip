@@ -228,7 +228,9 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   }
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
-  l.blk_bytes = 0;  // (staging a block's characters helped by ~4 %, but its LDS costs a wave per SIMD with the group queue)
+  // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
+  // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
+  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 32u : 0u;
   l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;

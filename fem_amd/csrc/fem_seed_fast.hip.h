@@ -28,8 +28,9 @@ constexpr uint32_t kGroupQueue = 12;
 constexpr uint32_t kSmallStrand = 12, kQueueSeeds = 64;
 constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u + kReadBlock * 8u;  // seeds, the reads' lengths and pre-filter counts
 // LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
-constexpr uint32_t kFlEv = 0, kFlSv = 512, kFlMax = 1056, kFlFirst = 1568, kFlNval = 1824, kFlLen = 2080, kFlLast = 2336,
-                   kFlSlotN = 2592, kFlSlotFirst = 2720, kFlSlotLast = 2848, kFlushScratchBytes = 2976;
+// Arrays whose lifetimes do not overlap share words: gmax -> sv, own -> firstp, nval -> slot_n / slot_first, slen -> lastp.
+constexpr uint32_t kFlSv = 0, kFlMax = 0, kFlEv = 544, kFlFirst = 1056, kFlNval = 1312, kFlSlotN = 1312, kFlSlotFirst = 1440,
+                   kFlLen = 1568, kFlLast = 1568, kFlSlotLast = 1824, kFlushScratchBytes = 1952;
 
 // char -> 2-bit code for four bases at once.  code: per byte 0..3; nflag: per byte 1 where the base is not
 // A/C/G/T in either case (src/utils.h:72).
@@ -642,8 +643,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     uint32_t lo = 0, info = 0, f = 0;
     if (ln < n_seeds) lo = q_lo[ln], info = q_info[ln], f = (info >> 10) & 127u;
     const uint32_t at = wave_scan_add(f) - f;
-    own[ln] = 0, gmax[ln] = 0, nval[ln] = 0, slen[ln] = 0, lastp[ln] = 0;
-    if (ln < 32u) slot_n[ln] = 0;
+    own[ln] = 0, gmax[ln] = 0, nval[ln] = 0, slen[ln] = 0;
     wave_sync_lds();
     if (ln < n_seeds) own[at] = ln + 1u;
     wave_sync_lds();
@@ -680,6 +680,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     ev[ln] = v;
     wave_sync_lds();
     const uint32_t my_len = have ? slen[seg] : 0u, my_nval = have ? nval[seg] : 0u;
+    wave_sync_lds();  // slen[] and nval[] are read; their words become lastp[] and the slot arrays
+    lastp[ln] = 0;
+    if (ln < 32u) slot_n[ln] = 0;
     // rank inside the segment by (value, lane)
     const uint32_t pos = ln - seg_start;
     uint32_t rank = 0;
