@@ -1,15 +1,18 @@
-// fem_seed_fast.hip.h — the lean form of the seed + filter kernel for the parameters `FEM map` actually runs:
+// fem_seed_fast.hip.h — the seed + filter kernel for the parameters `FEM map` actually runs:
 // k = 12, step = 3 (reference src/FEM_map.c:67-68) and R = e + 1 + a fixed at compile time (1..10).
 //
-// One wavefront per read:
-//   encode     one unaligned dword (4 bases) per lane, SWAR char -> 2-bit code, packed into LDS
+// One wavefront per block of 16 reads.  Per read:
+//   encode     four characters per lane, SWAR char -> 2-bit code, packed into LDS
 //   hash       24-bit k-mer hash per lane from the packed words; reverse strand = reversed complement of the same hash
-//   lookup     one 8-byte load of lookup[h], lookup[h+1] per seed and strand            (src/index.h:22-28)
-//   select     seed-selection DP with DPP prefix-min + clz traceback                    (src/filter.c:3-43)
-//   lists      every occurrence of the selected seeds in one lane; last-seed rule, window filter and staged
-//              greedy de-dup on wave-uniform scalars; range clip; hand-over              (src/filter.c:80-144)
-// Reads that do not fit this shape (more than 64 occurrences selected on a strand, a DP group wider than 64
-// columns) are appended to a queue and done by the generic seed_filter_kernel.  Results are identical.
+//   lookup     frequency of every seed on both strands                                  (src/index.h:22-28)
+// then, in two forms:
+//   HASH (dense index, long occurrence lists): per read — seed-selection DP (DPP prefix-min, clz traceback,
+//     src/filter.c:3-43), lists in lanes or the hash-join form, staged greedy de-dup, range clip, hand-over
+//     (src/filter.c:45-144);
+//   lean (sparse index): the read only queues its live phase groups; select_flush runs DP + traceback for a dozen
+//     groups of several reads at once, flush_small finishes all queued reads' lists in one pass over the lanes.
+// Reads that do not fit (more than 64 occurrences selected, a DP group wider than 64 columns, ...) are appended to a
+// queue and done by the generic seed_filter_kernel.  Results are identical.
 #pragma once
 #include "fem_kernels.hip.h"
 
@@ -19,13 +22,12 @@ constexpr int kK = 12, kStep = 3, kLg = 4;
 constexpr uint32_t kHashMask = (1u << (2 * kK)) - 1u;
 constexpr uint32_t kReadBlock = 16;  // consecutive reads one wave takes at a time (seed_fast_kernel)
 constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast kernel did not handle
-// Small reads (lean form): a read whose strands select at most kSmallStrand occurrences each is not finished on its own
-// — its non-empty seeds wait in an LDS queue and a whole batch of reads is finished in one pass over the lanes
-// (flush_small).  Queue entry: lookup[h] and start | frequency << 10 | tag << 17, tag = read-in-block << 7 | strand << 6 |
-// group << 4 | run.
-// Live phase groups (lean form) wait as well: up to kGroupQueue of them, from several reads, are selected at once.
+// Lean form, queue of selected seeds: the non-empty seeds of several reads (at most kQueueSeeds, 64 occurrences) wait in
+// LDS until flush_small finishes all of them in one pass.  Entry: lookup[h] and start | frequency << 10 | tag << 17,
+// tag = read-in-block << 7 | strand << 6 | group << 4 | run.
+// Lean form, queue of live phase groups: up to kGroupQueue of them, from several reads, are selected at once.
 constexpr uint32_t kGroupQueue = 12;
-constexpr uint32_t kSmallStrand = 12, kQueueSeeds = 64;
+constexpr uint32_t kQueueSeeds = 64;
 constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u + kReadBlock * 8u;  // seeds, the reads' lengths and pre-filter counts
 // LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
 // Arrays whose lifetimes do not overlap share words: gmax -> sv, own -> firstp, nval -> slot_n / slot_first, slen -> lastp.
