@@ -207,7 +207,9 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   };
   l.pkw = take(l.n_words * 4u);
   l.nkw = take(l.n_words * 4u);
-  l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 8u));  // reused for the strands' candidates once the seeds are selected
+  // (hash, frequency) of every seed of both strands — hash-join form only: the lean form looks its seeds up straight
+  // into the group queue; reused for the strands' candidates once the seeds are selected
+  l.sf = take(hash ? std::max(2u * l.smax * 8u, 2u * 64u * 8u) : 2u * 64u * 8u);
   l.dp_bits = take(std::max(n_groups, femk::kGroupQueue) * R * 8u);  // one ballot per (pass, row); up to kGroupQueue passes
   if (hash) {
     l.X = take(64u * 8u);                 // scatter
@@ -226,8 +228,6 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
     l.gq_cap = std::max(384u, n_groups * n_used);
     l.gq = take(l.gq_cap * 4u + femk::kGroupQueue * 16u + 2u * 32u * 4u);
   }
-  // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
-  // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
   // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
   // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
   l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 32u : 0u;

@@ -1006,7 +1006,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
       // The DP of phase group si only ever looks at its first G - Lg + 1 seeds, G = (S - si) / step (row r spans columns
       // c + (r-1) Lg, c < C - 1): seeds behind the last one any group uses are not looked up.
-      uint32_t big_freq = 0;  // lean form: some bucket holds more than the group queue's 8-bit field takes
       int last_used = 0;
       for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
       // hash of seed j and of its reverse-strand partner S-1-j (bit-reversed complement: no second encode)
@@ -1019,60 +1018,132 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);  // pair order restored below
         hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
       };
+      // hash of the seed at offset j of strand `strand` (the reverse strand's seed j is the reversed complement of the
+      // forward seed at S-1-j)
+      auto strand_hash = [&](uint32_t strand, int j) -> uint32_t {
+        uint32_t hf, hr;
+        seed_hashes(strand ? S - 1 - j : j, hf, hr);
+        return strand ? hr : hf;
+      };
       if (!HASH) {
-        // lean form: (hash, frequency) per seed.  Empty buckets (bitmap) have 0, non-empty ones outside the folded
-        // filter exactly 1; only the others read the table.  lookup[h] itself is fetched for the selected seeds only.
-        // Two rounds of 64 seeds go through the three dependent levels together (bit tests, filter tests, table
-        // reads): the phase is latency-bound, and this halves its chain per read.
-        for (int j0 = 0; j0 < S; j0 += 2 * kWave) {
-          uint32_t hf[2], hr[2], ff[2] = {0, 0}, fr[2] = {0, 0};
-          bool in[2], nf[2], nr[2];
-          uint32_t wf[2], wr[2];
+        // ---- lean form: lookups by phase group, in two rounds (the phase is bound by the number of divergent loads) ----
+        // Round 1 tests only the seeds at columns 0 and 1 of every row: a group with a zero-cost selection among them
+        // contributes nothing (its minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0)
+        // — rows 1..s free at column 0 and rows s+1..R free at column 1 for some s.  Round 2 looks up all seeds of the
+        // other groups, straight into the group queue: hash << 8 | frequency.  Empty buckets (bitmap) have 0, non-empty
+        // ones outside the folded filter exactly 1; only the others read the table.
+        uint32_t live = 0;
+        if (p.nonempty) {
+          constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;          // (group, row) lanes of one column
+          constexpr uint32_t kColsPerTurn = 2u * kPer <= (uint32_t)kWave ? 2u : 1u;  // both columns at once if they fit
+          uint64_t z[2] = {0, 0};
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = j0 + u * kWave + (int)ln;
-            in[u] = j < S;
-            hf[u] = hr[u] = 0;
-            if (in[u]) seed_hashes(j, hf[u], hr[u]);
-            nf[u] = in[u] && strand_ok[0] && j <= last_used;
-            nr[u] = in[u] && strand_ok[1] && S - 1 - j <= last_used;
+          for (uint32_t c0 = 0; c0 < 2u; c0 += kColsPerTurn) {
+            const uint32_t col = c0 + ln / kPer, gl = ln % kPer;
+            const uint32_t tg = gl / (uint32_t)R, tr = gl % (uint32_t)R, t_strand = tg / (uint32_t)kStep, t_si = tg % (uint32_t)kStep;
+            const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
+            const bool t_in = ln < kColsPerTurn * kPer && strand_ok[t_strand & 1u] && col < t_cols;
+            bool empty = false;
+            if (t_in) {
+              const uint32_t h = strand_hash(t_strand, (int)(t_si + (uint32_t)kStep * ((uint32_t)kLg * tr + col)));
+              empty = !((p.nonempty[h >> 5] >> (h & 31u)) & 1u);
+            }
+            const uint64_t zb = __ballot(empty);
+            if (kColsPerTurn == 2u) {
+              z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
+            } else {
+              z[c0] = zb;
+            }
+          }
+          const uint32_t full = (1u << R) - 1u;
+          const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
+          const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
+          const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
+          const bool g_in = ln < 2u * (uint32_t)kStep && strand_ok[(ln / (uint32_t)kStep) & 1u];
+          live = (uint32_t)__ballot(g_in && !(from1 <= free0));
+        } else {
+          live = (strand_ok[0] ? 7u : 0u) | (strand_ok[1] ? 56u : 0u);
+        }
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
+        if (ln == 0) q_len[rb] = L;
+        const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
+        uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
+        // The live groups' seeds, one after the other, are the read's stretch of the queue: lane t of that stretch finds
+        // its group from the running totals.  kStreams x 64 of them go through the three dependent levels (bit test,
+        // filter test, table read) together.
+        uint32_t total = 0, g_first[2 * kStep], g_used[2 * kStep];
+#pragma unroll
+        for (uint32_t g = 0; g < 2u * (uint32_t)kStep; ++g) {
+          const uint32_t g_si = g % (uint32_t)kStep;
+          const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1);
+          const bool on = (live >> g) & 1u;
+          g_first[g] = total, g_used[g] = on ? ncols + (uint32_t)((R - 1) * kLg) : 0u;
+          if (on) {
+            if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries + total, g_used[g], ncols, (rb << 3) | ((g / (uint32_t)kStep) << 2) | g_si);
+            ++gq_groups;
+            gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
+          }
+          total += g_used[g];
+        }
+#ifndef FEM_LEAN_STREAMS
+#define FEM_LEAN_STREAMS 2
+#endif
+        constexpr int kStreams = FEM_LEAN_STREAMS;
+        for (uint32_t t0 = 0; t0 < total; t0 += (uint32_t)(kStreams * kWave)) {
+          uint32_t hh[kStreams], fq[kStreams], w1[kStreams];
+          bool act[kStreams], ne[kStreams];
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) {
+            const uint32_t t = t0 + (uint32_t)(v * kWave) + ln;
+            act[v] = t < total;
+            uint32_t gs = 0, first = 0;
+#pragma unroll
+            for (uint32_t g = 1; g < 2u * (uint32_t)kStep; ++g)
+              if (g_used[g] && t >= g_first[g]) gs = g, first = g_first[g];
+            const uint32_t g_strand = gs >= (uint32_t)kStep ? 1u : 0u, g_si = gs - g_strand * (uint32_t)kStep;
+            hh[v] = act[v] ? strand_hash(g_strand, (int)(g_si + (uint32_t)kStep * (t - first))) : 0u;
+            fq[v] = 0;
           }
           if (p.nonempty) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              wf[u] = nf[u] ? p.nonempty[hf[u] >> 5] : 0u;
-              wr[u] = nr[u] ? p.nonempty[hr[u] >> 5] : 0u;
+            for (int v = 0; v < kStreams; ++v) w1[v] = act[v] ? p.nonempty[hh[v] >> 5] : 0u;
+#pragma unroll
+            for (int v = 0; v < kStreams; ++v) {
+              ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;
+              fq[v] = ne[v] ? 1u : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              nf[u] = (wf[u] >> (hf[u] & 31u)) & 1u, nr[u] = (wr[u] >> (hr[u] & 31u)) & 1u;
-              ff[u] = nf[u] ? 1u : 0u, fr[u] = nr[u] ? 1u : 0u;
-            }
+            for (int v = 0; v < kStreams; ++v) w1[v] = ne[v] ? p.multi[(hh[v] & kMultiMask) >> 5] : 0u;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              wf[u] = nf[u] ? p.multi[(hf[u] & kMultiMask) >> 5] : 0u;
-              wr[u] = nr[u] ? p.multi[(hr[u] & kMultiMask) >> 5] : 0u;
-            }
+            for (int v = 0; v < kStreams; ++v) ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;  // now: the table has to be read
+          } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) nf[u] = (wf[u] >> (hf[u] & 31u)) & 1u, nr[u] = (wr[u] >> (hr[u] & 31u)) & 1u;
+            for (int v = 0; v < kStreams; ++v) ne[v] = act[v];
           }
-          uint2 tf[2], tr[2];
+          uint2 tb[kStreams];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            tf[u] = tr[u] = make_uint2(0u, 0u);
-            if (nf[u]) __builtin_memcpy(&tf[u], p.lookup + hf[u], 8);  // plain load: `nt` was measured 40 % slower here
-            if (nr[u]) __builtin_memcpy(&tr[u], p.lookup + hr[u], 8);
+          for (int v = 0; v < kStreams; ++v) {
+            tb[v] = make_uint2(0u, 0u);
+            if (ne[v]) __builtin_memcpy(&tb[v], p.lookup + hh[v], 8);  // plain load: `nt` was measured 40 % slower here
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = j0 + u * kWave + (int)ln;
-            if (nf[u]) ff[u] = tf[u].y - tf[u].x;
-            if (nr[u]) fr[u] = tr[u].y - tr[u].x;
-            big_freq |= (uint32_t)(ff[u] > 254u || fr[u] > 254u);
-            if (in[u] && strand_ok[0]) sf[j] = make_uint2(hf[u], ff[u]);
-            if (in[u] && strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(hr[u], fr[u]);
+          for (int v = 0; v < kStreams; ++v) {
+            if (ne[v]) fq[v] = tb[v].y - tb[v].x;
+            big_freq |= (uint32_t)(fq[v] > 254u);
+            if (act[v]) gq_row[gq_entries + t0 + (uint32_t)(v * kWave) + ln] = (hh[v] << 8) | (fq[v] & 255u);
           }
         }
+        gq_entries += total;
+        if (__any(big_freq != 0)) {  // the generic kernel takes the read: take its groups out of the queue again
+          gq_groups = groups_before, gq_entries = entries_before, gq_maxcols = maxcols_before;
+          if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+          slow = true;
+          break;
+        }
+        if (live) gq_reads |= 1u << rb;
+        wave_sync_lds();
+        selected = false;
+        break;
       } else {
         for (int j0 = 0; j0 < S; j0 += kWave) {
           const int j = j0 + (int)ln;
@@ -1093,48 +1164,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       selected = false;
       break;
 #endif
-      if (!HASH) {
-        if (__any(big_freq != 0)) {  // a bucket too full for the group queue's field: the generic kernel takes the read
-          slow = true;
-          break;
-        }
-        // A group with a zero-cost selection contributes nothing (its minimum is 0: whatever the traceback takes has no
-        // occurrences, and M[R][C-1] = 0).  Sufficient test on columns 0 and 1 of every row: rows 1..s free at column 0
-        // and rows s+1..R free at column 1 for some s.  The other groups are queued.
-        uint32_t live = 0;
-        {
-          const uint32_t tg = ln / (uint32_t)R, tr = ln % (uint32_t)R;
-          const uint32_t t_strand = (tg / (uint32_t)kStep) & 1u, t_si = tg % (uint32_t)kStep;
-          const bool t_in = ln < 2u * kSeeds && strand_ok[t_strand];
-          const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
-          const uint2 *t_sf = sf + t_strand * smax + t_si + (uint32_t)(kStep * kLg) * tr;
-          const uint64_t z0 = __ballot(t_in && t_sf[0].y == 0u), z1 = __ballot(t_in && t_cols > 1u && t_sf[t_in ? kStep : 0].y == 0u);
-          const uint32_t full = (1u << R) - 1u;
-          const uint32_t a0 = (uint32_t)(z0 >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z1 >> (ln * (uint32_t)R)) & full;
-          const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
-          const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
-          const bool g_in = ln < 2u * (uint32_t)kStep && strand_ok[(ln / (uint32_t)kStep) & 1u];
-          live = (uint32_t)__ballot(g_in && !(from1 <= free0));
-        }
-        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
-        if (ln == 0) q_len[rb] = L;
-        if (live) gq_reads |= 1u << rb;
-        for (uint32_t m = live; m; m &= m - 1u) {
-          const uint32_t g = (uint32_t)__builtin_ctz(m), g_strand = g / (uint32_t)kStep, g_si = g % (uint32_t)kStep;
-          const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1), n_used = ncols + (uint32_t)((R - 1) * kLg);
-          const uint2 *src = sf + g_strand * smax + g_si;
-          for (uint32_t i = ln; i < n_used; i += (uint32_t)kWave) {
-            const uint2 q = src[(uint32_t)kStep * i];
-            gq_row[gq_entries + i] = (q.x << 8) | q.y;
-          }
-          if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries, n_used, ncols, (rb << 3) | (g_strand << 2) | g_si);
-          gq_entries += n_used, ++gq_groups;
-          gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
-        }
-        wave_sync_lds();
-        selected = false;
-        break;
-      }
 
       // ---- seed selection ----
       const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
