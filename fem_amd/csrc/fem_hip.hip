@@ -205,8 +205,10 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
     o += (bytes + 15u) & ~15u;
     return at;
   };
-  l.pkw = take(l.n_words * 4u);
-  l.nkw = take(l.n_words * 4u);
+  if (hash) {  // (the lean form encodes a block of reads at once: strm)
+    l.pkw = take(l.n_words * 4u);
+    l.nkw = take(l.n_words * 4u);
+  }
   // (hash, frequency) of every seed of both strands — hash-join form only: the lean form looks its seeds up straight
   // into the group queue; reused for the strands' candidates once the seeds are selected
   l.sf = take(hash ? std::max(2u * l.smax * 8u, 2u * 64u * 8u) : 2u * 64u * 8u);
@@ -221,17 +223,24 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   }
   l.B = take(2u * femk::kReadBlock * 8u);  // the block's begin/count entries
   if (!hash) {
+    // One block of reads (kReadBlock consecutive ones, contiguous in the batch) is staged and encoded at once; blocks
+    // longer than this many characters (reads over 256 bases among them) go to the generic kernel.
+    const uint32_t blk_chars = femk::kReadBlock * std::min(max_len, 256u);
+    l.strm_words = blk_chars / 16u + 3u;
+    l.strm = take(3u * l.strm_words * 4u);
+    const uint32_t q_at = o;
     l.F = take(femk::kQueueBytes);  // queue of small reads' seeds
     // queue of live phase groups: a read may add all six of its groups, each with G - Lg + 1 words
     const uint32_t g0 = l.smax / (uint32_t)femk::kStep;
     const uint32_t n_used = g0 > (uint32_t)femk::kLg ? g0 - (uint32_t)femk::kLg + 1u : 1u;
     l.gq_cap = std::max(384u, n_groups * n_used);
     l.gq = take(l.gq_cap * 4u + femk::kGroupQueue * 16u + 2u * 32u * 4u);
+    // the block's raw characters (+ slack for the 16-byte copies) are dead once the streams exist, and both queues
+    // are empty at that point: they share the space
+    l.blk_bytes = blk_chars + 32u;
+    l.blk = q_at;
+    if (o < q_at + l.blk_bytes) take(q_at + l.blk_bytes - o);
   }
-  // raw characters of one block of reads (+ slack for the 16-byte copy and the two-word reads), short reads only
-  // (not with the hash-join form: its LDS already limits the waves per CU and the join, not the read, sets its pace)
-  l.blk_bytes = !hash && max_len <= 256u ? femk::kReadBlock * max_len + 32u : 0u;
-  l.blk = take(l.blk_bytes);
   if (hash) {              // hash-join form: open-addressing table; xcap = most occurrences one group may select
     l.xcap = (uint32_t)femk::bloom_chunks((int)R) * 64u;
     l.F = take(femk::bloom_slots((int)R) / 16u * 4u);  // bitmap: two bits per key slot

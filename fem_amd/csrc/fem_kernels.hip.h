@@ -45,6 +45,8 @@ struct SeedLayout {
   uint32_t n_words;
   uint32_t blk, blk_bytes;   // seed_fast_kernel: the raw characters of one block of reads (0 bytes: not staged)
   uint32_t gq, gq_cap;       // seed_fast_kernel, lean form: queue of live phase groups (rows of gq_cap words, then descriptors)
+  uint32_t strm, strm_words; // seed_fast_kernel, lean form: three 2-bit streams over one block of reads (forward bases,
+                             // their reverse complement, N marks), strm_words words each, a pad word at either end included
   uint32_t wave_bytes;
 };
 

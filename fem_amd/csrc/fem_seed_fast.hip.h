@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   uint64_t *scatter = (uint64_t *)(wbase + p.lay.X);
   uint32_t *bloom = (uint32_t *)(wbase + p.lay.F);  // HASH only: two bits per key slot, kept all-zero between groups
   uint8_t *blk_chars = wbase + p.lay.blk;
+  uint32_t *strm_fwd = (uint32_t *)(wbase + p.lay.strm), *strm_rev = strm_fwd + p.lay.strm_words, *strm_n = strm_rev + p.lay.strm_words;
   uint8_t *list_scratch = wbase + p.lay.A;
   uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
   uint64_t *cand_lds = (uint64_t *)(wbase + p.lay.sf);  // 2 x 64 candidates; the seed table's region holds at least that
@@ -897,26 +898,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   // begin / count of the block's 2 * kReadBlock (read, strand) entries gather in LDS and go out in one vector store;
   // kBlkSkip marks reads left to the generic kernel (it writes their entries)
   blk_entries[ln] = make_uint2(kBlkSkip, 0u);
-  // The block's characters are contiguous: one coalesced copy into LDS pays the HBM latency once for the whole
-  // block instead of once per read (each read otherwise starts with a dependent, mostly line-missing load).
-  const bool staged = p.lay.blk_bytes != 0;
   const uint64_t blk_base = p.read_off[r0];
-  if (staged) {
+  // Lean form.  The block's characters are contiguous: one coalesced copy into LDS pays the HBM latency once for the
+  // whole block, and the whole block is encoded at once (every lane busy, no per-read loop) into three 2-bit streams
+  // of 16 bases per word, first base in the top bits: the bases (N as A, src/utils.h:92), their reverse complement
+  // (the block read backwards; N as A again) and the N marks.  A seed's hash on either strand is then a 24-bit window
+  // of one stream.  Blocks too long for the staging space go to the generic kernel.
+  bool blk_ok = false, blk_has_n = false;
+  uint32_t n_stream = 0;  // bases per stream
+  if (!HASH) {
     const uint32_t r_hi = r0 + kReadBlock < p.n_reads ? r0 + kReadBlock : p.n_reads;
-    const uint32_t nbytes = (uint32_t)(p.read_off[r_hi] - blk_base);  // <= kReadBlock * max_len
-    wave_sync_lds();  // the previous block's last reader is done
+    const uint64_t nbytes64 = p.read_off[r_hi] - blk_base;
+    blk_ok = nbytes64 + 32u <= (uint64_t)p.lay.blk_bytes;
+    wave_sync_lds();  // the previous block's last reader is done (the staging space is the queues', both empty now)
+    if (blk_ok) {
+      const uint32_t nbytes = (uint32_t)nbytes64;
 #pragma unroll 1
-    for (uint32_t i = ln * 16u; i < nbytes + 16u; i += (uint32_t)kWave * 16u)  // 64 bytes of slack behind the batch's bases
-      *(uint4 *)(blk_chars + i) = load_u128_unaligned(p.bases + blk_base + i);
-    wave_sync_lds();
+      for (uint32_t i = ln * 16u; i < nbytes + 16u; i += (uint32_t)kWave * 16u)  // 64 bytes of slack behind the batch's bases
+        *(uint4 *)(blk_chars + i) = load_u128_unaligned(p.bases + blk_base + i);
+      wave_sync_lds();
+      const uint32_t nw = nbytes / 16u + 1u;
+      n_stream = 16u * nw;
+      uint32_t any_n = 0;
+#pragma unroll 1
+      for (uint32_t m = ln; m < 4u * nw; m += (uint32_t)kWave) {  // four characters -> one byte of each stream
+        uint32_t code, nflag;
+        encode4(*(const uint32_t *)(blk_chars + 4u * m), code, nflag);
+        const uint32_t nb = 4u * m < nbytes ? nbytes - 4u * m : 0u;
+        nflag &= nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+        code &= ~(nflag * 3u);
+        const uint32_t byte_addr = 4u + (m & ~3u) + (3u - (m & 3u));  // big-endian inside each word; word 0 is padding
+        ((uint8_t *)strm_fwd)[byte_addr] = (uint8_t)pack4(code);
+        ((uint8_t *)strm_n)[byte_addr] = (uint8_t)pack4(nflag * 3u);
+        any_n |= nflag;
+      }
+      blk_has_n = __any(any_n != 0);
+      wave_sync_lds();
+#pragma unroll 1
+      for (uint32_t w = ln; w < nw; w += (uint32_t)kWave) {
+        const uint32_t r = __brev(~strm_fwd[nw - w] & ~strm_n[nw - w]);  // base order reversed; the pairs' bits swap back below
+        strm_rev[1u + w] = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+      }
+      wave_sync_lds();
+    }
   }
-  // four characters at any byte offset of the staged block
-  auto chars_at = [&](uint64_t off, uint32_t idx) -> uint32_t {
-    if (!staged) return load_u32_unaligned(p.bases + off + idx);
-    const uint32_t a = (uint32_t)(off - blk_base) + idx;
-    const uint32_t *w = (const uint32_t *)(blk_chars + (a & ~3u));
-    return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
-  };
+  // HASH form: four characters of a read at any byte offset
+  auto chars_at = [&](uint64_t off, uint32_t idx) -> uint32_t { return load_u32_unaligned(p.bases + off + idx); };
   // One extra turn after the block's last read flushes the queue of small reads; flush_small and finish_read are
   // called from one place each (they are large, and inlined).
   for (uint32_t rb = 0;; ++rb) {
@@ -932,6 +959,157 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       const uint32_t g0 = S > 0 ? (uint32_t)S / (uint32_t)kStep : 0u;
       const uint32_t worst = 2u * (uint32_t)kStep * (g0 > (uint32_t)kLg ? g0 - (uint32_t)kLg + 1u : 1u);
       if (tail_turn || gq_groups + 2u * (uint32_t)kStep > kGroups || gq_entries + worst > p.lay.gq_cap) select_flush(r0, tail_turn);
+      if (tail_turn) break;
+      // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
+      bool shape_ok = S > 0 && R <= S / kStep;
+      if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
+      if (!shape_ok) {
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // both entries stay 0
+        continue;
+      }
+      if ((uint32_t)(S / kStep - R * kLg + 1) > (uint32_t)kWave || (uint32_t)S > smax || !blk_ok) {  // (columns of phase group 0)
+        queue_slow(read);
+        continue;
+      }
+      const uint32_t a = (uint32_t)(off - blk_base);
+      // ambiguous-base gate (src/utils.h:108-114, src/filter.c:180-182): N at offsets >= k, counted on either strand
+      bool ok0 = true, ok1 = true;
+      if (blk_has_n) {
+        uint32_t n_fwd_amb = 0, n_rev_amb = 0;
+        for (uint32_t c0 = 0; c0 < L; c0 += (uint32_t)kWave) {
+          const uint32_t c = c0 + ln, pos = a + c;
+          const bool is_n = c < L && ((strm_n[1u + (pos >> 4)] >> (30u - 2u * (pos & 15u))) & 1u);
+          n_fwd_amb += (uint32_t)__popcll(__ballot(is_n && c >= (uint32_t)kK));
+          n_rev_amb += (uint32_t)__popcll(__ballot(is_n && L - 1u - c >= (uint32_t)kK));
+        }
+        ok0 = n_fwd_amb <= (uint32_t)p.e, ok1 = n_rev_amb <= (uint32_t)p.e;
+      }
+      // Stream position of seed 0 of either strand (the reverse strand's seed j is the window that starts j bases
+      // behind the reversed read's start; its stream lies strm_words words behind the forward one), and the hash of
+      // the seed at a position: the 24 bits that end 2 (pos + k) bits into the stream.
+      const uint32_t org0 = a, org1 = 16u * p.lay.strm_words + n_stream - a - L;
+      auto stream_hash = [&](uint32_t pos) -> uint32_t {
+        const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
+        const uint32_t *st = strm_fwd + ((end2 - 1u) >> 5);  // st[0], st[1]: the word before the one the window ends in, and that one
+        return __builtin_amdgcn_alignbit(st[0], st[1], 0u - end2) & kHashMask;
+      };
+      // ---- lean form: lookups by phase group, in two rounds (the phase is bound by the number of divergent loads) ----
+      // Round 1 tests only the seeds at columns 0 and 1 of every row: a group with a zero-cost selection among them
+      // contributes nothing (its minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0)
+      // — rows 1..s free at column 0 and rows s+1..R free at column 1 for some s.  Round 2 looks up all seeds of the
+      // other groups, straight into the group queue: hash << 8 | frequency.  Empty buckets (bitmap) have 0, non-empty
+      // ones outside the folded filter exactly 1; only the others read the table.
+      uint32_t live = 0;
+      if (p.nonempty) {
+        constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;          // (group, row) lanes of one column
+        constexpr uint32_t kColsPerTurn = 2u * kPer <= (uint32_t)kWave ? 2u : 1u;  // both columns at once if they fit
+        uint64_t z[2] = {0, 0};
+#pragma unroll
+        for (uint32_t c0 = 0; c0 < 2u; c0 += kColsPerTurn) {
+          const uint32_t col = c0 + ln / kPer, gl = ln % kPer;
+          const uint32_t tg = gl / (uint32_t)R, tr = gl % (uint32_t)R, t_strand = tg / (uint32_t)kStep, t_si = tg % (uint32_t)kStep;
+          const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
+          const bool t_in = ln < kColsPerTurn * kPer && ((t_strand & 1u) ? ok1 : ok0) && col < t_cols;
+          bool empty = false;
+          if (t_in) {
+            const uint32_t h = stream_hash((t_strand ? org1 : org0) + t_si + (uint32_t)kStep * ((uint32_t)kLg * tr + col));
+            empty = !((p.nonempty[h >> 5] >> (h & 31u)) & 1u);
+          }
+          const uint64_t zb = __ballot(empty);
+          if (kColsPerTurn == 2u) {
+            z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
+          } else {
+            z[c0] = zb;
+          }
+        }
+        const uint32_t full = (1u << R) - 1u;
+        const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
+        const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
+        const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
+        const bool g_in = ln < 2u * (uint32_t)kStep && (ln >= (uint32_t)kStep ? ok1 : ok0);
+        live = (uint32_t)__ballot(g_in && !(from1 <= free0));
+      } else {
+        live = (ok0 ? 7u : 0u) | (ok1 ? 56u : 0u);
+      }
+      if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
+      if (ln == 0) q_len[rb] = L;
+      const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
+      uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
+      // The live groups' seeds, one after the other, are the read's stretch of the queue: lane t of that stretch finds
+      // its group from the running totals.  kStreams x 64 of them go through the three dependent levels (bit test,
+      // filter test, table read) together.
+      uint32_t total = 0, g_first[2 * kStep], g_used[2 * kStep];
+#pragma unroll
+      for (uint32_t g = 0; g < 2u * (uint32_t)kStep; ++g) {
+        const uint32_t g_si = g % (uint32_t)kStep;
+        const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1);
+        const bool on = (live >> g) & 1u;
+        g_first[g] = total, g_used[g] = on ? ncols + (uint32_t)((R - 1) * kLg) : 0u;
+        if (on) {
+          if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries + total, g_used[g], ncols, (rb << 3) | ((g / (uint32_t)kStep) << 2) | g_si);
+          ++gq_groups;
+          gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
+        }
+        total += g_used[g];
+      }
+#ifndef FEM_LEAN_STREAMS
+#define FEM_LEAN_STREAMS 2
+#endif
+      constexpr int kStreams = FEM_LEAN_STREAMS;
+      for (uint32_t t0 = 0; t0 < total; t0 += (uint32_t)(kStreams * kWave)) {
+        uint32_t hh[kStreams], fq[kStreams], w1[kStreams];
+        bool act[kStreams], ne[kStreams];
+#pragma unroll
+        for (int v = 0; v < kStreams; ++v) {
+          const uint32_t t = t0 + (uint32_t)(v * kWave) + ln;
+          act[v] = t < total;
+          uint32_t gs = 0, first = 0;
+#pragma unroll
+          for (uint32_t g = 1; g < 2u * (uint32_t)kStep; ++g)
+            if (g_used[g] && t >= g_first[g]) gs = g, first = g_first[g];
+          const uint32_t g_strand = gs >= (uint32_t)kStep ? 1u : 0u, g_si = gs - g_strand * (uint32_t)kStep;
+          hh[v] = act[v] ? stream_hash((g_strand ? org1 : org0) + g_si + (uint32_t)kStep * (t - first)) : 0u;
+          fq[v] = 0;
+        }
+        if (p.nonempty) {
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) w1[v] = act[v] ? p.nonempty[hh[v] >> 5] : 0u;
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) {
+            ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;
+            fq[v] = ne[v] ? 1u : 0u;
+          }
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) w1[v] = ne[v] ? p.multi[(hh[v] & kMultiMask) >> 5] : 0u;
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;  // now: the table has to be read
+        } else {
+#pragma unroll
+          for (int v = 0; v < kStreams; ++v) ne[v] = act[v];
+        }
+        uint2 tb[kStreams];
+#pragma unroll
+        for (int v = 0; v < kStreams; ++v) {
+          tb[v] = make_uint2(0u, 0u);
+          if (ne[v]) __builtin_memcpy(&tb[v], p.lookup + hh[v], 8);  // plain load: `nt` was measured 40 % slower here
+        }
+#pragma unroll
+        for (int v = 0; v < kStreams; ++v) {
+          if (ne[v]) fq[v] = tb[v].y - tb[v].x;
+          big_freq |= (uint32_t)(fq[v] > 254u);
+          if (act[v]) gq_row[gq_entries + t0 + (uint32_t)(v * kWave) + ln] = (hh[v] << 8) | (fq[v] & 255u);
+        }
+      }
+      gq_entries += total;
+      if (__any(big_freq != 0)) {  // the generic kernel takes the read: take its groups out of the queue again
+        gq_groups = groups_before, gq_entries = entries_before, gq_maxcols = maxcols_before;
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+        queue_slow(read);
+        continue;
+      }
+      if (live) gq_reads |= 1u << rb;
+      wave_sync_lds();
+      continue;
     }
     if (tail_turn) break;
     bool slow = false, selected = false;  // selected: seeds are in the lanes (or the read is `slow`)
@@ -1018,133 +1196,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);  // pair order restored below
         hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
       };
-      // hash of the seed at offset j of strand `strand` (the reverse strand's seed j is the reversed complement of the
-      // forward seed at S-1-j)
-      auto strand_hash = [&](uint32_t strand, int j) -> uint32_t {
-        uint32_t hf, hr;
-        seed_hashes(strand ? S - 1 - j : j, hf, hr);
-        return strand ? hr : hf;
-      };
-      if (!HASH) {
-        // ---- lean form: lookups by phase group, in two rounds (the phase is bound by the number of divergent loads) ----
-        // Round 1 tests only the seeds at columns 0 and 1 of every row: a group with a zero-cost selection among them
-        // contributes nothing (its minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0)
-        // — rows 1..s free at column 0 and rows s+1..R free at column 1 for some s.  Round 2 looks up all seeds of the
-        // other groups, straight into the group queue: hash << 8 | frequency.  Empty buckets (bitmap) have 0, non-empty
-        // ones outside the folded filter exactly 1; only the others read the table.
-        uint32_t live = 0;
-        if (p.nonempty) {
-          constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;          // (group, row) lanes of one column
-          constexpr uint32_t kColsPerTurn = 2u * kPer <= (uint32_t)kWave ? 2u : 1u;  // both columns at once if they fit
-          uint64_t z[2] = {0, 0};
-#pragma unroll
-          for (uint32_t c0 = 0; c0 < 2u; c0 += kColsPerTurn) {
-            const uint32_t col = c0 + ln / kPer, gl = ln % kPer;
-            const uint32_t tg = gl / (uint32_t)R, tr = gl % (uint32_t)R, t_strand = tg / (uint32_t)kStep, t_si = tg % (uint32_t)kStep;
-            const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
-            const bool t_in = ln < kColsPerTurn * kPer && strand_ok[t_strand & 1u] && col < t_cols;
-            bool empty = false;
-            if (t_in) {
-              const uint32_t h = strand_hash(t_strand, (int)(t_si + (uint32_t)kStep * ((uint32_t)kLg * tr + col)));
-              empty = !((p.nonempty[h >> 5] >> (h & 31u)) & 1u);
-            }
-            const uint64_t zb = __ballot(empty);
-            if (kColsPerTurn == 2u) {
-              z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
-            } else {
-              z[c0] = zb;
-            }
-          }
-          const uint32_t full = (1u << R) - 1u;
-          const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
-          const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
-          const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
-          const bool g_in = ln < 2u * (uint32_t)kStep && strand_ok[(ln / (uint32_t)kStep) & 1u];
-          live = (uint32_t)__ballot(g_in && !(from1 <= free0));
-        } else {
-          live = (strand_ok[0] ? 7u : 0u) | (strand_ok[1] ? 56u : 0u);
-        }
-        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
-        if (ln == 0) q_len[rb] = L;
-        const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
-        uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
-        // The live groups' seeds, one after the other, are the read's stretch of the queue: lane t of that stretch finds
-        // its group from the running totals.  kStreams x 64 of them go through the three dependent levels (bit test,
-        // filter test, table read) together.
-        uint32_t total = 0, g_first[2 * kStep], g_used[2 * kStep];
-#pragma unroll
-        for (uint32_t g = 0; g < 2u * (uint32_t)kStep; ++g) {
-          const uint32_t g_si = g % (uint32_t)kStep;
-          const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1);
-          const bool on = (live >> g) & 1u;
-          g_first[g] = total, g_used[g] = on ? ncols + (uint32_t)((R - 1) * kLg) : 0u;
-          if (on) {
-            if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries + total, g_used[g], ncols, (rb << 3) | ((g / (uint32_t)kStep) << 2) | g_si);
-            ++gq_groups;
-            gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
-          }
-          total += g_used[g];
-        }
-#ifndef FEM_LEAN_STREAMS
-#define FEM_LEAN_STREAMS 2
-#endif
-        constexpr int kStreams = FEM_LEAN_STREAMS;
-        for (uint32_t t0 = 0; t0 < total; t0 += (uint32_t)(kStreams * kWave)) {
-          uint32_t hh[kStreams], fq[kStreams], w1[kStreams];
-          bool act[kStreams], ne[kStreams];
-#pragma unroll
-          for (int v = 0; v < kStreams; ++v) {
-            const uint32_t t = t0 + (uint32_t)(v * kWave) + ln;
-            act[v] = t < total;
-            uint32_t gs = 0, first = 0;
-#pragma unroll
-            for (uint32_t g = 1; g < 2u * (uint32_t)kStep; ++g)
-              if (g_used[g] && t >= g_first[g]) gs = g, first = g_first[g];
-            const uint32_t g_strand = gs >= (uint32_t)kStep ? 1u : 0u, g_si = gs - g_strand * (uint32_t)kStep;
-            hh[v] = act[v] ? strand_hash(g_strand, (int)(g_si + (uint32_t)kStep * (t - first))) : 0u;
-            fq[v] = 0;
-          }
-          if (p.nonempty) {
-#pragma unroll
-            for (int v = 0; v < kStreams; ++v) w1[v] = act[v] ? p.nonempty[hh[v] >> 5] : 0u;
-#pragma unroll
-            for (int v = 0; v < kStreams; ++v) {
-              ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;
-              fq[v] = ne[v] ? 1u : 0u;
-            }
-#pragma unroll
-            for (int v = 0; v < kStreams; ++v) w1[v] = ne[v] ? p.multi[(hh[v] & kMultiMask) >> 5] : 0u;
-#pragma unroll
-            for (int v = 0; v < kStreams; ++v) ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;  // now: the table has to be read
-          } else {
-#pragma unroll
-            for (int v = 0; v < kStreams; ++v) ne[v] = act[v];
-          }
-          uint2 tb[kStreams];
-#pragma unroll
-          for (int v = 0; v < kStreams; ++v) {
-            tb[v] = make_uint2(0u, 0u);
-            if (ne[v]) __builtin_memcpy(&tb[v], p.lookup + hh[v], 8);  // plain load: `nt` was measured 40 % slower here
-          }
-#pragma unroll
-          for (int v = 0; v < kStreams; ++v) {
-            if (ne[v]) fq[v] = tb[v].y - tb[v].x;
-            big_freq |= (uint32_t)(fq[v] > 254u);
-            if (act[v]) gq_row[gq_entries + t0 + (uint32_t)(v * kWave) + ln] = (hh[v] << 8) | (fq[v] & 255u);
-          }
-        }
-        gq_entries += total;
-        if (__any(big_freq != 0)) {  // the generic kernel takes the read: take its groups out of the queue again
-          gq_groups = groups_before, gq_entries = entries_before, gq_maxcols = maxcols_before;
-          if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
-          slow = true;
-          break;
-        }
-        if (live) gq_reads |= 1u << rb;
-        wave_sync_lds();
-        selected = false;
-        break;
-      } else {
+      {
         for (int j0 = 0; j0 < S; j0 += kWave) {
           const int j = j0 + (int)ln;
           if (j < S) {
