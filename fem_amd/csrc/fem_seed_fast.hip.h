@@ -1035,22 +1035,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       if (ln == 0) q_len[rb] = L;
       const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
       uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
-      // The live groups' seeds, one after the other, are the read's stretch of the queue: lane t of that stretch finds
-      // its group from the running totals.  kStreams x 64 of them go through the three dependent levels (bit test,
-      // filter test, table read) together.
-      uint32_t total = 0, g_first[2 * kStep], g_used[2 * kStep];
+      // The live groups' seeds, one after the other, are the read's stretch of the queue.  Lane g < 6 describes group g
+      // (its stretch starts behind the live groups before it); the stretches' starts and the stream position of their
+      // seed 0 are then broadcast, and lane t of the stretch finds its seed from them: position = base + step * t.
+      // kStreams x 64 of them go through the three dependent levels (bit test, filter test, table read) together.
+      uint32_t total = 0, g_first[2 * kStep], g_base[2 * kStep];
+      {
+        uint32_t used_of[kStep];  // seeds the DP of a phase group looks at: G - Lg + 1
 #pragma unroll
-      for (uint32_t g = 0; g < 2u * (uint32_t)kStep; ++g) {
-        const uint32_t g_si = g % (uint32_t)kStep;
-        const uint32_t ncols = (uint32_t)((S - (int)g_si) / kStep - R * kLg + 1);
-        const bool on = (live >> g) & 1u;
-        g_first[g] = total, g_used[g] = on ? ncols + (uint32_t)((R - 1) * kLg) : 0u;
-        if (on) {
-          if (ln == 0) gq_desc[gq_groups] = make_uint4(gq_entries + total, g_used[g], ncols, (rb << 3) | ((g / (uint32_t)kStep) << 2) | g_si);
-          ++gq_groups;
-          gq_maxcols = ncols > gq_maxcols ? ncols : gq_maxcols;
+        for (int si = 0; si < kStep; ++si) used_of[si] = (uint32_t)((S - si) / kStep - kLg + 1);
+        constexpr uint32_t kPhase0 = 1u | (1u << kStep);  // groups of phase 0, one per strand
+        const uint32_t below = live & ((1u << (ln & 31u)) - 1u);
+        uint32_t my_first = 0;
+#pragma unroll
+        for (int si = 0; si < kStep; ++si) {
+          my_first += used_of[si] * (uint32_t)__popc(below & (kPhase0 << si));
+          total += used_of[si] * (uint32_t)__popc(live & (kPhase0 << si));
         }
-        total += g_used[g];
+        const bool my_on = ln < 2u * (uint32_t)kStep && ((live >> ln) & 1u);
+        const uint32_t my_strand = ln >= (uint32_t)kStep ? 1u : 0u, my_si = ln - my_strand * (uint32_t)kStep;
+        const uint32_t my_used = my_si == 0 ? used_of[0] : my_si == 1 ? used_of[1] : used_of[2];
+        if (my_on)
+          gq_desc[gq_groups + (uint32_t)__popc(below)] =
+              make_uint4(gq_entries + my_first, my_used, my_used - (uint32_t)((R - 1) * kLg), (rb << 3) | (my_strand << 2) | my_si);
+        const uint32_t first_x = my_on ? my_first : 0xFFFFFFFFu;  // a dead group takes no lane
+        const uint32_t base_x = (my_strand ? org1 : org0) + my_si - (uint32_t)kStep * my_first;
+#pragma unroll
+        for (int g = 0; g < 2 * kStep; ++g) {
+          g_first[g] = (uint32_t)__builtin_amdgcn_readlane((int)first_x, g);
+          g_base[g] = (uint32_t)__builtin_amdgcn_readlane((int)base_x, g);
+        }
+        gq_groups += (uint32_t)__popc(live);
+        const uint32_t widest = used_of[0] - (uint32_t)((R - 1) * kLg);  // columns of phase group 0: no group has more
+        if (live) gq_maxcols = widest > gq_maxcols ? widest : gq_maxcols;
       }
 #ifndef FEM_LEAN_STREAMS
 #define FEM_LEAN_STREAMS 2
@@ -1063,12 +1080,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         for (int v = 0; v < kStreams; ++v) {
           const uint32_t t = t0 + (uint32_t)(v * kWave) + ln;
           act[v] = t < total;
-          uint32_t gs = 0, first = 0;
+          uint32_t base = g_base[0];
 #pragma unroll
-          for (uint32_t g = 1; g < 2u * (uint32_t)kStep; ++g)
-            if (g_used[g] && t >= g_first[g]) gs = g, first = g_first[g];
-          const uint32_t g_strand = gs >= (uint32_t)kStep ? 1u : 0u, g_si = gs - g_strand * (uint32_t)kStep;
-          hh[v] = act[v] ? stream_hash((g_strand ? org1 : org0) + g_si + (uint32_t)kStep * (t - first)) : 0u;
+          for (int g = 1; g < 2 * kStep; ++g) base = t >= g_first[g] ? g_base[g] : base;
+          hh[v] = act[v] ? stream_hash(base + (uint32_t)kStep * t) : 0u;
           fq[v] = 0;
         }
         if (p.nonempty) {
