@@ -88,8 +88,7 @@ struct fem_dev {
   uint64_t *d_occ = nullptr;
   uint64_t n_occ = 0;
   int32_t k = 0, step = 0;
-  uint32_t *d_nonempty = nullptr;  // bucket non-empty bitmap, built for sparse indexes only
-  uint32_t *d_multi = nullptr;     // folded filter of the buckets with two or more entries (same condition)
+  uint32_t *d_summary = nullptr;  // bucket summaries (femk::SeedParams::summary), built for sparse indexes only
   // reference
   uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
@@ -371,8 +370,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   sp.lay = make_layout(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
 
   sp.n_seq = h->n_seq;
-  sp.nonempty = h->d_nonempty;
-  sp.multi = h->d_multi;
+  sp.summary = h->d_summary;
   sp.slow_queue = s.d_slow, sp.slow_cap = s.slow_cap;
   sp.work_queue = nullptr;
   const int R = p.e + 1 + p.a;
@@ -470,22 +468,18 @@ int launch_batch(fem_dev *h, Slot &s) {
   return FEM_OK;
 }
 
-// After the index is resident: for sparse indexes build the bucket non-empty bitmap the fast seed kernel tests first.
-int refresh_nonempty(fem_dev *h) {
-  if (h->d_nonempty) (void)hipFree(h->d_nonempty);
-  if (h->d_multi) (void)hipFree(h->d_multi);
-  h->d_nonempty = nullptr, h->d_multi = nullptr;
+// After the index is resident: for sparse indexes build the bucket summaries the fast seed kernel tests first.
+int refresh_summary(fem_dev *h) {
+  if (h->d_summary) (void)hipFree(h->d_summary);
+  h->d_summary = nullptr;
   const uint64_t n_buckets = h->n_lookup - 1;
   // dense index: nearly every bucket is non-empty, the tests would not pay.  (Fewer than 2^31 entries also keeps bit
   // 31 of a lookup value free: the fast seed kernel tags deferred lookups with it.)
-  if (h->n_occ >= n_buckets || h->n_occ >= 0x80000000ull) return FEM_OK;
-  const uint64_t words = n_buckets / 32 + 2, multi_words = ((uint64_t)femk::kMultiMask + 1) / 32;
-  HIP_TRY(h, hipMalloc((void **)&h->d_nonempty, words * sizeof(uint32_t)));
-  HIP_TRY(h, hipMalloc((void **)&h->d_multi, multi_words * sizeof(uint32_t)));
-  HIP_TRY(h, hipMemset(h->d_nonempty, 0, words * sizeof(uint32_t)));
-  HIP_TRY(h, hipMemset(h->d_multi, 0, multi_words * sizeof(uint32_t)));
-  hipLaunchKernelGGL(femk::nonempty_bitmap_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, n_buckets,
-                     h->d_nonempty, h->d_multi);
+  if (h->n_occ >= n_buckets || h->n_occ >= 0x80000000ull || (n_buckets >> 3) >= (1ull << 22)) return FEM_OK;
+  const uint64_t words = n_buckets / femk::kSummaryBuckets + 2;
+  HIP_TRY(h, hipMalloc((void **)&h->d_summary, words * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemset(h->d_summary, 0, words * sizeof(uint32_t)));
+  hipLaunchKernelGGL(femk::bucket_summary_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, n_buckets, h->d_summary);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());
   return FEM_OK;
@@ -566,7 +560,7 @@ int fem_dev_close(fem_dev *h) {
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
-                  (void *)h->d_seq_len, (void *)h->d_nonempty, (void *)h->d_multi, (void *)h->d_plane[0], (void *)h->d_plane[1],
+                  (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
                   (void *)h->d_plane[2], (void *)h->d_plane[3]})
     if (p) (void)hipFree(p);
   delete h;
@@ -595,7 +589,7 @@ int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lo
   HIP_TRY(h, hipMemcpy(h->d_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (n_occ) HIP_TRY(h, hipMemcpy(h->d_occ, occ, n_occ * sizeof(uint64_t), hipMemcpyHostToDevice));
   h->n_lookup = n_lookup, h->n_occ = n_occ, h->k = k, h->step = step;
-  return refresh_nonempty(h);
+  return refresh_summary(h);
 }
 
 int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len) {
@@ -659,7 +653,7 @@ int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_ou
   int rc = femix::build_index(h->d_ref, h->seq_off, h->seq_len, k, step, h->n_cu, &h->d_lookup, &h->d_occ, &n_occ, &err);
   if (rc != FEM_OK) return fail(h, rc, err);
   h->n_lookup = (1ull << (2 * k)) + 1, h->n_occ = n_occ, h->k = k, h->step = step;
-  if ((rc = refresh_nonempty(h))) return rc;
+  if ((rc = refresh_summary(h))) return rc;
   if (n_occ_out) *n_occ_out = n_occ;
   if (lookup_out)
     HIP_TRY(h, hipMemcpy(lookup_out, h->d_lookup, h->n_lookup * sizeof(uint32_t), hipMemcpyDeviceToHost));

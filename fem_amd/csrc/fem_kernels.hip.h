@@ -71,14 +71,12 @@ struct SeedParams {
   uint32_t *slow_queue;        // written by seed_fast_kernel
   uint32_t slow_cap;
   const uint32_t *work_queue;  // read by seed_filter_kernel; nullptr = process every read of the batch
-  // one bit per hash bucket, set iff the bucket is non-empty (2 MiB for k = 12: stays in each XCD's L2).  Sparse
-  // indexes only (nullptr otherwise): most of the 2*(L-k+1) lookups per read then never touch the 64 MiB table.
-  const uint32_t *nonempty;
-  // Folded filter over the buckets with two or more entries: bit (h & kMultiMask) is set if ANY bucket with that
-  // residue holds >= 2.  A non-empty bucket whose bit is clear has frequency exactly 1 — all the seed-selection DP
-  // needs; lookup[h] is then fetched only for the few such seeds that end up selected.  256 KiB: it stays in L2 next
-  // to the 2 MiB non-empty bitmap (a full second bitmap would not).
-  const uint32_t *multi;
+  // Bucket summaries, one word per kSummaryBuckets = 24 consecutive hash buckets: bit r = bucket 24 q + r is non-empty;
+  // bit 24 + m = one of the buckets 24 q + 3 m .. 3 m + 2 holds two or more entries.  A non-empty bucket whose second
+  // bit is clear has frequency exactly 1 — all the seed-selection DP needs; lookup[h] is then fetched only for the few
+  // such seeds that end up selected.  One load answers both questions; 2.7 MiB for k = 12, which each XCD's L2 keeps.
+  // Sparse indexes only (nullptr otherwise): most of the lookups per read then never touch the 64 MiB table.
+  const uint32_t *summary;
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries
@@ -1227,21 +1225,25 @@ __global__ void ref_planes_kernel(const uint8_t *codes, const uint8_t *raw, uint
   }
 }
 
-constexpr uint32_t kMultiMask = (1u << 21) - 1u;  // bits of the folded "two or more entries" filter
+constexpr uint32_t kSummaryBuckets = 24;  // buckets per summary word (SeedParams::summary)
 
-// bit h of `bits` = (lookup[h+1] != lookup[h]); one lane per bucket, one ballot per 64 buckets.
-// Buckets with two or more entries also set their bit in the folded filter `multi` (zeroed by the caller).
-__global__ void nonempty_bitmap_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *bits, uint32_t *multi) {
+// summary word and bit positions of bucket h: q = h / 24 by a float multiply (exact for h >> 3 < 2^22, checked
+// exhaustively on the host: tests/test_host.py) — the integer multiplies are quarter rate
+__device__ __forceinline__ void summary_slot(uint32_t h, uint32_t &q, uint32_t &r) {
+  q = (uint32_t)((float)(h >> 3) * 0.33333334f);
+  r = h - kSummaryBuckets * q;
+}
+__device__ __forceinline__ bool summary_nonempty(uint32_t w, uint32_t r) { return (w >> r) & 1u; }
+__device__ __forceinline__ bool summary_multi(uint32_t w, uint32_t r) { return (w >> (kSummaryBuckets + ((r * 11u) >> 5))) & 1u; }  // r / 3
+
+// one lane per bucket; `summary` zeroed by the caller (n_buckets / 24 + 2 words)
+__global__ void bucket_summary_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *summary) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t h0 = (uint64_t)blockIdx.x * blockDim.x; h0 < n_buckets; h0 += stride) {
-    const uint64_t h = h0 + threadIdx.x;
-    const uint32_t f = h < n_buckets ? lookup[h + 1] - lookup[h] : 0u;
-    const uint64_t m = __ballot(f != 0u);
-    if ((threadIdx.x & 63u) == 0 && h < n_buckets) {  // h is a multiple of 64 here; the array has two spare words
-      bits[h >> 5] = (uint32_t)m;
-      bits[(h >> 5) + 1] = (uint32_t)(m >> 32);
-    }
-    if (f >= 2u) atomicOr(&multi[((uint32_t)h & kMultiMask) >> 5], 1u << (h & 31u));
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_buckets; h += stride) {
+    const uint32_t f = lookup[h + 1] - lookup[h];
+    if (f == 0u) continue;
+    const uint32_t q = (uint32_t)(h / kSummaryBuckets), r = (uint32_t)(h % kSummaryBuckets);
+    atomicOr(&summary[q], (1u << r) | (f >= 2u ? 1u << (kSummaryBuckets + r / 3u) : 0u));
   }
 }
 

@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       // other groups, straight into the group queue: hash << 8 | frequency.  Empty buckets (bitmap) have 0, non-empty
       // ones outside the folded filter exactly 1; only the others read the table.
       uint32_t live = 0;
-      if (p.nonempty) {
+      if (p.summary) {
         constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;          // (group, row) lanes of one column
         constexpr uint32_t kColsPerTurn = 2u * kPer <= (uint32_t)kWave ? 2u : 1u;  // both columns at once if they fit
         uint64_t z[2] = {0, 0};
@@ -1013,7 +1013,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
           bool empty = false;
           if (t_in) {
             const uint32_t h = stream_hash((t_strand ? org1 : org0) + t_si + (uint32_t)kStep * ((uint32_t)kLg * tr + col));
-            empty = !((p.nonempty[h >> 5] >> (h & 31u)) & 1u);
+            uint32_t q, r;
+            summary_slot(h, q, r);
+            empty = !summary_nonempty(p.summary[q], r);
           }
           const uint64_t zb = __ballot(empty);
           if (kColsPerTurn == 2u) {
@@ -1086,18 +1088,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
           hh[v] = act[v] ? stream_hash(base + (uint32_t)kStep * t) : 0u;
           fq[v] = 0;
         }
-        if (p.nonempty) {
-#pragma unroll
-          for (int v = 0; v < kStreams; ++v) w1[v] = act[v] ? p.nonempty[hh[v] >> 5] : 0u;
+        if (p.summary) {
+          uint32_t sr[kStreams];
 #pragma unroll
           for (int v = 0; v < kStreams; ++v) {
-            ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;
-            fq[v] = ne[v] ? 1u : 0u;
+            uint32_t q;
+            summary_slot(hh[v], q, sr[v]);
+            w1[v] = act[v] ? p.summary[q] : 0u;
           }
 #pragma unroll
-          for (int v = 0; v < kStreams; ++v) w1[v] = ne[v] ? p.multi[(hh[v] & kMultiMask) >> 5] : 0u;
-#pragma unroll
-          for (int v = 0; v < kStreams; ++v) ne[v] = (w1[v] >> (hh[v] & 31u)) & 1u;  // now: the table has to be read
+          for (int v = 0; v < kStreams; ++v) {
+            const bool some = summary_nonempty(w1[v], sr[v]);
+            fq[v] = some ? 1u : 0u;
+            ne[v] = some && summary_multi(w1[v], sr[v]);  // the table has to be read
+          }
         } else {
 #pragma unroll
           for (int v = 0; v < kStreams; ++v) ne[v] = act[v];

@@ -173,3 +173,14 @@ def test_synthetic_generator_is_reproducible_and_shardable():
     res = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offs), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
     assert res.stats[1] > 750
     assert 0.3 < np.mean(res.m_dir) < 0.7
+
+
+def test_summary_slot_arithmetic_is_exact():
+    """The seed kernel finds a bucket's summary word with q = uint32(float32(h >> 3) * 0.33333334f) (fem_kernels.hip.h,
+    summary_slot) and its "two or more" bit with (r * 11) >> 5: both must equal the integer divisions the table is built
+    with, for every bucket the table may cover (h >> 3 < 2^22)."""
+    x = np.arange(1 << 22, dtype=np.uint32)
+    q = (x.astype(np.float32) * np.float32(0.33333334)).astype(np.uint32)
+    assert np.array_equal(q, x // 3)
+    r = np.arange(24, dtype=np.uint32)
+    assert np.array_equal((r * 11) >> 5, r // 3)
