@@ -1072,7 +1072,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         if (live) gq_maxcols = widest > gq_maxcols ? widest : gq_maxcols;
       }
 #ifndef FEM_LEAN_STREAMS
-#define FEM_LEAN_STREAMS 2
+#define FEM_LEAN_STREAMS 1
 #endif
       constexpr int kStreams = FEM_LEAN_STREAMS;
       for (uint32_t t0 = 0; t0 < total; t0 += (uint32_t)(kStreams * kWave)) {
