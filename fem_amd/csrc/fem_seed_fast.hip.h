@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
   // begin / count of the block's 2 * kReadBlock (read, strand) entries gather in LDS and go out in one vector store;
   // kBlkSkip marks reads left to the generic kernel (it writes their entries)
-  blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+  if (HASH && ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
   const uint64_t blk_base = p.read_off[r0];
   // Lean form.  The block's characters are contiguous: one coalesced copy into LDS pays the HBM latency once for the
   // whole block, and the whole block is encoded at once (every lane busy, no per-read loop) into three 2-bit streams
@@ -942,6 +942,112 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       wave_sync_lds();
     }
   }
+  // Lean form, continued.  What each read of the block needs later is worked out for all of them at once, read rb in
+  // lanes 2 rb and 2 rb + 1 (the block's begin/count entries are two per read), and fetched with v_readlane when the
+  // read's turn comes: no scalar arithmetic, no dependent load of read_off per read.
+  uint32_t rd_org0 = 0, rd_org1 = 0, rd_used = 0, rd_flags = 0, rd_live = 0;
+  constexpr uint32_t kRdFast = 1u, kRdSlow = 2u;  // rd_flags; bits 2.. = column 1 exists in the groups of phase 0, 1, 2
+  if (!HASH) {
+    const uint32_t my_rb = ln >> 1, my_read = r0 + my_rb;
+    const bool in = my_rb < kReadBlock && my_read < p.n_reads;
+    uint64_t o0 = 0, o1 = 0;
+    if (in) o0 = p.read_off[my_read], o1 = p.read_off[my_read + 1];
+    const uint32_t L = (uint32_t)(o1 - o0);
+    const int S = (int)L - kK + 1;  // num_seeds_in_read
+    // gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined: both entries stay 0
+    bool shape_ok = in && S > 0 && R <= S / kStep;
+    if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
+    // DP wider than a wave (columns of phase group 0), or no streams: the generic kernel's
+    const bool too_wide = (uint32_t)(S / kStep - R * kLg + 1) > (uint32_t)kWave || (uint32_t)S > smax || !blk_ok;
+    const uint32_t a = (uint32_t)(o0 - blk_base);
+    // Stream position of seed 0 of either strand: the reverse strand's seed j is the window that starts j bases
+    // behind the reversed read's start; its stream lies strm_words words behind the forward one.
+    rd_org0 = a, rd_org1 = 16u * p.lay.strm_words + n_stream - a - L;
+    if (shape_ok && !too_wide) {
+      rd_flags = kRdFast;
+#pragma unroll
+      for (int si = 0; si < kStep; ++si) {
+        const uint32_t used = (uint32_t)((S - si) / kStep - kLg + 1);  // seeds the DP of a phase group looks at: G - Lg + 1
+        rd_used |= used << (8 * si);                                   // (<= 64 + (R - 1) Lg < 256)
+        rd_flags |= (uint32_t)(used - (uint32_t)((R - 1) * kLg) > 1u) << (2 + si);
+      }
+    } else if (shape_ok) {
+      rd_flags = kRdSlow;
+    }
+    if (ln < 2u * kReadBlock) {
+      // begin / count stay 0 unless flush_small finds a candidate; kBlkSkip: the generic kernel (or nobody) writes them
+      blk_entries[ln] = make_uint2(in && !(rd_flags & kRdSlow) ? 0u : kBlkSkip, 0u);
+      if (in && !(ln & 1u)) q_len[my_rb] = L;
+    }
+    wave_sync_lds();
+    // ---- round 1 of the lookups, for every read of the block: which phase groups can contribute at all ----
+    // A group with a zero-cost selection among the seeds at columns 0 and 1 of every row contributes nothing (its
+    // minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0) — rows 1..s free at column 0
+    // and rows s+1..R free at column 1 for some s.  Only those seeds are tested here, kRound1Batch reads' loads in
+    // flight together; round 2, at the read's turn, looks up all seeds of the other ("live") groups.
+    constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;                  // (group, row) lanes of one column
+    constexpr uint32_t kTurns = 2u * kPer <= (uint32_t)kWave ? 1u : 2u;           // both columns at once if they fit
+    constexpr uint32_t kRound1Batch = 4u / kTurns;
+    const uint32_t t_col = kTurns == 1u ? ln / kPer : 0u, t_gl = ln % kPer;        // (kTurns == 2: column = turn)
+    const uint32_t t_g = t_gl / (uint32_t)R, t_row = t_gl % (uint32_t)R, t_strand = t_g / (uint32_t)kStep, t_si = t_g % (uint32_t)kStep;
+    const bool t_lane = ln < (2u / kTurns) * kPer;
+    const uint32_t t_ofs = t_si + (uint32_t)kStep * ((uint32_t)kLg * t_row + t_col);  // seed offset on its strand, column 0 or t_col
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < kReadBlock && r0 + b0 < p.n_reads; b0 += kRound1Batch) {
+      uint32_t w[kRound1Batch][kTurns], sr[kRound1Batch][kTurns], okm[kRound1Batch];
+#pragma unroll
+      for (uint32_t u = 0; u < kRound1Batch; ++u) {
+        const int sel = (int)(2u * (b0 + u));
+        const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)rd_flags, sel);
+        const uint32_t org0 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org0, sel), org1 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org1, sel);
+        okm[u] = (flags & kRdFast) ? 63u : 0u;
+        if ((flags & kRdFast) && blk_has_n) {
+          // ambiguous-base gate (src/utils.h:108-114, src/filter.c:180-182): N at offsets >= k, counted on either strand
+          const uint32_t len = bcast0(q_len[b0 + u]);
+          uint32_t n_fwd_amb = 0, n_rev_amb = 0;
+          for (uint32_t c0 = 0; c0 < len; c0 += (uint32_t)kWave) {
+            const uint32_t c = c0 + ln, pos = org0 + c;
+            const bool is_n = c < len && ((strm_n[1u + (pos >> 4)] >> (30u - 2u * (pos & 15u))) & 1u);
+            n_fwd_amb += (uint32_t)__popcll(__ballot(is_n && c >= (uint32_t)kK));
+            n_rev_amb += (uint32_t)__popcll(__ballot(is_n && len - 1u - c >= (uint32_t)kK));
+          }
+          okm[u] = (n_fwd_amb <= (uint32_t)p.e ? 7u : 0u) | (n_rev_amb <= (uint32_t)p.e ? 56u : 0u);
+        }
+#pragma unroll
+        for (uint32_t turn = 0; turn < kTurns; ++turn) {
+          const uint32_t col = kTurns == 1u ? t_col : turn;
+          const bool t_in = p.summary && t_lane && okm[u] != 0u && (col == 0u || ((flags >> (2u + t_si)) & 1u));
+          w[u][turn] = 0xFFFFFFFFu, sr[u][turn] = 0;  // (not tested: not empty)
+          if (t_in) {
+            const uint32_t pos = (t_strand ? org1 : org0) + t_ofs + (kTurns == 1u ? 0u : (uint32_t)kStep * turn);
+            const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
+            const uint32_t *st = strm_fwd + ((end2 - 1u) >> 5);
+            const uint32_t h = __builtin_amdgcn_alignbit(st[0], st[1], 0u - end2) & kHashMask;
+            uint32_t q;
+            summary_slot(h, q, sr[u][turn]);
+            w[u][turn] = p.summary[q];
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kRound1Batch; ++u) {
+        uint64_t z[2];
+        if (kTurns == 1u) {
+          const uint64_t zb = __ballot(!summary_nonempty(w[u][0], sr[u][0]));
+          z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
+        } else {
+          z[0] = __ballot(!summary_nonempty(w[u][0], sr[u][0]));
+          z[1] = __ballot(!summary_nonempty(w[u][kTurns - 1u], sr[u][kTurns - 1u]));
+        }
+        const uint32_t full = (1u << R) - 1u;
+        const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
+        const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
+        const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
+        const uint32_t live = (uint32_t)__ballot(ln < 2u * (uint32_t)kStep && !(from1 <= free0)) & okm[u];
+        rd_live = my_rb == b0 + u ? live : rd_live;
+      }
+    }
+  }
   // HASH form: four characters of a read at any byte offset
   auto chars_at = [&](uint64_t off, uint32_t idx) -> uint32_t { return load_u32_unaligned(p.bases + off + idx); };
   // One extra turn after the block's last read flushes the queue of small reads; flush_small and finish_read are
@@ -951,109 +1057,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     const uint32_t read = r0 + rb;
     uint64_t off = 0;
     uint32_t L = 0;
-    if (!tail_turn) off = p.read_off[read], L = (uint32_t)(p.read_off[read + 1] - off);
+    if (HASH && !tail_turn) off = p.read_off[read], L = (uint32_t)(p.read_off[read + 1] - off);
     const int S = (int)L - kK + 1;  // num_seeds_in_read
     if (!HASH) {
-      // the queues are flushed while no read is in flight: before a read whose six groups might not fit, and at the
-      // block's end
-      const uint32_t g0 = S > 0 ? (uint32_t)S / (uint32_t)kStep : 0u;
-      const uint32_t worst = 2u * (uint32_t)kStep * (g0 > (uint32_t)kLg ? g0 - (uint32_t)kLg + 1u : 1u);
-      if (tail_turn || gq_groups + 2u * (uint32_t)kStep > kGroups || gq_entries + worst > p.lay.gq_cap) select_flush(r0, tail_turn);
-      if (tail_turn) break;
-      // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
-      bool shape_ok = S > 0 && R <= S / kStep;
-      if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
-      if (!shape_ok) {
-        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // both entries stay 0
-        continue;
+      const int sel = (int)(2u * (rb & (kReadBlock - 1u)));  // a lane with the read's parameters
+      const uint32_t live = tail_turn ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)rd_live, sel);
+      uint32_t used_of[kStep], total = 0;  // seeds of a group of each phase, and of all live groups
+      {
+        const uint32_t used_w = (uint32_t)__builtin_amdgcn_readlane((int)rd_used, sel);
+        constexpr uint32_t kPhase0 = 1u | (1u << kStep);  // groups of phase 0, one per strand
+#pragma unroll
+        for (int si = 0; si < kStep; ++si) {
+          used_of[si] = (used_w >> (8 * si)) & 255u;
+          total += used_of[si] * (uint32_t)__popc(live & (kPhase0 << si));
+        }
       }
-      if ((uint32_t)(S / kStep - R * kLg + 1) > (uint32_t)kWave || (uint32_t)S > smax || !blk_ok) {  // (columns of phase group 0)
+      // the queues are flushed while no read is in flight: before a read whose live groups do not fit, and at the
+      // block's end
+      if (tail_turn || gq_groups + (uint32_t)__popc(live) > kGroups || gq_entries + total > p.lay.gq_cap) select_flush(r0, tail_turn);
+      if (tail_turn) break;
+      if ((uint32_t)__builtin_amdgcn_readlane((int)rd_flags, sel) & kRdSlow) {
         queue_slow(read);
         continue;
       }
-      const uint32_t a = (uint32_t)(off - blk_base);
-      // ambiguous-base gate (src/utils.h:108-114, src/filter.c:180-182): N at offsets >= k, counted on either strand
-      bool ok0 = true, ok1 = true;
-      if (blk_has_n) {
-        uint32_t n_fwd_amb = 0, n_rev_amb = 0;
-        for (uint32_t c0 = 0; c0 < L; c0 += (uint32_t)kWave) {
-          const uint32_t c = c0 + ln, pos = a + c;
-          const bool is_n = c < L && ((strm_n[1u + (pos >> 4)] >> (30u - 2u * (pos & 15u))) & 1u);
-          n_fwd_amb += (uint32_t)__popcll(__ballot(is_n && c >= (uint32_t)kK));
-          n_rev_amb += (uint32_t)__popcll(__ballot(is_n && L - 1u - c >= (uint32_t)kK));
-        }
-        ok0 = n_fwd_amb <= (uint32_t)p.e, ok1 = n_rev_amb <= (uint32_t)p.e;
-      }
-      // Stream position of seed 0 of either strand (the reverse strand's seed j is the window that starts j bases
-      // behind the reversed read's start; its stream lies strm_words words behind the forward one), and the hash of
-      // the seed at a position: the 24 bits that end 2 (pos + k) bits into the stream.
-      const uint32_t org0 = a, org1 = 16u * p.lay.strm_words + n_stream - a - L;
+      if (!live) continue;  // (begin / count stay 0)
+      const uint32_t org0 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org0, sel), org1 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org1, sel);
+      // hash of the seed at a stream position: the 24 bits that end 2 (pos + k) bits into the stream
       auto stream_hash = [&](uint32_t pos) -> uint32_t {
         const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
         const uint32_t *st = strm_fwd + ((end2 - 1u) >> 5);  // st[0], st[1]: the word before the one the window ends in, and that one
         return __builtin_amdgcn_alignbit(st[0], st[1], 0u - end2) & kHashMask;
       };
-      // ---- lean form: lookups by phase group, in two rounds (the phase is bound by the number of divergent loads) ----
-      // Round 1 tests only the seeds at columns 0 and 1 of every row: a group with a zero-cost selection among them
-      // contributes nothing (its minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0)
-      // — rows 1..s free at column 0 and rows s+1..R free at column 1 for some s.  Round 2 looks up all seeds of the
-      // other groups, straight into the group queue: hash << 8 | frequency.  Empty buckets (bitmap) have 0, non-empty
-      // ones outside the folded filter exactly 1; only the others read the table.
-      uint32_t live = 0;
-      if (p.summary) {
-        constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;          // (group, row) lanes of one column
-        constexpr uint32_t kColsPerTurn = 2u * kPer <= (uint32_t)kWave ? 2u : 1u;  // both columns at once if they fit
-        uint64_t z[2] = {0, 0};
-#pragma unroll
-        for (uint32_t c0 = 0; c0 < 2u; c0 += kColsPerTurn) {
-          const uint32_t col = c0 + ln / kPer, gl = ln % kPer;
-          const uint32_t tg = gl / (uint32_t)R, tr = gl % (uint32_t)R, t_strand = tg / (uint32_t)kStep, t_si = tg % (uint32_t)kStep;
-          const uint32_t t_cols = (uint32_t)((S - (int)t_si) / kStep - R * kLg + 1);
-          const bool t_in = ln < kColsPerTurn * kPer && ((t_strand & 1u) ? ok1 : ok0) && col < t_cols;
-          bool empty = false;
-          if (t_in) {
-            const uint32_t h = stream_hash((t_strand ? org1 : org0) + t_si + (uint32_t)kStep * ((uint32_t)kLg * tr + col));
-            uint32_t q, r;
-            summary_slot(h, q, r);
-            empty = !summary_nonempty(p.summary[q], r);
-          }
-          const uint64_t zb = __ballot(empty);
-          if (kColsPerTurn == 2u) {
-            z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
-          } else {
-            z[c0] = zb;
-          }
-        }
-        const uint32_t full = (1u << R) - 1u;
-        const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
-        const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
-        const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
-        const bool g_in = ln < 2u * (uint32_t)kStep && (ln >= (uint32_t)kStep ? ok1 : ok0);
-        live = (uint32_t)__ballot(g_in && !(from1 <= free0));
-      } else {
-        live = (ok0 ? 7u : 0u) | (ok1 ? 56u : 0u);
-      }
-      if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);  // until flush_small finds a candidate
-      if (ln == 0) q_len[rb] = L;
+      // ---- round 2: the live groups' seeds, straight into the group queue as hash << 8 | frequency.  Empty buckets
+      // (summary) have 0, non-empty ones without the "two or more" mark exactly 1; only the others read the table.
       const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
       uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
       // The live groups' seeds, one after the other, are the read's stretch of the queue.  Lane g < 6 describes group g
       // (its stretch starts behind the live groups before it); the stretches' starts and the stream position of their
       // seed 0 are then broadcast, and lane t of the stretch finds its seed from them: position = base + step * t.
       // kStreams x 64 of them go through the three dependent levels (bit test, filter test, table read) together.
-      uint32_t total = 0, g_first[2 * kStep], g_base[2 * kStep];
+      uint32_t g_first[2 * kStep], g_base[2 * kStep];
       {
-        uint32_t used_of[kStep];  // seeds the DP of a phase group looks at: G - Lg + 1
-#pragma unroll
-        for (int si = 0; si < kStep; ++si) used_of[si] = (uint32_t)((S - si) / kStep - kLg + 1);
-        constexpr uint32_t kPhase0 = 1u | (1u << kStep);  // groups of phase 0, one per strand
+        constexpr uint32_t kPhase0 = 1u | (1u << kStep);
         const uint32_t below = live & ((1u << (ln & 31u)) - 1u);
         uint32_t my_first = 0;
 #pragma unroll
-        for (int si = 0; si < kStep; ++si) {
-          my_first += used_of[si] * (uint32_t)__popc(below & (kPhase0 << si));
-          total += used_of[si] * (uint32_t)__popc(live & (kPhase0 << si));
-        }
+        for (int si = 0; si < kStep; ++si) my_first += used_of[si] * (uint32_t)__popc(below & (kPhase0 << si));
         const bool my_on = ln < 2u * (uint32_t)kStep && ((live >> ln) & 1u);
         const uint32_t my_strand = ln >= (uint32_t)kStep ? 1u : 0u, my_si = ln - my_strand * (uint32_t)kStep;
         const uint32_t my_used = my_si == 0 ? used_of[0] : my_si == 1 ? used_of[1] : used_of[2];
