@@ -863,13 +863,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       wave_sync_lds();
     }
     // ---- read by read into the small-read queue ----
+    // What the loop needs per read is worked out for all of them first, (read, strand) slot ln in lane ln < 32.
+    uint32_t rd_word = 0;   // lanes 2 rb, 2 rb + 1: occurrences of the read's strands that can pass the filter; bit 8: the read stays here
+    bool mine_any = false;  // seed lanes: the seed has occurrences and its strand can pass the filter
+    if (K) {
+      const uint32_t t_own = ln < 2u * kReadBlock ? slot_total[ln] : 0u, pre_own = ln < 2u * kReadBlock ? slot_pre[ln] : 0u;
+      const uint32_t t_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t_own, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+      const uint32_t pre_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre_own, 0xB1, 0xF, 0xF, false);
+      const bool stays = t_own <= (uint32_t)kWave && t_other <= (uint32_t)kWave && t_own + t_other <= (uint32_t)kWave;
+      const uint32_t use_own = t_own > (uint32_t)p.a ? t_own : 0u, use_other = t_other > (uint32_t)p.a ? t_other : 0u;
+      rd_word = (stays ? 256u + use_own + use_other : 0u);
+      // "candidates before the filter" of the reads that stay: uint32 per strand (src/filter.c:202), widened
+      const bool counts = ln < 2u * kReadBlock && !(ln & 1u) && stays && ((reads >> (ln >> 1)) & 1u);
+      const unsigned long long pre_read = (unsigned long long)pre_own + pre_other;
+      if (counts) q_pre[ln >> 1] = pre_read;
+      const uint32_t lo16 = counts ? (uint32_t)(pre_read & 0xFFFFu) : 0u, hi = counts ? (uint32_t)(pre_read >> 16) : 0u;  // (hi < 2^17)
+      pre_sum += (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(lo16), kWave - 1) +
+                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(hi), kWave - 1) << 16);
+      const uint32_t use_mine = (uint32_t)__shfl((int)use_own, (int)((g_tag >> 6) & 31u));  // slot = read << 1 | strand
+      mine_any = g_freq > 0 && use_mine != 0u;
+    }
     for (uint32_t todo = reads;;) {
       const bool more = todo != 0;
       const uint32_t rb = more ? (uint32_t)__builtin_ctz(todo) : 0u;
-      const uint32_t t0 = more ? bcast0(slot_total[2u * rb]) : 0u, t1 = more ? bcast0(slot_total[2u * rb + 1u]) : 0u;
-      const bool stays = t0 <= (uint32_t)kWave && t1 <= (uint32_t)kWave && t0 + t1 <= (uint32_t)kWave;
-      const uint32_t use0 = t0 > (uint32_t)p.a ? t0 : 0u, use1 = t1 > (uint32_t)p.a ? t1 : 0u;  // strands that can pass the filter
-      if ((more && stays && q_entries + use0 + use1 > (uint32_t)kWave) || (!more && tail)) flush_small(r0);
+      const uint32_t word = more ? (uint32_t)__builtin_amdgcn_readlane((int)rd_word, (int)(2u * rb)) : 0u;
+      const bool stays = (word & 256u) != 0u;
+      const uint32_t use = word & 255u;
+      if ((more && stays && q_entries + use > (uint32_t)kWave) || (!more && tail)) flush_small(r0);
       if (!more) break;
       todo &= todo - 1u;
       if (!stays) {  // (nothing has been emitted or counted for it)
@@ -877,17 +897,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         queue_slow(r0 + rb);
         continue;
       }
-      const unsigned long long pre_read = (unsigned long long)bcast0(slot_pre[2u * rb]) + bcast0(slot_pre[2u * rb + 1u]);
-      pre_sum += pre_read;
-      if (ln == 0) q_pre[rb] = pre_read;
-      const bool mine = g_freq > 0 && (g_tag >> 7) == rb && (((g_tag >> 6) & 1u) ? use1 : use0) != 0u;
+      const bool mine = mine_any && (g_tag >> 7) == rb;
       const uint64_t mm = __ballot(mine);
       if (mine) {
         const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
         q_lo[at_] = g_lo;
         q_info[at_] = g_start | (g_freq << 10) | (g_tag << 17);
       }
-      q_seeds += (uint32_t)__popcll(mm), q_entries += use0 + use1;
+      q_seeds += (uint32_t)__popcll(mm), q_entries += use;
       wave_sync_lds();
     }
   };
