@@ -208,18 +208,14 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
     l.pkw = take(l.n_words * 4u);
     l.nkw = take(l.n_words * 4u);
   }
-  // (hash, frequency) of every seed of both strands — hash-join form only: the lean form looks its seeds up straight
-  // into the group queue; reused for the strands' candidates once the seeds are selected
-  l.sf = take(hash ? std::max(2u * l.smax * 8u, 2u * 64u * 8u) : 2u * 64u * 8u);
+  // (hash, frequency) of every seed of both strands, reused for the strands' candidates once the seeds are selected
+  // — hash-join form only: the lean form looks its seeds up straight into the group queue
+  if (hash) l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 8u));
   l.dp_bits = take(std::max(n_groups, femk::kGroupQueue) * R * 8u);  // one ballot per (pass, row); up to kGroupQueue passes
   if (hash) {
     l.X = take(64u * 8u);                 // scatter
     l.A = take(femk::kListScratchBytes);  // lists_in_lanes
-  } else {
-    // lean form: no per-read list phase; flush_small lays its scratch over the seed table and what follows it
-    const uint32_t so_far = o - l.sf;
-    l.X = l.A = take(femk::kFlushScratchBytes > so_far ? femk::kFlushScratchBytes - so_far : 0u);
-  }
+  }  // (lean form: no per-read list phase; flush_small lays its scratch over the group queue, dead by then)
   l.B = take(2u * femk::kReadBlock * 8u);  // the block's begin/count entries
   if (!hash) {
     // One block of reads (kReadBlock consecutive ones, contiguous in the batch) is staged and encoded at once; blocks
@@ -233,7 +229,7 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
     const uint32_t g0 = l.smax / (uint32_t)femk::kStep;
     const uint32_t n_used = g0 > (uint32_t)femk::kLg ? g0 - (uint32_t)femk::kLg + 1u : 1u;
     l.gq_cap = std::max(384u, n_groups * n_used);
-    l.gq = take(l.gq_cap * 4u + femk::kGroupQueue * 16u + 2u * 32u * 4u);
+    l.gq = take(std::max(l.gq_cap * 4u + femk::kGroupQueue * 16u + 2u * 32u * 4u, femk::kFlushScratchBytes));
     // the block's raw characters (+ slack for the 16-byte copies) are dead once the streams exist, and both queues
     // are empty at that point: they share the space
     l.blk_bytes = blk_chars + 32u;

@@ -492,7 +492,10 @@ __device__ uint32_t select_seeds_lanes(const SeedParams &p, int S, const bool *s
 // values than the rest (seven waves spill into the read loop and lose 20 %).  The hash-join form wants ~120-150
 // registers: with few seeds per group five waves (96 VGPRs) beat four, its LDS allows no more; with many seeds per
 // group the spills cost more than the fifth wave brings.
-constexpr int lean_waves(int R, bool hash) { return hash ? (R <= 6 ? 5 : 1) : 6; }
+#ifndef FEM_LEAN_WAVES
+#define FEM_LEAN_WAVES 7
+#endif
+constexpr int lean_waves(int R, bool hash) { return hash ? (R <= 6 ? 5 : 1) : FEM_LEAN_WAVES; }
 
 template <int R, bool HASH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_waves(R, HASH), 8))) seed_fast_kernel(SeedParams p) {
@@ -626,7 +629,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 
   // ---- small-read batch (lean form only) ----
   uint32_t *q_lo = (uint32_t *)(wbase + p.lay.F), *q_info = q_lo + kQueueSeeds, *q_len = q_info + kQueueSeeds;
-  uint8_t *fl = wbase + p.lay.sf;
+  uint8_t *fl = wbase + p.lay.gq;  // flush_small's scratch: over the group queue, whose groups are all in lanes by then
   unsigned long long *q_pre = (unsigned long long *)(q_len + kReadBlock);
   uint32_t q_seeds = 0, q_entries = 0;  // seeds / occurrences queued
   // Finishes every queued read at once: one occurrence per lane over all of them, segments = (read, strand, group).
