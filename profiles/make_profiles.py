@@ -23,7 +23,7 @@ PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slot
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
     ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"],
 ]
-KERNELS = ("seed_fast_kernel", "seed_filter_kernel", "verify_kernel", "count_mappings_kernel")
+KERNELS = ("seed_fast_kernel", "seed_filter_kernel", "verify_kernel", "count_mappings_kernel", "bucket_summary_kernel")
 
 
 def run(cmd, log):
