@@ -88,6 +88,8 @@ struct fem_dev {
   uint64_t *d_occ = nullptr;
   uint64_t n_occ = 0;
   int32_t k = 0, step = 0;
+  uint64_t fast_occ_key = ~0ull;  // seed_fast_kernel residency, cached per (R, form, LDS bytes)
+  int fast_occ_blocks = 0;
   uint32_t *d_summary = nullptr;  // bucket summaries (femk::SeedParams::summary), built for sparse indexes only
   // reference
   uint8_t *d_ref = nullptr;      // base codes
@@ -250,6 +252,29 @@ void launch_fast(bool hash, dim3 grid, dim3 block, uint32_t lds, hipStream_t st,
     hipLaunchKernelGGL((femk::seed_fast_kernel<R, true>), grid, block, lds, st, sp);
   else
     hipLaunchKernelGGL((femk::seed_fast_kernel<R, false>), grid, block, lds, st, sp);
+}
+
+template <int R>
+int fast_blocks_per_cu_r(bool hash, int block, uint32_t lds) {
+  int nb = 0;
+  hipError_t err = hash ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_fast_kernel<R, true>, block, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_fast_kernel<R, false>, block, lds);
+  return err == hipSuccess ? nb : 0;
+}
+// blocks of seed_fast_kernel<R, hash> one CU holds at a time (registers and LDS both count); 0 = unknown
+int fast_blocks_per_cu(int R, bool hash, int block, uint32_t lds) {
+  switch (R) {
+    case 1: return fast_blocks_per_cu_r<1>(hash, block, lds);
+    case 2: return fast_blocks_per_cu_r<2>(hash, block, lds);
+    case 3: return fast_blocks_per_cu_r<3>(hash, block, lds);
+    case 4: return fast_blocks_per_cu_r<4>(hash, block, lds);
+    case 5: return fast_blocks_per_cu_r<5>(hash, block, lds);
+    case 6: return fast_blocks_per_cu_r<6>(hash, block, lds);
+    case 7: return fast_blocks_per_cu_r<7>(hash, block, lds);
+    case 8: return fast_blocks_per_cu_r<8>(hash, block, lds);
+    case 9: return fast_blocks_per_cu_r<9>(hash, block, lds);
+    default: return fast_blocks_per_cu_r<10>(hash, block, lds);
+  }
 }
 
 hipEvent_t get_event(fem_dev *h) {
@@ -420,6 +445,19 @@ int launch_batch(fem_dev *h, Slot &s) {
       fp.lay = make_layout_fast(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k), hash);
       uint32_t wpb, lds_bytes, grid;
       shape(fp.lay, &wpb, &lds_bytes, &grid);
+      {
+        // A wave takes blocks of kReadBlock reads at a fixed stride.  The grid is a multiple of what is resident at a
+        // time (registers included): measured on C2, exactly-resident 6.9 ms, x2 6.6, x4 6.4, x6 6.2, x8 6.2 — waves
+        // that all start together stay in the same phase and queue for the same unit.  Each wave pads its last chunk
+        // of candidate slots, though: many more waves cost the verify kernel lanes (x16: +0.4 ms there).
+        // FEM_GRID_MULT overrides the multiple (measurement only).
+        const uint64_t key = ((uint64_t)R << 40) | ((uint64_t)hash << 32) | lds_bytes;
+        if (h->fast_occ_key != key) h->fast_occ_key = key, h->fast_occ_blocks = fast_blocks_per_cu((int)R, hash, (int)(64u * wpb), lds_bytes);
+        static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 6;
+        const uint64_t per_cu = h->fast_occ_blocks > 0 ? (uint64_t)h->fast_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        const uint64_t wanted = (s.n_reads + (uint64_t)femk::kReadBlock * wpb - 1) / ((uint64_t)femk::kReadBlock * wpb);
+        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wanted, (uint64_t)h->n_cu * per_cu * mult));
+      }
       auto launch_range = [&](uint32_t lo, uint32_t hi) {
         femk::SeedParams q = fp;
         q.read_begin = lo, q.n_reads = hi;
