@@ -965,9 +965,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   // Lean form, continued.  What each read of the block needs later is worked out for all of them at once, read rb in
   // lanes 2 rb and 2 rb + 1 (the block's begin/count entries are two per read), and fetched with v_readlane when the
   // read's turn comes: no scalar arithmetic, no dependent load of read_off per read.
-  uint32_t rd_org0 = 0, rd_org1 = 0, rd_used = 0, rd_flags = 0, rd_live = 0;
+  uint32_t rd_flags = 0, rd_live = 0, rd_total = 0;  // (rd_total: seeds of the live groups | columns of the widest group << 16)
+  // ... and per (read, group), lanes 6 (rb & 7) + g, [0] for reads 0..7 and [1] for 8..15: where the group's seeds go in
+  // its read's stretch of the group queue (kPg* fields), and the stream position of its seed 0 minus step * that start
+  uint32_t pg_word[2] = {0, 0}, pg_base[2] = {0, 0};
+  constexpr uint32_t kPgFirstBits = 10, kPgUsedShift = 10, kPgOrdShift = 18, kPgOnBit = 21, kPgTagShift = 22;
   constexpr uint32_t kRdFast = 1u, kRdSlow = 2u;  // rd_flags; bits 2.. = column 1 exists in the groups of phase 0, 1, 2
   if (!HASH) {
+    uint32_t rd_org0 = 0, rd_org1 = 0, rd_used = 0;
     const uint32_t my_rb = ln >> 1, my_read = r0 + my_rb;
     const bool in = my_rb < kReadBlock && my_read < p.n_reads;
     uint64_t o0 = 0, o1 = 0;
@@ -1067,6 +1072,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         rd_live = my_rb == b0 + u ? live : rd_live;
       }
     }
+    // ---- the live groups' places in their reads' stretches of the group queue, for the whole block ----
+    {
+      constexpr uint32_t kPhase0 = 1u | (1u << kStep);  // groups of phase 0, one per strand
+      uint32_t tot = 0;
+#pragma unroll
+      for (int si = 0; si < kStep; ++si) tot += ((rd_used >> (8 * si)) & 255u) * (uint32_t)__popc(rd_live & (kPhase0 << si));
+      rd_total = tot | (((rd_used & 255u) - (uint32_t)((R - 1) * kLg)) << 16);  // columns of phase group 0: no group has more
+      const uint32_t pl = ln < 8u * 2u * (uint32_t)kStep ? ln : 0u, prb = (pl * 43u) >> 8, g = pl - 2u * (uint32_t)kStep * prb;  // pl / 6
+      static_assert(kStep == 3, "the division above");
+      const uint32_t strand = g >= (uint32_t)kStep ? 1u : 0u, si = g - strand * (uint32_t)kStep;
+#pragma unroll
+      for (uint32_t half = 0; half < 2u; ++half) {
+        const int src = (int)(2u * (prb + 8u * half));
+        const uint32_t live_r = (uint32_t)__shfl((int)rd_live, src), used_w = (uint32_t)__shfl((int)rd_used, src);
+        const uint32_t o0 = (uint32_t)__shfl((int)rd_org0, src), o1 = (uint32_t)__shfl((int)rd_org1, src);
+        const uint32_t org = strand ? o1 : o0;
+        const uint32_t below = live_r & ((1u << g) - 1u);
+        uint32_t first = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < kStep; ++s2) first += ((used_w >> (8 * s2)) & 255u) * (uint32_t)__popc(below & (kPhase0 << s2));
+        const bool on = ln < 8u * 2u * (uint32_t)kStep && ((live_r >> g) & 1u);
+        const uint32_t used = (used_w >> (8u * si)) & 255u;
+        pg_word[half] = on ? first | (used << kPgUsedShift) | ((uint32_t)__popc(below) << kPgOrdShift) | (1u << kPgOnBit) | (((strand << 2) | si) << kPgTagShift) : 0u;
+        pg_base[half] = org + si - (uint32_t)kStep * first;
+      }
+    }
   }
   // HASH form: four characters of a read at any byte offset
   auto chars_at = [&](uint64_t off, uint32_t idx) -> uint32_t { return load_u32_unaligned(p.bases + off + idx); };
@@ -1082,16 +1113,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     if (!HASH) {
       const int sel = (int)(2u * (rb & (kReadBlock - 1u)));  // a lane with the read's parameters
       const uint32_t live = tail_turn ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)rd_live, sel);
-      uint32_t used_of[kStep], total = 0;  // seeds of a group of each phase, and of all live groups
-      {
-        const uint32_t used_w = (uint32_t)__builtin_amdgcn_readlane((int)rd_used, sel);
-        constexpr uint32_t kPhase0 = 1u | (1u << kStep);  // groups of phase 0, one per strand
-#pragma unroll
-        for (int si = 0; si < kStep; ++si) {
-          used_of[si] = (used_w >> (8 * si)) & 255u;
-          total += used_of[si] * (uint32_t)__popc(live & (kPhase0 << si));
-        }
-      }
+      const uint32_t total_w = (uint32_t)__builtin_amdgcn_readlane((int)rd_total, sel);
+      const uint32_t total = tail_turn ? 0u : total_w & 0xFFFFu;  // seeds of all live groups
       // the queues are flushed while no read is in flight: before a read whose live groups do not fit, and at the
       // block's end
       if (tail_turn || gq_groups + (uint32_t)__popc(live) > kGroups || gq_entries + total > p.lay.gq_cap) select_flush(r0, tail_turn);
@@ -1101,7 +1124,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         continue;
       }
       if (!live) continue;  // (begin / count stay 0)
-      const uint32_t org0 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org0, sel), org1 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org1, sel);
       // hash of the seed at a stream position: the 24 bits that end 2 (pos + k) bits into the stream
       auto stream_hash = [&](uint32_t pos) -> uint32_t {
         const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
@@ -1112,33 +1134,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       // (summary) have 0, non-empty ones without the "two or more" mark exactly 1; only the others read the table.
       const uint32_t groups_before = gq_groups, entries_before = gq_entries, maxcols_before = gq_maxcols;
       uint32_t big_freq = 0;  // some bucket holds more than the queue's 8-bit field takes
-      // The live groups' seeds, one after the other, are the read's stretch of the queue.  Lane g < 6 describes group g
-      // (its stretch starts behind the live groups before it); the stretches' starts and the stream position of their
-      // seed 0 are then broadcast, and lane t of the stretch finds its seed from them: position = base + step * t.
-      // kStreams x 64 of them go through the three dependent levels (bit test, filter test, table read) together.
-      uint32_t g_first[2 * kStep], g_base[2 * kStep];
+      // The live groups' seeds, one after the other, are the read's stretch of the queue; its lanes of pg_word / pg_base
+      // say where each group starts.  Lane t of the stretch finds its seed from them: position = base + step * t.
+      // kStreams x 64 of them go through the dependent levels (summary test, table read) together.
+      const uint32_t pg_lane0 = 2u * (uint32_t)kStep * (rb & 7u);
+      const uint32_t pw = rb < 8u ? pg_word[0] : pg_word[1], pb = rb < 8u ? pg_base[0] : pg_base[1];
+      if (ln - pg_lane0 < 2u * (uint32_t)kStep && ((pw >> kPgOnBit) & 1u)) {
+        const uint32_t used = (pw >> kPgUsedShift) & 255u;
+        gq_desc[gq_groups + ((pw >> kPgOrdShift) & 7u)] =
+            make_uint4(gq_entries + (pw & ((1u << kPgFirstBits) - 1u)), used, used - (uint32_t)((R - 1) * kLg), (rb << 3) | ((pw >> kPgTagShift) & 7u));
+      }
+      gq_groups += (uint32_t)__popc(live);
       {
-        constexpr uint32_t kPhase0 = 1u | (1u << kStep);
-        const uint32_t below = live & ((1u << (ln & 31u)) - 1u);
-        uint32_t my_first = 0;
-#pragma unroll
-        for (int si = 0; si < kStep; ++si) my_first += used_of[si] * (uint32_t)__popc(below & (kPhase0 << si));
-        const bool my_on = ln < 2u * (uint32_t)kStep && ((live >> ln) & 1u);
-        const uint32_t my_strand = ln >= (uint32_t)kStep ? 1u : 0u, my_si = ln - my_strand * (uint32_t)kStep;
-        const uint32_t my_used = my_si == 0 ? used_of[0] : my_si == 1 ? used_of[1] : used_of[2];
-        if (my_on)
-          gq_desc[gq_groups + (uint32_t)__popc(below)] =
-              make_uint4(gq_entries + my_first, my_used, my_used - (uint32_t)((R - 1) * kLg), (rb << 3) | (my_strand << 2) | my_si);
-        const uint32_t first_x = my_on ? my_first : 0xFFFFFFFFu;  // a dead group takes no lane
-        const uint32_t base_x = (my_strand ? org1 : org0) + my_si - (uint32_t)kStep * my_first;
-#pragma unroll
-        for (int g = 0; g < 2 * kStep; ++g) {
-          g_first[g] = (uint32_t)__builtin_amdgcn_readlane((int)first_x, g);
-          g_base[g] = (uint32_t)__builtin_amdgcn_readlane((int)base_x, g);
-        }
-        gq_groups += (uint32_t)__popc(live);
-        const uint32_t widest = used_of[0] - (uint32_t)((R - 1) * kLg);  // columns of phase group 0: no group has more
-        if (live) gq_maxcols = widest > gq_maxcols ? widest : gq_maxcols;
+        const uint32_t widest = total_w >> 16;
+        gq_maxcols = widest > gq_maxcols ? widest : gq_maxcols;
       }
 #ifndef FEM_LEAN_STREAMS
 #define FEM_LEAN_STREAMS 1
@@ -1151,9 +1160,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
         for (int v = 0; v < kStreams; ++v) {
           const uint32_t t = t0 + (uint32_t)(v * kWave) + ln;
           act[v] = t < total;
-          uint32_t base = g_base[0];
-#pragma unroll
-          for (int g = 1; g < 2 * kStep; ++g) base = t >= g_first[g] ? g_base[g] : base;
+          uint32_t base = 0;
+          for (uint32_t m = live; m; m &= m - 1u) {  // (the first live group starts at 0)
+            const int gl = (int)(pg_lane0 + (uint32_t)__builtin_ctz(m));
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)pw, gl) & ((1u << kPgFirstBits) - 1u);
+            const uint32_t gbase = (uint32_t)__builtin_amdgcn_readlane((int)pb, gl);
+            base = t >= first ? gbase : base;
+          }
           hh[v] = act[v] ? stream_hash(base + (uint32_t)kStep * t) : 0u;
           fq[v] = 0;
         }
