@@ -155,3 +155,24 @@ def test_short_tandem_repeats_survive_in_several_phase_groups(dev):
     assert_same(want, got)
     per_strand = np.diff(want.cand_off.astype(np.int64))
     assert (per_strand >= 2).sum() > 10, "fixture must contain reads with several candidates per strand"
+
+
+@pytest.mark.parametrize("e,a,lengths", [
+    (0, 1, (64, 65, 66)), (1, 1, (50, 75, 100)), (2, 0, (99, 100, 101)), (3, 1, (100,)), (3, 1, (70, 100, 130, 180, 250)),
+    (4, 1, (110, 111, 112, 113)), (5, 2, (150, 151)), (6, 1, (140, 200)), (7, 2, (180, 256)), (3, 1, (240, 256, 257, 300, 90)),
+])
+def test_sparse_index_sweep_over_lengths_and_errors(dev, e, a, lengths):
+    # sparse index (every third position of a random reference): the block-staged form of the fast seed kernel.  Reads
+    # of mixed lengths in random order, so that blocks of 16 reads straddle every length (and the 256-base staging
+    # limit in the last case: those blocks go to the generic kernel), with and without N.
+    rng = np.random.default_rng(1000 + 31 * e + a + sum(lengths))
+    seqs = [util.rand_seq(rng, 400_000), util.rand_seq(rng, 30_000)]
+    reads = []
+    for L in lengths:
+        reads += util.make_reads(rng, seqs, 120, L, e)
+        reads += util.make_reads(rng, seqs, 40, L, e, n_rate=0.01)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    want, got = run_both(dev, seqs, reads, e=e, a=a)
+    assert want.stats[1] > len(reads) // 3
+    assert_same(want, got)
