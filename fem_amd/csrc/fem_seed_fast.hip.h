@@ -1008,27 +1008,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     // ---- round 1 of the lookups, for every read of the block: which phase groups can contribute at all ----
     // A group with a zero-cost selection among the seeds at columns 0 and 1 of every row contributes nothing (its
     // minimum is 0: whatever the traceback takes has no occurrences, and M[R][C-1] = 0) — rows 1..s free at column 0
-    // and rows s+1..R free at column 1 for some s.  Only those seeds are tested here, kRound1Batch reads' loads in
-    // flight together; round 2, at the read's turn, looks up all seeds of the other ("live") groups.
-    constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;                  // (group, row) lanes of one column
-    constexpr uint32_t kTurns = 2u * kPer <= (uint32_t)kWave ? 1u : 2u;           // both columns at once if they fit
-    constexpr uint32_t kRound1Batch = 4u / kTurns;
-    const uint32_t t_col = kTurns == 1u ? ln / kPer : 0u, t_gl = ln % kPer;        // (kTurns == 2: column = turn)
+    // and rows s+1..R free at column 1 for some s.  Only those seeds are tested here; round 2, at the read's turn,
+    // looks up all seeds of the other ("live") groups.  Every probe is a 64-byte fill from L2 and those fills are what
+    // bounds this phase, so column 1 is probed only for groups that column 0 left undecided (a group
+    // whose rows are all free at column 0 is dead already).  One lane per (read, group, row): kRpo reads per
+    // wave-instruction, kRound1Batch reads' probes in flight together.
+    constexpr uint32_t kPer = 2u * (uint32_t)kStep * (uint32_t)R;  // (group, row) lanes of one read
+    constexpr uint32_t kFit = (uint32_t)kWave / kPer, kRpo = kFit >= 4u ? 4u : kFit >= 2u ? 2u : 1u;  // reads per wave-instruction
+    constexpr uint32_t kRound1Batch = 4u, kOps = kRound1Batch / kRpo;
+    static_assert(kRpo >= 1u && kRound1Batch % kRpo == 0u && kReadBlock % kRound1Batch == 0u, "round-1 batching");
+    const uint32_t t_rd = ln / kPer, t_gl = ln % kPer;             // read within the instruction (idle lanes: >= kRpo)
     const uint32_t t_g = t_gl / (uint32_t)R, t_row = t_gl % (uint32_t)R, t_strand = t_g / (uint32_t)kStep, t_si = t_g % (uint32_t)kStep;
-    const bool t_lane = ln < (2u / kTurns) * kPer;
-    const uint32_t t_ofs = t_si + (uint32_t)kStep * ((uint32_t)kLg * t_row + t_col);  // seed offset on its strand, column 0 or t_col
+    const bool t_lane = ln < kRpo * kPer;
+    const uint32_t t_ofs = t_si + (uint32_t)(kStep * kLg) * t_row;  // seed offset on its strand, column 0
+    const uint32_t t_shift = kPer * t_rd + (uint32_t)R * t_g;        // where the group's rows sit in an instruction's ballot
+    constexpr uint32_t kFull = (1u << R) - 1u;
+    // the 24 bits that end 2 (pos + k) bits into the streams -> summary word and bit of that bucket
+    auto probe = [&](uint32_t pos, uint32_t &r) -> uint32_t {
+      const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
+      const uint32_t *st = strm_fwd + ((end2 - 1u) >> 5);
+      uint32_t q;
+      summary_slot(__builtin_amdgcn_alignbit(st[0], st[1], 0u - end2) & kHashMask, q, r);
+      return p.summary[q];
+    };
 #pragma unroll 1
     for (uint32_t b0 = 0; b0 < kReadBlock && r0 + b0 < p.n_reads; b0 += kRound1Batch) {
-      uint32_t w[kRound1Batch][kTurns], sr[kRound1Batch][kTurns], okm[kRound1Batch];
+      uint32_t okm[kRound1Batch];  // groups the ambiguous-base gate leaves (src/utils.h:108-114, src/filter.c:180-182)
 #pragma unroll
       for (uint32_t u = 0; u < kRound1Batch; ++u) {
         const int sel = (int)(2u * (b0 + u));
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)rd_flags, sel);
-        const uint32_t org0 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org0, sel), org1 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org1, sel);
         okm[u] = (flags & kRdFast) ? 63u : 0u;
-        if ((flags & kRdFast) && blk_has_n) {
-          // ambiguous-base gate (src/utils.h:108-114, src/filter.c:180-182): N at offsets >= k, counted on either strand
-          const uint32_t len = bcast0(q_len[b0 + u]);
+        if ((flags & kRdFast) && blk_has_n) {  // N at offsets >= k, counted on either strand
+          const uint32_t len = bcast0(q_len[b0 + u]), org0 = (uint32_t)__builtin_amdgcn_readlane((int)rd_org0, sel);
           uint32_t n_fwd_amb = 0, n_rev_amb = 0;
           for (uint32_t c0 = 0; c0 < len; c0 += (uint32_t)kWave) {
             const uint32_t c = c0 + ln, pos = org0 + c;
@@ -1038,36 +1050,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
           }
           okm[u] = (n_fwd_amb <= (uint32_t)p.e ? 7u : 0u) | (n_rev_amb <= (uint32_t)p.e ? 56u : 0u);
         }
+      }
+      uint32_t pos0[kOps], w[kOps], sr[kOps];
+      bool col1[kOps];  // the lane's group has a column 1
+      uint64_t z0[kOps], z1[kOps];
 #pragma unroll
-        for (uint32_t turn = 0; turn < kTurns; ++turn) {
-          const uint32_t col = kTurns == 1u ? t_col : turn;
-          const bool t_in = p.summary && t_lane && okm[u] != 0u && (col == 0u || ((flags >> (2u + t_si)) & 1u));
-          w[u][turn] = 0xFFFFFFFFu, sr[u][turn] = 0;  // (not tested: not empty)
-          if (t_in) {
-            const uint32_t pos = (t_strand ? org1 : org0) + t_ofs + (kTurns == 1u ? 0u : (uint32_t)kStep * turn);
-            const uint32_t end2 = 2u * pos + 2u * (uint32_t)kK;
-            const uint32_t *st = strm_fwd + ((end2 - 1u) >> 5);
-            const uint32_t h = __builtin_amdgcn_alignbit(st[0], st[1], 0u - end2) & kHashMask;
-            uint32_t q;
-            summary_slot(h, q, sr[u][turn]);
-            w[u][turn] = p.summary[q];
-          }
-        }
+      for (uint32_t op = 0; op < kOps; ++op) {  // column 0
+        const uint32_t u_lane = op * kRpo + (t_lane ? t_rd : 0u);  // the lane's read of the batch
+        const int src = (int)(2u * (b0 + u_lane));
+        const uint32_t flags = (uint32_t)__shfl((int)rd_flags, src);
+        const uint32_t o0 = (uint32_t)__shfl((int)rd_org0, src), o1 = (uint32_t)__shfl((int)rd_org1, src);
+        uint32_t ok = okm[op * kRpo];
+#pragma unroll
+        for (uint32_t k2 = 1; k2 < kRpo; ++k2) ok = t_rd == k2 ? okm[op * kRpo + k2] : ok;
+        const bool t_in = p.summary && t_lane && ((ok >> t_g) & 1u);
+        col1[op] = t_in && ((flags >> (2u + t_si)) & 1u);
+        pos0[op] = (t_strand ? o1 : o0) + t_ofs;
+        w[op] = 0xFFFFFFFFu, sr[op] = 0;  // (not tested: not empty)
+        if (t_in) w[op] = probe(pos0[op], sr[op]);
       }
 #pragma unroll
-      for (uint32_t u = 0; u < kRound1Batch; ++u) {
-        uint64_t z[2];
-        if (kTurns == 1u) {
-          const uint64_t zb = __ballot(!summary_nonempty(w[u][0], sr[u][0]));
-          z[0] = zb & ((1ull << kPer) - 1ull), z[1] = zb >> kPer;
-        } else {
-          z[0] = __ballot(!summary_nonempty(w[u][0], sr[u][0]));
-          z[1] = __ballot(!summary_nonempty(w[u][kTurns - 1u], sr[u][kTurns - 1u]));
-        }
-        const uint32_t full = (1u << R) - 1u;
-        const uint32_t a0 = (uint32_t)(z[0] >> (ln * (uint32_t)R)) & full, a1 = (uint32_t)(z[1] >> (ln * (uint32_t)R)) & full;
-        const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                  // rows 1..free0 are free at column 0
-        const uint32_t from1 = a1 == full ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & full);  // rows from1+1..R are free at column 1
+      for (uint32_t op = 0; op < kOps; ++op) {  // column 1, where column 0 did not settle it
+        z0[op] = __ballot(!summary_nonempty(w[op], sr[op]));
+        const bool undecided = ((uint32_t)(z0[op] >> t_shift) & kFull) != kFull;
+        w[op] = 0xFFFFFFFFu, sr[op] = 0;
+        if (col1[op] && undecided) w[op] = probe(pos0[op] + (uint32_t)kStep, sr[op]);
+      }
+#pragma unroll
+      for (uint32_t op = 0; op < kOps; ++op) z1[op] = __ballot(!summary_nonempty(w[op], sr[op]));
+#pragma unroll
+      for (uint32_t u = 0; u < kRound1Batch; ++u) {  // lane g < 6: group g of read u of the batch
+        const uint32_t op = u / kRpo, at = kPer * (u % kRpo) + ln * (uint32_t)R;
+        const uint32_t a0 = (uint32_t)(z0[op] >> at) & kFull, a1 = (uint32_t)(z1[op] >> at) & kFull;
+        const uint32_t free0 = (uint32_t)__builtin_ctz(~a0);                                   // rows 1..free0 are free at column 0
+        const uint32_t from1 = a1 == kFull ? 0u : 32u - (uint32_t)__builtin_clz(~a1 & kFull);  // rows from1+1..R are free at column 1
         const uint32_t live = (uint32_t)__ballot(ln < 2u * (uint32_t)kStep && !(from1 <= free0)) & okm[u];
         rd_live = my_rb == b0 + u ? live : rd_live;
       }
