@@ -829,16 +829,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       int col = (int)d.z - 1;
       bool alive = act;
       uint32_t idx = 0xFFFFFFFFu;
+      if (W <= 32u) {  // a group's take bits fit one word: the chain runs on 32-bit values
 #pragma unroll
-      for (int r = R; r >= 1; --r) {
-        if (alive && (uint32_t)(R - r) <= t) {
-          const unsigned long long row_bits = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W);
-          const unsigned long long seg = row_bits & ((2ull << col) - 1ull);
-          if (seg == 0) {
-            alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
-          } else {
-            col = 63 - __builtin_clzll(seg);
-            if ((uint32_t)(R - r) == t) idx = (uint32_t)(col + (r - 1) * kLg);
+        for (int r = R; r >= 1; --r) {
+          if (alive && (uint32_t)(R - r) <= t) {
+            const uint32_t row_bits = (uint32_t)(take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)] >> (slot_of * W));
+            const uint32_t seg = row_bits & ((2u << col) - 1u);
+            if (seg == 0) {
+              alive = false;  // column 0 reached before R seeds were taken (UB in reference): the rest stay zero
+            } else {
+              col = 31 - __builtin_clz(seg);
+              if ((uint32_t)(R - r) == t) idx = (uint32_t)(col + (r - 1) * kLg);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = R; r >= 1; --r) {
+          if (alive && (uint32_t)(R - r) <= t) {
+            const unsigned long long row_bits = take_bits[pass_of * (uint32_t)R + (uint32_t)(r - 1)];
+            const unsigned long long seg = row_bits & ((2ull << col) - 1ull);
+            if (seg == 0) {
+              alive = false;
+            } else {
+              col = 63 - __builtin_clzll(seg);
+              if ((uint32_t)(R - r) == t) idx = (uint32_t)(col + (r - 1) * kLg);
+            }
           }
         }
       }
