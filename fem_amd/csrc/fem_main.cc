@@ -52,7 +52,7 @@ void usage_map() {
   fprintf(stderr, "        -f       STR  seeding algorithm: \"g\" for group seeding and \"v\" for variable-length seeding \n");
   fprintf(stderr, "        -a       INT  # additional q-grams (only for test)\n");
   fprintf(stderr, "        --gpus   INT  number of GPUs to shard read batches over [1]\n");
-  fprintf(stderr, "        --batch  INT  reads per device batch [1000000]\n\n");
+  fprintf(stderr, "        --batch  INT  reads per device batch [250000]\n\n");
   fprintf(stderr, "Input/output: \n");
   fprintf(stderr, "        --ref    STR  Input reference file\n");
   fprintf(stderr, "        --index  STR  Input index file\n");
@@ -186,7 +186,7 @@ int map_main(int argc, char **argv) {
   char *ref_path = nullptr, *index_path = nullptr, *read_path = nullptr, *out_path = nullptr;
   fem_params params{12, 3, 2, 1};  // src/FEM_map.c:67-70: k and step are fixed, whatever the index header says
   int n_threads = 1, n_gpus = 1;
-  uint64_t batch_reads = 1000000;
+  uint64_t batch_reads = 250000;  // (8 M reads, FASTQ -> SAM: 250 k per batch 17-22 Mreads/s, 1 M per batch 9-14: the pipeline fills sooner)
   const char *short_opt = "ha:f:e:t:o:r:i:b:";
   static struct option long_opt[] = {{"help", no_argument, nullptr, 'h'},       {"ref", required_argument, nullptr, 'r'},
                                      {"index", required_argument, nullptr, 'i'}, {"read1", required_argument, nullptr, 'b'},
