@@ -1030,8 +1030,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 //   * reference: three bit planes of the base codes (bit q of code(ref[i]) at bit i of plane q).  One unaligned
 //     16-byte load per plane covers the windows of six 16-column steps; Peq[c] for a column is a three-way XNOR of
 //     the planes, shifted;
-//   * read: 16 characters per load, decoded four at a time (SWAR), byte-reversed and complemented on the reverse
-//     strand (prepare_negative_sequence_at, src/sequence_batch.h:90-98).
+//   * read: 16 characters per load, four loads back to back into the lane's LDS words (they share 64-byte sectors;
+//     one load per step missed the L1 every time), decoded four at a time (SWAR), byte-reversed and complemented on
+//     the reverse strand (prepare_negative_sequence_at, src/sequence_batch.h:90-98).
 // Nothing is accumulated here: count_mappings_kernel derives the per-read counts and the counters afterwards (one
 // returning atomic per accepted candidate used to cost as much as everything else in this kernel together).
 // ---------------------------------------------------------------------------------------------------------
@@ -1083,6 +1084,11 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const int e = p.e;
   const uint32_t width = 2u * (uint32_t)e + 1u;
+  // Four 16-character chunks of the lane's read wait in LDS: fetched back to back they share their 64-byte sectors,
+  // fetched one per step (16 columns = microseconds apart at eight waves per SIMD) every chunk missed the L1 again
+  // (1.26 -> 1.14 ms at C2).  Eight chunks at once cost three waves per SIMD and were slower.
+  constexpr int kStageChunks = 4;
+  __shared__ uint4 stage[kStageChunks][256];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const uint32_t meta = p.cand_meta[i];
     if (meta == kInvalidMeta) {
@@ -1103,15 +1109,21 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
     // the reverse strand's chunk comes from the far end; the last, partial one may start in front of the read
     auto text_chunk = [&](int col) { return load_u128_unaligned(strand == 0 ? rd + col : rd + (L - 16 - col)); };
     auto plane_chunk = [&](int q, int col) { return load_u128_unaligned(p.plane[q] + ((pat + (uint32_t)col) >> 3)); };
-    uint4 rw = make_uint4(0, 0, 0, 0), P0 = rw, P1 = rw, P2 = rw, P0n = rw, P1n = rw, P2n = rw;
+    uint4 P0 = make_uint4(0, 0, 0, 0), P1 = P0, P2 = P0, P0n = P0, P1n = P0, P2n = P0;
     if (n_steps > 0) {
-      rw = text_chunk(0);
       P0n = plane_chunk(0, 0), P1n = plane_chunk(1, 0), P2n = plane_chunk(2, 0);
     }
     const uint32_t pat_bit = (uint32_t)pat & 7u;
     for (int step = 0; step < n_steps && !rejected; ++step) {
       const int col = step << 4, sub = step % kStepsPerPlaneLoad;
-      const uint4 r = rw;
+      if (step % kStageChunks == 0) {
+        uint4 t4[kStageChunks];
+#pragma unroll
+        for (int c = 0; c < kStageChunks; ++c) t4[c] = step + c < n_steps ? text_chunk(col + 16 * c) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < kStageChunks; ++c) stage[c][threadIdx.x] = t4[c];
+      }
+      const uint4 r = stage[step % kStageChunks][threadIdx.x];
       if (sub == 0) {  // loads of the next stretch are issued one stretch ahead, those of the next step one step ahead
         P0 = P0n, P1 = P1n, P2 = P2n;
         if (step + kStepsPerPlaneLoad < n_steps) {
@@ -1119,7 +1131,6 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
           P0n = plane_chunk(0, nc), P1n = plane_chunk(1, nc), P2n = plane_chunk(2, nc);
         }
       }
-      if (step + 1 < n_steps) rw = text_chunk(col + 16);
       // window of this step: pattern[col .. col + 16 + 2e), bit j <-> pattern[col + j]
       const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat + 96 k) & 7 == pat & 7
       const uint32_t b0 = bits_at(P0, wbit), b1 = bits_at(P1, wbit), b2 = bits_at(P2, wbit);
