@@ -1088,9 +1088,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 #pragma unroll
       for (uint32_t op = 0; op < kOps; ++op) {  // column 1, where column 0 did not settle it
         z0[op] = __ballot(!summary_nonempty(w[op], sr[op]));
-        const bool undecided = ((uint32_t)(z0[op] >> t_shift) & kFull) != kFull;
+        // rows 1..free0 of the lane's group are free at column 0: only the rows behind them matter at column 1 (s =
+        // free0 asks the least of column 1), and none if that is all of them
+        const uint32_t free0 = (uint32_t)__builtin_ctz(~((uint32_t)(z0[op] >> t_shift) & kFull));
         w[op] = 0xFFFFFFFFu, sr[op] = 0;
-        if (col1[op] && undecided) w[op] = probe(pos0[op] + (uint32_t)kStep, sr[op]);
+        if (col1[op] && t_row >= free0) w[op] = probe(pos0[op] + (uint32_t)kStep, sr[op]);
       }
 #pragma unroll
       for (uint32_t op = 0; op < kOps; ++op) z1[op] = __ballot(!summary_nonempty(w[op], sr[op]));
