@@ -731,21 +731,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
     const uint64_t mo = __ballot(ok);
     const uint32_t n_out = (uint32_t)__popcll(mo);
     if (n_out > 0) {
-      uint32_t base;
-      if (n_out <= chunk.left) {
-        base = chunk.next;
-        chunk.next += n_out, chunk.left -= n_out;
+      // every entry is one candidate: the batch fills what is left of the wave's chunk and goes on in a new one (no
+      // slots are left unused in between: unused slots are lanes the verify kernel wastes)
+      const uint32_t left = chunk.left, old_next = chunk.next;
+      uint32_t new_base = 0;
+      if (n_out > left) {
+        if (ln == 0) new_base = atomicAdd(&p.ctr[0], kSlotChunk);
+        new_base = bcast0(new_base);
+        chunk.next = new_base + (n_out - left), chunk.left = kSlotChunk - (n_out - left);
       } else {
-        pad_chunk(p, chunk);
-        base = 0;
-        if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
-        base = bcast0(base);
-        chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+        chunk.next += n_out, chunk.left -= n_out;
       }
-      if ((unsigned long long)base + n_out > p.cand_cap) {
+      const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
+      const uint32_t at_ = rank < left ? old_next + rank : new_base + (rank - left);
+      const unsigned long long last = n_out > left ? (unsigned long long)new_base + (n_out - left) : (unsigned long long)old_next + n_out;
+      if (last > p.cand_cap) {
         if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
       } else if (ok) {
-        const uint32_t at_ = base + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull));
         p.cand[at_] = cv - e64;
         p.cand_meta[at_] = (r0 + (ln >> 1)) * 2u + (ln & 1u);  // a list of one: never a full group of 8
         blk_entries[ln] = make_uint2(at_, 1u);
