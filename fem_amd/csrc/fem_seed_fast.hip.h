@@ -883,19 +883,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       }
       wave_sync_lds();
     }
-    // ---- read by read into the small-read queue ----
-    // What the loop needs per read is worked out for all of them first, (read, strand) slot ln in lane ln < 32.
-    uint32_t rd_word = 0;   // lanes 2 rb, 2 rb + 1: occurrences of the read's strands that can pass the filter; bit 8: the read stays here
-    bool mine_any = false;  // seed lanes: the seed has occurrences and its strand can pass the filter
+    // ---- into the small-read queue, as many reads at a time as fit ----
+    // What that needs per read is worked out for all of them first, (read, strand) slot ln in lane ln < 32.
+    bool mine_any = false;   // seed lanes: the seed has occurrences and its strand can pass the filter
+    uint32_t cum = 0;        // lanes 2 rb: occurrences of the reads up to rb that stay here and can pass the filter
+    uint32_t rem = 0, go_slow = 0;  // bit 2 rb: read rb waits to be pushed / has to go to the generic kernel
     if (K) {
       const uint32_t t_own = ln < 2u * kReadBlock ? slot_total[ln] : 0u, pre_own = ln < 2u * kReadBlock ? slot_pre[ln] : 0u;
       const uint32_t t_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t_own, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
       const uint32_t pre_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre_own, 0xB1, 0xF, 0xF, false);
       const bool stays = t_own <= (uint32_t)kWave && t_other <= (uint32_t)kWave && t_own + t_other <= (uint32_t)kWave;
       const uint32_t use_own = t_own > (uint32_t)p.a ? t_own : 0u, use_other = t_other > (uint32_t)p.a ? t_other : 0u;
-      rd_word = (stays ? 256u + use_own + use_other : 0u);
+      const bool of_read = ln < 2u * kReadBlock && !(ln & 1u) && ((reads >> (ln >> 1)) & 1u);
+      const bool counts = of_read && stays;
+      rem = (uint32_t)__ballot(counts), go_slow = (uint32_t)__ballot(of_read && !stays);
+      cum = wave_scan_add(counts ? use_own + use_other : 0u);
       // "candidates before the filter" of the reads that stay: uint32 per strand (src/filter.c:202), widened
-      const bool counts = ln < 2u * kReadBlock && !(ln & 1u) && stays && ((reads >> (ln >> 1)) & 1u);
       const unsigned long long pre_read = (unsigned long long)pre_own + pre_other;
       if (counts) q_pre[ln >> 1] = pre_read;
       const uint32_t lo16 = counts ? (uint32_t)(pre_read & 0xFFFFu) : 0u, hi = counts ? (uint32_t)(pre_read >> 16) : 0u;  // (hi < 2^17)
@@ -904,29 +907,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       const uint32_t use_mine = (uint32_t)__shfl((int)use_own, (int)((g_tag >> 6) & 31u));  // slot = read << 1 | strand
       mine_any = g_freq > 0 && use_mine != 0u;
     }
-    for (uint32_t todo = reads;;) {
-      const bool more = todo != 0;
-      const uint32_t rb = more ? (uint32_t)__builtin_ctz(todo) : 0u;
-      const uint32_t word = more ? (uint32_t)__builtin_amdgcn_readlane((int)rd_word, (int)(2u * rb)) : 0u;
-      const bool stays = (word & 256u) != 0u;
-      const uint32_t use = word & 255u;
-      if ((more && stays && q_entries + use > (uint32_t)kWave) || (!more && tail)) flush_small(r0);
-      if (!more) break;
-      todo &= todo - 1u;
-      if (!stays) {  // (nothing has been emitted or counted for it)
-        if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
-        queue_slow(r0 + rb);
-        continue;
+    for (uint32_t m = go_slow; m; m &= m - 1u) {  // (nothing has been emitted or counted for these)
+      const uint32_t rb = (uint32_t)__builtin_ctz(m) >> 1;
+      if (ln / 2u == rb) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+      queue_slow(r0 + rb);
+    }
+    for (uint32_t pushed = 0;;) {  // pushed: occurrences of the reads pushed so far
+      // the reads that still fit the queue: a prefix of the waiting ones (cum is monotone)
+      const uint32_t now = (uint32_t)__ballot(ln < 2u * kReadBlock && ((rem >> ln) & 1u) && q_entries + (cum - pushed) <= (uint32_t)kWave);
+      if (now) {
+        const bool mine = mine_any && ((now >> (2u * (g_tag >> 7))) & 1u);
+        const uint64_t mm = __ballot(mine);
+        if (mine) {
+          const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
+          q_lo[at_] = g_lo;
+          q_info[at_] = g_start | (g_freq << 10) | (g_tag << 17);
+        }
+        const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)cum, 31 - __builtin_clz(now));
+        q_seeds += (uint32_t)__popcll(mm), q_entries += upto - pushed;
+        pushed = upto, rem &= ~now;
+        wave_sync_lds();
       }
-      const bool mine = mine_any && (g_tag >> 7) == rb;
-      const uint64_t mm = __ballot(mine);
-      if (mine) {
-        const uint32_t at_ = q_seeds + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull));
-        q_lo[at_] = g_lo;
-        q_info[at_] = g_start | (g_freq << 10) | (g_tag << 17);
-      }
-      q_seeds += (uint32_t)__popcll(mm), q_entries += use;
-      wave_sync_lds();
+      if (rem == 0 && !tail) break;
+      flush_small(r0);  // the next read does not fit, or the block ends
+      if (rem == 0) break;
     }
   };
 
