@@ -1242,10 +1242,10 @@ constexpr uint32_t kSummaryBuckets = 24;  // buckets per summary word (SeedParam
 // exhaustively on the host: tests/test_host.py) — the integer multiplies are quarter rate
 __device__ __forceinline__ void summary_slot(uint32_t h, uint32_t &q, uint32_t &r) {
   q = (uint32_t)((float)(h >> 3) * 0.33333334f);
-  r = h - kSummaryBuckets * q;
+  r = h - __umul24(q, kSummaryBuckets);  // (24-bit multiplies are full rate; q < 2^22)
 }
 __device__ __forceinline__ bool summary_nonempty(uint32_t w, uint32_t r) { return (w >> r) & 1u; }
-__device__ __forceinline__ bool summary_multi(uint32_t w, uint32_t r) { return (w >> (kSummaryBuckets + ((r * 11u) >> 5))) & 1u; }  // r / 3
+__device__ __forceinline__ bool summary_multi(uint32_t w, uint32_t r) { return (w >> (kSummaryBuckets + (__umul24(r, 11u) >> 5))) & 1u; }  // r / 3
 
 // one lane per bucket; `summary` zeroed by the caller (n_buckets / 24 + 2 words)
 __global__ void bucket_summary_kernel(const uint32_t *lookup, uint64_t n_buckets, uint32_t *summary) {
