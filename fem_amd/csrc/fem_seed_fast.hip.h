@@ -748,8 +748,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       if (last > p.cand_cap) {
         if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
       } else if (ok) {
-        p.cand[at_] = cv - e64;
-        p.cand_meta[at_] = (r0 + (ln >> 1)) * 2u + (ln & 1u);  // a list of one: never a full group of 8
+        // (written once, read by the next kernel: non-temporal, like the block's characters — the L2 is the summary table's)
+        __builtin_nontemporal_store(cv - e64, &p.cand[at_]);
+        __builtin_nontemporal_store((r0 + (ln >> 1)) * 2u + (ln & 1u), &p.cand_meta[at_]);  // a list of one: never a full group of 8
         blk_entries[ln] = make_uint2(at_, 1u);
       }
       cand_sum += n_out;
@@ -957,7 +958,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
       const uint32_t nbytes = (uint32_t)nbytes64;
 #pragma unroll 1
       for (uint32_t i = ln * 16u; i < nbytes + 16u; i += (uint32_t)kWave * 16u)  // 64 bytes of slack behind the batch's bases
-        *(uint4 *)(blk_chars + i) = load_u128_unaligned(p.bases + blk_base + i);
+      {  // read once: non-temporal, so that the bytes do not push the summary table out of L2
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+        const u32x4 t4 = __builtin_nontemporal_load((const u32x4_unaligned *)(p.bases + blk_base + i));
+        *(uint4 *)(blk_chars + i) = make_uint4(t4.x, t4.y, t4.z, t4.w);
+      }
       wave_sync_lds();
       const uint32_t nw = nbytes / 16u + 1u;
       n_stream = 16u * nw;
@@ -1401,8 +1407,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   const uint2 entry = blk_entries[ln];
   wave_sync_lds();
   if (ln < 2u * kReadBlock && entry.x != kBlkSkip) {
-    p.cand_begin[r0 * 2u + ln] = entry.x;
-    p.cand_count[r0 * 2u + ln] = entry.y;
+    __builtin_nontemporal_store(entry.x, &p.cand_begin[r0 * 2u + ln]);
+    __builtin_nontemporal_store(entry.y, &p.cand_count[r0 * 2u + ln]);
   }
   }
 #ifdef FEM_STAMPS
