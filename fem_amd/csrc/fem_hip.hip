@@ -447,10 +447,10 @@ int launch_batch(fem_dev *h, Slot &s) {
       shape(fp.lay, &wpb, &lds_bytes, &grid);
       {
         // A wave takes blocks of kReadBlock reads at a fixed stride.  The grid is a multiple of what is resident at a
-        // time (registers included): measured on C2, exactly-resident 6.9 ms, x2 6.6, x4 6.4, x6 6.2, x8 6.2 — waves
-        // that all start together stay in the same phase and queue for the same unit.  Each wave pads its last chunk
-        // of candidate slots, though: many more waves cost the verify kernel lanes (x16: +0.4 ms there).
-        // FEM_GRID_MULT overrides the multiple (measurement only).
+        // time (registers included): measured on C2, exactly-resident 6.9 ms, x2 6.6, x4 6.4, x6 6.2, x8 6.2 — the
+        // CUs do not all run at the same pace and later generations of waves even that out (staggering the starts
+        // alone did not).  Each wave pads its last chunk of candidate slots, though: many more waves cost the verify
+        // kernel lanes (x16: +0.4 ms there).  FEM_GRID_MULT overrides the multiple (measurement only).
         const uint64_t key = ((uint64_t)R << 40) | ((uint64_t)hash << 32) | lds_bytes;
         if (h->fast_occ_key != key) h->fast_occ_key = key, h->fast_occ_blocks = fast_blocks_per_cu((int)R, hash, (int)(64u * wpb), lds_bytes);
         static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 6;
