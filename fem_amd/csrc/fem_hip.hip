@@ -75,6 +75,9 @@ struct Slot {
 
 // ctr[4] | arena_ctr[2] | stats[4]
 constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
+// ... and, in a cache line of its own behind them, the work cursor of seed_fast_kernel
+constexpr size_t kCtlWorkCursor = 128, kCtlAlloc = 256;
+static_assert(kCtlBytes <= kCtlWorkCursor, "control block layout");
 
 }  // namespace
 
@@ -328,7 +331,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     s.cand_cap = (uint32_t)want;
   }
   if (!s.d_ctl) {
-    HIP_TRY(h, hipMalloc((void **)&s.d_ctl, kCtlBytes));
+    HIP_TRY(h, hipMalloc((void **)&s.d_ctl, kCtlAlloc));
     HIP_TRY(h, hipHostMalloc((void **)&s.h_ctl, kCtlBytes, hipHostMallocDefault));
   }
   if (!s.d_arena) {
@@ -370,7 +373,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   uint32_t *d_ctr = (uint32_t *)s.d_ctl;
   unsigned long long *d_arena_ctr = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t));
   unsigned long long *d_stats = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
-  HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlBytes, s.stream));
+  HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlAlloc, s.stream));
 
   femk::SeedParams sp{};
   sp.bases = s.bases();
@@ -386,6 +389,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   sp.cand = s.d_cand, sp.cand_meta = s.d_meta, sp.cand_cap = s.cand_cap;
   sp.cand_begin = s.d_begin, sp.cand_count = s.d_count;
   sp.ctr = d_ctr;
+  sp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
   sp.stats = d_stats;
   sp.arena = s.d_arena, sp.arena_cap = s.arena_cap, sp.arena_ctr = d_arena_ctr;
   sp.lay = make_layout(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
@@ -446,14 +450,13 @@ int launch_batch(fem_dev *h, Slot &s) {
       uint32_t wpb, lds_bytes, grid;
       shape(fp.lay, &wpb, &lds_bytes, &grid);
       {
-        // A wave takes blocks of kReadBlock reads at a fixed stride.  The grid is a multiple of what is resident at a
-        // time (registers included): measured on C2, exactly-resident 6.9 ms, x2 6.6, x4 6.4, x6 6.2, x8 6.2 — the
-        // CUs do not all run at the same pace and later generations of waves even that out (staggering the starts
-        // alone did not).  Each wave pads its last chunk of candidate slots, though: many more waves cost the verify
-        // kernel lanes (x16: +0.4 ms there).  FEM_GRID_MULT overrides the multiple (measurement only).
+        // The kernel's waves pull blocks of reads from a cursor: the grid is exactly what is resident at a time
+        // (registers included).  (With a fixed stride per wave the same grid took 6.9 ms against 6.2 at six times as
+        // many waves: the CUs do not all run at the same pace.  Every wave pads its last chunk of candidate slots, so
+        // extra waves cost the verify kernel lanes.)  FEM_GRID_MULT overrides the multiple (measurement only).
         const uint64_t key = ((uint64_t)R << 40) | ((uint64_t)hash << 32) | lds_bytes;
         if (h->fast_occ_key != key) h->fast_occ_key = key, h->fast_occ_blocks = fast_blocks_per_cu((int)R, hash, (int)(64u * wpb), lds_bytes);
-        static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 6;
+        static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 1;
         const uint64_t per_cu = h->fast_occ_blocks > 0 ? (uint64_t)h->fast_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         const uint64_t wanted = (s.n_reads + (uint64_t)femk::kReadBlock * wpb - 1) / ((uint64_t)femk::kReadBlock * wpb);
         grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wanted, (uint64_t)h->n_cu * per_cu * mult));

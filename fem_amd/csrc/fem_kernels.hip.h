@@ -55,6 +55,7 @@ struct SeedParams {
   const uint64_t *read_off;
   uint32_t n_reads;     // one past the last read of this launch
   uint32_t read_begin;  // first read of this launch (seed_fast_kernel; the generic kernel always covers its queue / all reads)
+  uint32_t *work_cursor;  // seed_fast_kernel: reads handed out so far (own cache line, zeroed per launch)
   const uint32_t *lookup;
   const uint64_t *occ;
   uint32_t inf32;  // (uint32_t)occurrence_table_size, the DP's +inf (src/filter.c:9)

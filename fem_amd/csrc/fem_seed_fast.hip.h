@@ -504,7 +504,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
   const uint32_t ln = lane_id();
   const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and known to be
-  const uint32_t waves_per_block = blockDim.x >> 6;
   uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
   uint32_t *pkw = (uint32_t *)(wbase + p.lay.pkw);
   uint32_t *nkw = (uint32_t *)(wbase + p.lay.nkw);
@@ -526,8 +525,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   SlotChunk qchunk;  // slow-read queue entries
   [[maybe_unused]] Prof prof;
 
-  const uint32_t wave_global = blockIdx.x * waves_per_block + wave_in_block;
-  const uint32_t n_waves = gridDim.x * waves_per_block;
 
   // ---- lists -> candidates -> clip + emit for ONE read whose selected seeds sit in the lanes (lane strand * kSeeds +
   //      group * R + run).  Returns false if the read has to go to the generic kernel (nothing emitted then). ----
@@ -937,7 +934,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
 
   // Each wave takes blocks of kReadBlock consecutive reads: its loads of read bases and its stores of the
   // per-(read, strand) begin/count entries then cover whole cache lines instead of one word per line and XCD.
-  for (uint32_t r0 = p.read_begin + wave_global * kReadBlock; r0 < p.n_reads; r0 += n_waves * kReadBlock) {
+  // The blocks are handed out dynamically, kPullBlocks at a time from one cursor (the CUs do not all run at the same
+  // pace: a fixed stride needed six times the resident waves to even that out, and every extra wave pads a chunk of
+  // candidate slots).  One returning atomic per 64 reads and wave.
+  constexpr uint32_t kPullBlocks = 4;  // (one block per pull: 7.8 ms, the cursor's atomics serialize; two 5.55, four 5.47, eight 5.55)
+  for (;;) {
+  uint32_t pull = 0;
+  if (ln == 0) pull = atomicAdd(p.work_cursor, kPullBlocks * kReadBlock);
+  pull = bcast0(pull);
+  if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
+  const uint32_t pull_first = p.read_begin + pull;
+  const uint32_t pull_end = p.n_reads - pull_first > kPullBlocks * kReadBlock ? pull_first + kPullBlocks * kReadBlock : p.n_reads;
+  for (uint32_t r0 = pull_first; r0 < pull_end; r0 += kReadBlock) {
   // begin / count of the block's 2 * kReadBlock (read, strand) entries gather in LDS and go out in one vector store;
   // kBlkSkip marks reads left to the generic kernel (it writes their entries)
   if (HASH && ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
@@ -1409,6 +1417,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(lean_w
   if (ln < 2u * kReadBlock && entry.x != kBlkSkip) {
     __builtin_nontemporal_store(entry.x, &p.cand_begin[r0 * 2u + ln]);
     __builtin_nontemporal_store(entry.y, &p.cand_count[r0 * 2u + ln]);
+  }
   }
   }
 #ifdef FEM_STAMPS
