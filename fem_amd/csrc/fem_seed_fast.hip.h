@@ -1,16 +1,18 @@
 // fem_seed_fast.hip.h — the seed + filter kernel for the parameters `FEM map` actually runs:
 // k = 12, step = 3 (reference src/FEM_map.c:67-68) and R = e + 1 + a fixed at compile time (1..10).
 //
-// One wavefront per block of 16 reads.  Per read:
-//   encode     four characters per lane, SWAR char -> 2-bit code, packed into LDS
-//   hash       24-bit k-mer hash per lane from the packed words; reverse strand = reversed complement of the same hash
-//   lookup     frequency of every seed on both strands                                  (src/index.h:22-28)
-// then, in two forms:
-//   HASH (dense index, long occurrence lists): per read — seed-selection DP (DPP prefix-min, clz traceback,
+// A wavefront takes blocks of 16 consecutive reads (pulled from a cursor), in one of two forms:
+//   HASH (dense index, long occurrence lists), per read: encode (four characters per lane, SWAR char -> 2-bit code,
+//     packed into LDS), 24-bit k-mer hash per lane (reverse strand = reversed complement of the same hash), frequency
+//     of every seed on both strands (src/index.h:22-28), seed-selection DP (DPP prefix-min, clz traceback,
 //     src/filter.c:3-43), lists in lanes or the hash-join form, staged greedy de-dup, range clip, hand-over
 //     (src/filter.c:45-144);
-//   lean (sparse index): the read only queues its live phase groups; select_flush runs DP + traceback for a dozen
-//     groups of several reads at once, flush_small finishes all queued reads' lists in one pass over the lanes.
+//   lean (sparse index), per block: the 16 reads' characters are staged and encoded at once into forward /
+//     reverse-complement / N streams (a seed's hash on either strand is a 24-bit window of one stream), the reads'
+//     parameters are worked out in lanes, and round 1 of the lookups (columns 0 and 1 of every row, against the bucket
+//     summaries) finds each read's live phase groups; then per read: round 2 looks up the live groups' seeds straight
+//     into the group queue; select_flush runs DP + traceback for a dozen groups of several reads at once, flush_small
+//     finishes all queued reads' lists in one pass over the lanes.
 // Reads that do not fit (more than 64 occurrences selected, a DP group wider than 64 columns, ...) are appended to a
 // queue and done by the generic seed_filter_kernel.  Results are identical.
 #pragma once
@@ -29,7 +31,7 @@ constexpr uint32_t kBlkSkip = 0xFFFFFFFFu;  // (begin) entry of a read the fast 
 constexpr uint32_t kGroupQueue = 12;
 constexpr uint32_t kQueueSeeds = 64;
 constexpr uint32_t kQueueBytes = kQueueSeeds * 8u + kReadBlock * 4u + kReadBlock * 8u;  // seeds, the reads' lengths and pre-filter counts
-// LDS scratch of flush_small (bytes from the seed table's offset; the regions behind it are dead between reads)
+// LDS scratch of flush_small (bytes from the group queue's offset: its groups are all in lanes by then)
 // Arrays whose lifetimes do not overlap share words: gmax -> sv, own -> firstp, nval -> slot_n / slot_first, slen -> lastp.
 constexpr uint32_t kFlSv = 0, kFlMax = 0, kFlEv = 544, kFlFirst = 1056, kFlNval = 1312, kFlSlotN = 1312, kFlSlotFirst = 1440,
                    kFlLen = 1568, kFlLast = 1568, kFlSlotLast = 1824, kFlushScratchBytes = 1952;
