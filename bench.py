@@ -103,12 +103,16 @@ def main():
 
     def step_once():
         dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
-        st = dev.fetch_stats(slot=0)  # waits for both kernels (and re-runs the batch if a scratch buffer had to grow)
-        if world > 1:  # MappingStats reduction (reference src/FEM_map.c:200-212) = one 40-byte RCCL all-reduce
-            stats_dev.copy_(torch.from_numpy(st.astype(np.int64)))
-            dist.all_reduce(stats_dev)
-            return stats_dev.cpu().numpy().astype(np.uint64), st
-        return st, st
+        return dev.fetch_stats(slot=0)  # waits for the kernels (and re-runs the batch if a scratch buffer had to grow)
+
+    def reduce_stats(st):
+        # MappingStats reduction (reference src/FEM_map.c:200-212: once per job, after the last batch) = one 40-byte
+        # RCCL all-reduce
+        if world == 1:
+            return st
+        stats_dev.copy_(torch.from_numpy(st.astype(np.int64)))
+        dist.all_reduce(stats_dev)
+        return stats_dev.cpu().numpy().astype(np.uint64)
 
     def fence():
         if world > 1:
@@ -121,8 +125,11 @@ def main():
     dev.reset_timing()
     fence()
     t_start = time.perf_counter()
+    job_stats = np.zeros(5, dtype=np.uint64)
     for _ in range(args.steps):
-        total_stats, local_stats = step_once()
+        local_stats = step_once()
+        job_stats += local_stats.astype(np.uint64)
+    total_stats = reduce_stats(job_stats)  # (inside the timed region: it is the path's one exchange)
     fence()
     elapsed = time.perf_counter() - t_start
     dev.set_timing(False)
@@ -184,9 +191,11 @@ def main():
         "dtype": "u64/u32 integer + 32-bit Myers bit-vectors", "data": "synthetic",
         "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": L, "e": e, "a": a, "k": k, "step": step,
                    "index_entries": n_occ, "parallelism": "reads sharded x%d, index replicated" % world,
+                   # MappingStats of the whole job (all ranks, all timed steps), as the reference prints them at its end
                    "counters": {"reads": int(total_stats[0]), "mapped_reads": int(total_stats[1]),
                                 "pre_filter": int(total_stats[2]), "candidates": int(total_stats[3]),
                                 "mappings": int(total_stats[4])},
+                   "counters_per_step_per_gpu": [int(x) for x in local_stats],
                    "algorithmic_bytes_per_step_per_gpu": seed_bytes + verify_bytes,
                    "kernel_ms_per_launch": {k_: round(v_, 4) for k_, v_ in per_launch.items()},
                    "kernel_launches_per_step": {k_: round(v_, 2) for k_, v_ in launches.items()},
