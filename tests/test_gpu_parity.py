@@ -176,3 +176,14 @@ def test_sparse_index_sweep_over_lengths_and_errors(dev, e, a, lengths):
     want, got = run_both(dev, seqs, reads, e=e, a=a)
     assert want.stats[1] > len(reads) // 3
     assert_same(want, got)
+
+
+@pytest.mark.parametrize("n_reads", [1, 15, 16, 17, 63, 64, 65, 129])
+def test_batch_sizes_around_the_block_and_pull_sizes(dev, n_reads):
+    # the fast seed kernel takes reads in blocks of 16, pulled 64 at a time from a cursor: batches that end inside a
+    # block, at a block's end, and inside / at the end of a pull
+    rng = np.random.default_rng(7000 + n_reads)
+    seqs = [util.rand_seq(rng, 150_000)]
+    reads = util.make_reads(rng, seqs, n_reads, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert_same(want, got)
