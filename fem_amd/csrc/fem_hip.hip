@@ -16,6 +16,7 @@
 #include "fem_index_build.hip.h"
 #include "fem_kernels.hip.h"
 #include "fem_seed_fast.hip.h"
+#include "fem_seed_dense.hip.h"
 #include "fem_tail.hip.h"
 
 namespace {
@@ -94,6 +95,10 @@ struct fem_dev {
   uint64_t fast_occ_key = ~0ull;  // seed_fast_kernel residency, cached per (R, form, LDS bytes)
   int fast_occ_blocks = 0;
   uint32_t *d_summary = nullptr;  // bucket summaries (femk::SeedParams::summary), built for sparse indexes only
+  // dense indexes: occurrence table in 32-bit global coordinates + its sequence tables (fem_seed_dense.hip.h)
+  uint32_t *d_occ32 = nullptr, *d_goff = nullptr, *d_blkseq = nullptr;
+  int dense_occ_blocks = 0;
+  uint64_t dense_occ_key = ~0ull;
   // reference
   uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
@@ -112,6 +117,8 @@ struct fem_dev {
   uint64_t t_n[7] = {0, 0, 0, 0, 0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
+  bool force_dense = false;    // FEM_FORCE_DENSE=1: build the 32-bit tables and run seed_dense_kernel whatever the index density (test hook)
+  bool no_dense = false;       // FEM_NO_DENSE=1: never run seed_dense_kernel (measurement / A-B hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
   std::vector<hipEvent_t> event_pool;
 };
@@ -249,6 +256,67 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   return l;
 }
 
+// LDS of one wave of seed_dense_kernel: packed bases, (lookup, frequency) per seed (later the strands' candidates), DP
+// take bits, flagged values per phase group, scatter, the block's begin/count entries, the join's bitmap
+femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
+  femk::SeedLayout l{};
+  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
+  const uint32_t n_groups = 2u * (uint32_t)p.step;
+  l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
+  l.n_words = (max_len + 15u) / 16u + 2u;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  l.pkw = take(l.n_words * 4u);
+  l.nkw = take(l.n_words * 4u);
+  l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 4u));
+  l.dp_bits = take(n_groups * R * 8u);
+  l.X = take(64u * 4u);
+  l.A = take(3u * 64u * 4u);
+  l.B = take(2u * femk::kReadBlock * 8u);
+  l.F = take(femk::dense_bitmap_words((int)R) * 4u);
+  l.wave_bytes = o;
+  return l;
+}
+
+template <int R>
+void launch_dense_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL((femk::seed_dense_kernel<R>), grid, block, lds, st, sp);
+}
+template <int R>
+int dense_blocks_per_cu_r(int block, uint32_t lds) {
+  int nb = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_dense_kernel<R>, block, lds) == hipSuccess ? nb : 0;
+}
+#define FEM_DENSE_SWITCH(R, CALL)      \
+  switch (R) {                         \
+    case 1: CALL(1); break;            \
+    case 2: CALL(2); break;            \
+    case 3: CALL(3); break;            \
+    case 4: CALL(4); break;            \
+    case 5: CALL(5); break;            \
+    case 6: CALL(6); break;            \
+    case 7: CALL(7); break;            \
+    case 8: CALL(8); break;            \
+    case 9: CALL(9); break;            \
+    default: CALL(10); break;          \
+  }
+int dense_blocks_per_cu(int R, int block, uint32_t lds) {
+  int nb = 0;
+#define FEM_CALL(r) nb = dense_blocks_per_cu_r<r>(block, lds)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+  return nb;
+}
+void launch_dense(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+#define FEM_CALL(r) launch_dense_r<r>(grid, block, lds, st, sp)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+}
+
 template <int R>
 void launch_fast(bool hash, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
   if (hash)
@@ -317,7 +385,10 @@ int ensure_outputs(fem_dev *h, Slot &s) {
     HIP_TRY(h, hipMalloc((void **)&s.d_nmap, cap * sizeof(uint32_t)));
     s.per_read_cap = cap;
   }
-  if (!s.d_cand) {
+  if (!s.d_cand || !s.d_meta || !s.d_ed || !s.d_end || s.cand_cap == 0) {
+    for (void *p : {(void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed, (void *)s.d_end})
+      if (p) (void)hipFree(p);
+    s.d_cand = nullptr, s.d_meta = nullptr, s.d_ed = nullptr, s.d_end = nullptr;
     uint64_t want = 2 * s.n_reads + (5u << 20);  // ~1 candidate per strand on typical data + chunk padding
     if (h->tiny_buffers) want = 512;
     want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
@@ -356,6 +427,7 @@ int ensure_outputs(fem_dev *h, Slot &s) {
 
 int grow_candidates(fem_dev *h, Slot &s, uint64_t want) {
   if (want > 0xFFFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^32 candidates in one batch; split the batch");
+  s.cand_cap = 0;  // published again only once all four arrays exist (ensure_outputs re-allocates otherwise)
   for (void *p : {(void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed, (void *)s.d_end})
     if (p) (void)hipFree(p);
   s.d_cand = nullptr, s.d_meta = nullptr, s.d_ed = nullptr, s.d_end = nullptr;
@@ -442,7 +514,25 @@ int launch_batch(fem_dev *h, Slot &s) {
       h->verify_blocks_per_cu = nb;
     }
     const uint32_t vgrid = (uint32_t)h->n_cu * (uint32_t)h->verify_blocks_per_cu;
-    if (use_fast) {
+    if (use_fast && h->d_occ32) {
+      // dense index: 32-bit coordinates, bitmap join (fem_seed_dense.hip.h)
+      femk::SeedParams fp = sp;
+      fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
+      fp.lay = make_layout_dense(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
+      if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
+      const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
+      const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
+      const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
+      if (h->dense_occ_key != key) h->dense_occ_key = key, h->dense_occ_blocks = dense_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
+      static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 1;
+      const uint64_t per_cu = h->dense_occ_blocks > 0 ? (uint64_t)h->dense_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+      const uint64_t wanted = (s.n_reads + (uint64_t)femk::kReadBlock * wpb - 1) / ((uint64_t)femk::kReadBlock * wpb);
+      const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wanted, (uint64_t)h->n_cu * per_cu * mult));
+      fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
+      rc = timed(0, s.stream, [&] { launch_dense(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+      if (rc) return rc;
+      sp.work_queue = s.d_slow;  // the generic kernel finishes what the dense one queued
+    } else if (use_fast) {
       femk::SeedParams fp = sp;
       // long occurrence lists (dense index): the hash-join form of the kernel; short ones: lists in lanes only
       const bool hash = h->force_hash || (double)h->n_occ > (double)h->n_lookup;
@@ -522,6 +612,54 @@ int refresh_summary(fem_dev *h) {
   return FEM_OK;
 }
 
+// After index AND reference are resident: for dense indexes (long occurrence lists) derive the occurrence table in
+// 32-bit global coordinates that seed_dense_kernel joins on (fem_seed_dense.hip.h).  Skipped (the 64-bit hash-join
+// form of seed_fast_kernel runs instead) when the coordinates do not fit 32 bits.
+constexpr double kDenseMinAvgBucket = 4.0;
+int refresh_dense(fem_dev *h) {
+  for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq})
+    if (p) (void)hipFree(p);
+  h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr;
+  if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
+  const uint64_t n_buckets = h->n_lookup - 1;
+  if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
+  if (h->n_seq > femk::kDenseMaxSeq) return FEM_OK;
+  std::vector<uint32_t> goff(h->n_seq + 1);
+  uint64_t at = femk::kDenseGap;
+  for (uint32_t i = 0; i < h->n_seq; ++i) {
+    goff[i] = (uint32_t)at;
+    at += (uint64_t)h->seq_len[i] + femk::kDenseGap;
+    if (at > femk::kDenseLimit) return FEM_OK;  // does not fit 32 bits: 64-bit join
+  }
+  goff[h->n_seq] = (uint32_t)at;
+  const uint32_t n_blk = (femk::kDenseRemap >> femk::kDenseBlkShift) + 1u;
+  std::vector<uint32_t> blkseq(n_blk, 0);
+  for (uint32_t b = 0, sq = 0; b < n_blk; ++b) {
+    const uint64_t first = (uint64_t)b << femk::kDenseBlkShift;
+    while (sq + 1u < h->n_seq && goff[sq + 1u] <= first) ++sq;
+    blkseq[b] = sq;
+  }
+  uint32_t *d_bad = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&h->d_goff, goff.size() * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_occ32, (h->n_occ + 64) * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&d_bad, sizeof(uint32_t)));
+  HIP_TRY(h, hipMemset(d_bad, 0, sizeof(uint32_t)));
+  HIP_TRY(h, hipMemcpy(h->d_goff, goff.data(), goff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_blkseq, blkseq.data(), blkseq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq,
+                     h->d_occ32, d_bad);
+  HIP_TRY(h, hipGetLastError());
+  uint32_t bad = 0;
+  HIP_TRY(h, hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost));
+  (void)hipFree(d_bad);
+  if (bad) {  // the index names sequences the reference does not have: leave that to the 64-bit path's checks
+    (void)hipFree(h->d_occ32);
+    h->d_occ32 = nullptr;
+  }
+  return FEM_OK;
+}
+
 int check_slot(fem_dev *h, int slot) {
   if (!h) return FEM_ERR_INVALID;
   if (slot < 0 || slot >= kSlots) return fail(h, FEM_ERR_INVALID, "slot out of range");
@@ -572,6 +710,10 @@ int fem_dev_open(int device, fem_dev **out) {
   h->force_generic = fg && fg[0] == '1';
   const char *fh = getenv("FEM_FORCE_HASH");
   h->force_hash = fh && fh[0] == '1';
+  const char *fd = getenv("FEM_FORCE_DENSE");
+  h->force_dense = fd && fd[0] == '1';
+  const char *nd = getenv("FEM_NO_DENSE");
+  h->no_dense = nd && nd[0] == '1';
   const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
   h->tiny_buffers = tb && tb[0] == '1';
   *out = h;
@@ -598,7 +740,7 @@ int fem_dev_close(fem_dev *h) {
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
-                  (void *)h->d_plane[2], (void *)h->d_plane[3]})
+                  (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -626,7 +768,8 @@ int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lo
   HIP_TRY(h, hipMemcpy(h->d_lookup, lookup, n_lookup * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (n_occ) HIP_TRY(h, hipMemcpy(h->d_occ, occ, n_occ * sizeof(uint64_t), hipMemcpyHostToDevice));
   h->n_lookup = n_lookup, h->n_occ = n_occ, h->k = k, h->step = step;
-  return refresh_summary(h);
+  int rc = refresh_summary(h);
+  return rc ? rc : refresh_dense(h);
 }
 
 int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len) {
@@ -673,7 +816,7 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     HIP_TRY(h, hipDeviceSynchronize());
   }
   h->ref_bytes = total, h->n_seq = n_seq;
-  return FEM_OK;
+  return refresh_dense(h);
 }
 
 int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_out, uint64_t *occ_out, uint64_t occ_cap,
@@ -691,12 +834,25 @@ int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_ou
   if (rc != FEM_OK) return fail(h, rc, err);
   h->n_lookup = (1ull << (2 * k)) + 1, h->n_occ = n_occ, h->k = k, h->step = step;
   if ((rc = refresh_summary(h))) return rc;
+  if ((rc = refresh_dense(h))) return rc;
   if (n_occ_out) *n_occ_out = n_occ;
   if (lookup_out)
     HIP_TRY(h, hipMemcpy(lookup_out, h->d_lookup, h->n_lookup * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (occ_out) {
     if (occ_cap < n_occ) return fail(h, FEM_ERR_INVALID, "occ_out too small");
     if (n_occ) HIP_TRY(h, hipMemcpy(occ_out, h->d_occ, n_occ * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return FEM_OK;
+}
+
+int fem_dev_fetch_index(fem_dev *h, uint32_t *lookup_out, uint64_t *occ_out, uint64_t occ_cap) {
+  if (!h) return FEM_ERR_INVALID;
+  if (!h->d_lookup) return fail(h, FEM_ERR_STATE, "no index is resident");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (lookup_out) HIP_TRY(h, hipMemcpy(lookup_out, h->d_lookup, h->n_lookup * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (occ_out) {
+    if (occ_cap < h->n_occ) return fail(h, FEM_ERR_INVALID, "occ_out too small");
+    if (h->n_occ) HIP_TRY(h, hipMemcpy(occ_out, h->d_occ, h->n_occ * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
   return FEM_OK;
 }
@@ -757,8 +913,8 @@ int fem_dev_sync(fem_dev *h, int slot) {
   if (rc) return rc;
   Slot &s = h->slot[slot];
   if (!s.mapped) return fail(h, FEM_ERR_STATE, "nothing was mapped in this slot");
+  HIP_TRY(h, hipSetDevice(h->device));  // the callers (fetch, fetch_records) allocate and launch on this device
   if (s.synced) return FEM_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
   for (int attempt = 0; attempt < 8; ++attempt) {
     HIP_TRY(h, hipStreamSynchronize(s.stream));
     drain_timing(h, s);

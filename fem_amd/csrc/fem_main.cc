@@ -132,8 +132,7 @@ int index_main(int argc, char **argv) {
   if ((rc = fem_dev_build_index(h, k, step, nullptr, nullptr, 0, &n_occ))) return dev_fail(h, "index build", rc);
   std::vector<uint32_t> lookup(((size_t)1 << (2 * k)) + 1);
   std::vector<uint64_t> occ(n_occ ? n_occ : 1);
-  if ((rc = fem_dev_build_index(h, k, step, lookup.data(), occ.data(), occ.size(), &n_occ)))
-    return dev_fail(h, "index build", rc);
+  if ((rc = fem_dev_fetch_index(h, lookup.data(), occ.data(), occ.size()))) return dev_fail(h, "index fetch", rc);
   fprintf(stderr, "Collected %lu seeds.\n", (unsigned long)n_occ);
   fprintf(stderr, "Lookup table size: %lu, occurrence table size: %lu.\n", (unsigned long)lookup.size(), (unsigned long)n_occ);
   fprintf(stderr, "Built index in %fs.\n", real_time() - t0);

@@ -1,0 +1,520 @@
+// fem_seed_dense.hip.h — seed + filter kernel for DENSE indexes (long occurrence lists: a 3 Gbp reference has ~60
+// entries per 12-mer bucket), k = 12, step = 3, R = e + 1 + a at compile time.  What BASELINE configs C3-C5 run.
+//
+// Same semantics as generate_group_seeding_candidates (reference src/filter.c:146-223); the data layout and the
+// join are built for the machine:
+//
+//   * 32-BIT OCCURRENCE COORDINATES.  The index file's occurrence table is uint64 `seq << 32 | pos`
+//     (src/index.c:67).  Next to it the library keeps a derived uint32 copy in ONE global coordinate,
+//     G = goff[seq] + pos, with a gap of kDenseGap positions between sequences, so that a whole list is half the
+//     bytes, every compare / subtract / LDS word of the join is one 32-bit operation, and candidates from different
+//     sequences can never come within e of each other.  The reference drops an occurrence whose position is below
+//     the seed's offset in the read (`(uint32_t)occ >= start`, src/filter.c:89,106).  Only entries with
+//     pos < kDenseNear (= the longest read the device path takes) can ever be dropped that way; those are stored
+//     in a separate code space (kDenseRemap | seq << 10 | pos) and resolved exactly on a rare path.
+//   * PER-RUN CHUNKS ON SCALAR BASES.  A seed's list is read by consecutive lanes from a wave-uniform base
+//     (coalesced; no per-lane run selection), at most two 64-entry chunks per seed in registers.  Longer lists
+//     (repeats) send the read to the generic kernel.
+//   * BITMAP JOIN IN LDS.  merge_candidate_locations + additional_qgram_filter (src/filter.c:80-131) keep a value
+//     iff a+1 values of the multiset lie in [v, v+e].  Two bits per 8-position slot (present / hit twice), set
+//     with one returning LDS atomic per entry: a value can only take part in a within-e pair if its slot was hit
+//     twice or a neighbouring slot is present.  One two-word LDS read covers the three slots.  The few flagged
+//     values (true hits + ~3 n^2 / slots chance ones) are compacted and the filter is evaluated exactly on them.
+//   * ONE CANDIDATE PER STRAND IS THE COMMON CASE.  If every survivor of the strand's three phase groups lies
+//     within e of the smallest, the staged greedy merge (src/filter.c:45-78, :209-213) leaves exactly that
+//     smallest value: one wave min/max instead of sort + merge.  Anything else takes the exact general path.
+//
+// Reads this kernel cannot finish (a list over 128 entries, more than 64 flagged values in a group, DP wider than
+// a wave, a == 0) are queued for the generic seed_filter_kernel; results are identical either way.
+#pragma once
+#include "fem_seed_fast.hip.h"
+
+namespace femk {
+
+constexpr uint32_t kDenseGap = 2048u;          // positions between two sequences in the global coordinate (> e + 1)
+constexpr uint32_t kDenseNear = 1024u;         // entries with pos < this are stored remapped (>= the longest read)
+constexpr uint32_t kDenseRemap = 0xF0000000u;  // remapped entry: kDenseRemap | seq << 10 | pos  (seq < 2^18)
+constexpr uint32_t kDenseMaxSeq = 1u << 18;
+constexpr uint32_t kDenseLimit = 0xEFFFF000u;  // global coordinates stay below this
+constexpr uint32_t kDenseSent = 0xEFFFFFFFu;   // "no entry" in a lane: still above kDenseVLimit after the start is subtracted
+constexpr uint32_t kDenseVLimit = 0xEFFFF800u; // v < this <=> the lane holds a real entry
+constexpr uint32_t kDenseBlkShift = 20;        // blkseq[] granularity: first sequence at or before a 1 Mi block
+constexpr uint32_t kDenseMaxList = 128u;       // entries of one seed's list this kernel takes (two chunks)
+
+// bitmap geometry: two bits per slot of 8 positions; slots are offset by one so that a window never starts below 0
+constexpr uint32_t dense_slots(int R) { return R >= 7 ? 32768u : 16384u; }
+constexpr uint32_t dense_bitmap_words(int R) { return dense_slots(R) / 16u + 2u; }
+
+// ---- derived tables (built once per index upload) ----
+// occ (uint64 seq << 32 | pos) -> global 32-bit coordinates; *bad is set if an entry names a sequence >= n_seq
+__global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32_t *goff, uint32_t n_seq, uint32_t *out,
+                                   uint32_t *bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t o = occ[i];
+    const uint32_t seq = (uint32_t)(o >> 32), pos = (uint32_t)o;
+    uint32_t v;
+    if (seq >= n_seq) {
+      v = kDenseSent;
+      *bad = 1u;
+    } else if (pos < kDenseNear) {
+      v = kDenseRemap | (seq << 10) | pos;
+    } else {
+      v = goff[seq] + pos;
+    }
+    out[i] = v;
+  }
+}
+
+// wave-wide min / max of a 32-bit value (DPP scans; the result is wave-uniform)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+  constexpr uint32_t kFill = 0xFFFFFFFFu;
+  x = dpp_min_step<0x111, 0xF>(x, kFill), x = dpp_min_step<0x112, 0xF>(x, kFill), x = dpp_min_step<0x114, 0xF>(x, kFill);
+  x = dpp_min_step<0x118, 0xF>(x, kFill), x = dpp_min_step<0x142, 0xA>(x, kFill), x = dpp_min_step<0x143, 0xC>(x, kFill);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(x), 63);
+}
+
+// merge_kvec_t_uint64_t (src/filter.c:45-78) on 32-bit global coordinates: `fs` = nF sorted survivors in lanes
+// 0..nF-1, `cv` = the nA candidates so far.  Returns the new count, 0xFFFFFFFF if the list outgrows the wave.
+__device__ __forceinline__ uint32_t dense_merge_group(uint32_t &cv, uint32_t nA, uint32_t fs, uint32_t nF, uint32_t e) {
+  const uint32_t ln = lane_id();
+  uint32_t merged = 0, last_kept = 0, nB = 0, ia = 0, jf = 0;
+  while (ia < nA || jf < nF) {
+    const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(ia < nA ? ia : 0));
+    const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)fs, (int)(jf < nF ? jf : 0));
+    const bool take_a = ia < nA && (jf >= nF || xa < xf);
+    const uint32_t x = take_a ? xa : xf;
+    ia += take_a ? 1u : 0u;
+    jf += take_a ? 0u : 1u;
+    if (nB == 0 || x > last_kept + e) {  // (global coordinates stay far below 2^32 - e)
+      if (nB >= (uint32_t)kWave) return 0xFFFFFFFFu;
+      merged = ln == nB ? x : merged;
+      ++nB;
+      last_kept = x;
+    }
+  }
+  cv = merged;
+  return nB;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One strand.  Lane lane0 + g * R + t holds run t of phase group g: (start, lookup[h], frequency), runs in the
+// order of the stable frequency sort (src/filter.c:204).  Leaves the strand's candidates (global coordinates,
+// ascending, before the range clip) in lanes 0..n-1 of `cv` and returns n; 0xFFFFFFFF = hand the read to the
+// generic kernel.  `bitmap` is all-zero on entry and on exit.
+// ---------------------------------------------------------------------------------------------------------
+template <int R>
+__device__ uint32_t dense_strand(const SeedParams &p, uint32_t lane0, uint32_t s_start, uint32_t s_lo, uint32_t s_freq,
+                                 uint32_t *bitmap, uint32_t *flg /* LDS [3][64] */, uint32_t *scatter /* LDS [64] */,
+                                 uint32_t &cv) {
+  const uint32_t ln = lane_id();
+  constexpr uint32_t kSlots = dense_slots(R);
+  constexpr uint32_t kBitMask = 2u * kSlots - 2u;  // 2 * slot, as a bit index
+  const uint32_t e = (uint32_t)p.e;
+  const uint32_t *occ32 = p.occ32;
+  uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value it has seen
+  uint64_t pass_mask[kStep] = {0, 0, 0};
+  uint32_t n_flagged[kStep] = {0, 0, 0};
+  bool any_pass = false;
+#pragma unroll
+  for (int g = 0; g < kStep; ++g) {
+    // ---- the group's runs as wave-uniform scalars ----
+    uint32_t f[R], lo[R], st[R];
+    uint32_t n_g = 0, f_max = 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const int j = (int)lane0 + g * R + t;
+      f[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
+      lo[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
+      st[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
+      f_max = f[t] > f_max ? f[t] : f_max;
+      n_g += f[t] < 0x10000u ? f[t] : 0x10000u;
+    }
+    if (n_g <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
+    if (n_g == f[R - 1]) continue;       // the last seed is merged only while the list has elements (src/filter.c:85)
+    if (f_max > kDenseMaxList) return 0xFFFFFFFFu;
+    // ---- load: chunk c of run t = entries 64 c + lane ----
+    uint32_t val[R][2];
+    uint32_t remap = 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      val[t][0] = kDenseSent, val[t][1] = kDenseSent;
+      if (ln < f[t]) val[t][0] = occ32[lo[t] + ln];
+      if (f[t] > (uint32_t)kWave && ln + (uint32_t)kWave < f[t]) val[t][1] = occ32[lo[t] + (uint32_t)kWave + ln];
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      remap |= (uint32_t)(val[t][0] >= kDenseRemap);
+      if (f[t] > (uint32_t)kWave) remap |= (uint32_t)(val[t][1] >= kDenseRemap);
+      val[t][0] -= st[t], val[t][1] -= st[t];  // (the sentinel stays above kDenseVLimit: start < 1024)
+    }
+    uint32_t max_u = 0;
+    bool any_u;
+    if (__builtin_expect(__any(remap != 0), 0)) {
+      // rare: entries within kDenseNear of a sequence start.  Resolve them exactly (pos >= start or dropped),
+      // then the maximum of U by a wave reduction (a dropped entry may sit at the end of a run).
+      uint32_t mx = 0, have_u = 0;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint32_t raw = val[t][c] + st[t];
+          if (raw >= kDenseRemap) {
+            const uint32_t sq = (raw - kDenseRemap) >> 10, pos = raw & (kDenseNear - 1u);
+            val[t][c] = pos >= st[t] ? p.goff[sq] + pos - st[t] : kDenseSent;
+          }
+          if (t < R - 1 && val[t][c] < kDenseVLimit) mx = val[t][c] > mx ? val[t][c] : mx, have_u = 1;
+        }
+      }
+      any_u = __any(have_u != 0);
+      max_u = wave_max_u32(mx);
+    } else {
+      // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
+      any_u = true;
+#pragma unroll
+      for (int t = 0; t < R - 1; ++t) {
+        if (f[t] == 0) continue;
+        const uint32_t lastv = f[t] > (uint32_t)kWave ? (uint32_t)__builtin_amdgcn_readlane((int)val[t][1], (int)((f[t] - 1u) & 63u))
+                                                      : (uint32_t)__builtin_amdgcn_readlane((int)val[t][0], (int)(f[t] - 1u));
+        max_u = lastv > max_u ? lastv : max_u;
+      }
+    }
+    if (!any_u) continue;
+    // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
+#pragma unroll
+    for (int c = 0; c < 2; ++c) val[R - 1][c] = val[R - 1][c] <= max_u ? val[R - 1][c] : kDenseSent;
+    // ---- insert ----
+    uint32_t mirrored = 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
+        const uint32_t v = val[t][c];
+        if (v < kDenseVLimit) {
+          const uint32_t b = (v >> 2) & kBitMask;  // 2 * slot: bit index of present(slot - 1) in the offset layout
+          const uint32_t bi = b + 2u;              // present(slot), twice(slot) = bi + 1
+          const uint32_t bit = 1u << (bi & 31u);
+          const uint32_t old = atomicOr(&bitmap[bi >> 5], bit);
+          if (old & bit) atomicOr(&bitmap[bi >> 5], bit << 1);
+          if (b == 0u || b == kBitMask) {  // the table wraps: mirror the edge slots into the padding slots
+            if (b == 0u) atomicOr(&bitmap[(2u * kSlots + 2u) >> 5], 1u << ((2u * kSlots + 2u) & 31u));
+            else atomicOr(&bitmap[0], 1u);
+            mirrored = 1;
+          }
+        }
+      }
+    }
+    wave_sync_lds();
+    // ---- flag: own slot hit twice, or a neighbouring slot present; compact the flagged values ----
+    uint32_t n_flag = 0;
+    uint32_t *flg_g = flg + g * kWave;
+    uint32_t wf[R][2];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        wf[t][c] = 0;
+        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
+        const uint32_t v = val[t][c];
+        bool flag = false;
+        if (v < kDenseVLimit) {
+          const uint32_t b = (v >> 2) & kBitMask;
+          wf[t][c] = b >> 5;
+          const uint32_t w0 = bitmap[b >> 5], w1 = bitmap[(b >> 5) + 1u];
+          const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, b);  // bits 0..5: present/twice of slot-1, slot, slot+1
+          flag = (x & 0x19u) != 0u;
+        }
+        const uint64_t m = __ballot(flag);
+        const uint32_t pos = n_flag + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (flag && pos < (uint32_t)kWave) flg_g[pos] = v;
+        n_flag += (uint32_t)__popcll(m);
+      }
+    }
+    wave_sync_lds();
+    // ---- leave the bitmap clean (every lane clears the two words of its window: covers its own bits) ----
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
+        if (val[t][c] < kDenseVLimit) bitmap[wf[t][c]] = 0u, bitmap[wf[t][c] + 1u] = 0u;
+      }
+    }
+    if (__builtin_expect(__any(mirrored != 0), 0)) {
+      if (ln == 0) bitmap[0] = 0u, bitmap[(2u * kSlots + 2u) >> 5] = 0u;
+    }
+    wave_sync_lds();
+    if (n_flag > (uint32_t)kWave) return 0xFFFFFFFFu;
+    if (n_flag <= (uint32_t)p.a) continue;
+    // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
+    const bool have = ln < n_flag;
+    const uint32_t fv = have ? flg_g[ln] : 0u;
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < n_flag; ++j) {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+      cnt += (uint32_t)(x - fv <= e);
+    }
+    const bool pass = have && cnt > (uint32_t)p.a;
+    const uint64_t pm = __ballot(pass);
+    if (pm == 0) continue;
+    pass_mask[g] = pm;
+    n_flagged[g] = n_flag;
+    any_pass = true;
+    cmin = pass && fv < cmin ? fv : cmin;
+    cmax = pass && fv > cmax ? fv : cmax;
+  }
+  if (!any_pass) return 0;
+  const uint32_t lo_all = wave_min_u32(cmin), hi_all = wave_max_u32(cmax);
+  if (hi_all - lo_all <= e) {  // every survivor within e of the smallest: the greedy merges keep exactly that one
+    cv = ln == 0 ? lo_all : 0u;
+    return 1;
+  }
+  // ---- general case: per group, survivors sorted into lanes and merged greedily (src/filter.c:45-78) ----
+  uint32_t nA = 0;
+  cv = 0;
+#pragma unroll
+  for (int g = 0; g < kStep; ++g) {
+    const uint64_t pm = pass_mask[g];
+    if (pm == 0) continue;
+    const uint32_t nF = (uint32_t)__popcll(pm);
+    const bool mine = (pm >> ln) & 1ull;
+    const uint32_t fv = ln < n_flagged[g] ? flg[g * kWave + ln] : 0u;
+    uint32_t rank = 0;
+    for (uint64_t m = pm; m;) {  // rank among the survivors (ties by lane)
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, j);
+      rank += (uint32_t)(x < fv || (x == fv && (uint32_t)j < ln));
+    }
+    wave_sync_lds();
+    if (mine) scatter[rank] = fv;
+    wave_sync_lds();
+    const uint32_t fs = ln < nF ? scatter[ln] : 0u;
+    nA = dense_merge_group(cv, nA, fs, nF, e);
+    if (nA == 0xFFFFFFFFu) return nA;
+  }
+  return nA;
+}
+
+constexpr int dense_waves(int R) { return R <= 6 ? 5 : 4; }
+
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_waves(R), 8))) seed_dense_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
+  static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
+  const uint32_t ln = lane_id();
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
+  uint32_t *pkw = (uint32_t *)(wbase + p.lay.pkw);
+  uint32_t *nkw = (uint32_t *)(wbase + p.lay.nkw);
+  uint2 *sf = (uint2 *)(wbase + p.lay.sf);
+  unsigned long long *take_bits = (unsigned long long *)(wbase + p.lay.dp_bits);
+  uint32_t *scatter = (uint32_t *)(wbase + p.lay.X);
+  uint32_t *flg = (uint32_t *)(wbase + p.lay.A);
+  uint32_t *bitmap = (uint32_t *)(wbase + p.lay.F);
+  uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
+  uint32_t *cand_lds = (uint32_t *)(wbase + p.lay.sf);  // 2 x 64 candidates over the seed table (dead by then)
+  for (uint32_t i = ln; i < dense_bitmap_words(R); i += kWave) bitmap[i] = 0;
+  const uint32_t smax = p.lay.smax;
+  unsigned long long pre_sum = 0, cand_sum = 0;
+  SlotChunk chunk, qchunk;
+
+  auto queue_slow = [&](uint32_t read) {
+    if (qchunk.left == 0) {
+      uint32_t base = 0;
+      if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
+      qchunk.next = bcast0(base);
+      qchunk.left = kQueueChunk;
+    }
+    if (qchunk.next < p.slow_cap) {
+      if (ln == 0) p.slow_queue[qchunk.next] = read;
+    } else if (ln == 0) {
+      atomicOr(&p.ctr[1], kFlagQueueOverflow);
+    }
+    ++qchunk.next, --qchunk.left;
+  };
+
+  constexpr uint32_t kPullBlocks = 1;
+  for (;;) {
+    uint32_t pull = 0;
+    if (ln == 0) pull = atomicAdd(p.work_cursor, kPullBlocks * kReadBlock);
+    pull = bcast0(pull);
+    if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
+    const uint32_t r0 = p.read_begin + pull;
+    if (ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+    for (uint32_t rb = 0; rb < kReadBlock && r0 + rb < p.n_reads; ++rb) {
+      const uint32_t read = r0 + rb;
+      const uint64_t off = p.read_off[read];
+      const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
+      const int S = (int)L - kK + 1;  // num_seeds_in_read
+      // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
+      bool shape_ok = S > 0 && R <= S / kStep;
+      if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
+      if (!shape_ok) {
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);
+        continue;
+      }
+      const uint32_t widest = (uint32_t)(S / kStep - R * kLg + 1);  // columns of phase group 0
+      if (widest > (uint32_t)kWave || (uint32_t)S > smax || p.a == 0) {
+        queue_slow(read);
+        continue;
+      }
+      // ---- encode: four characters per lane -> 2-bit codes packed big-endian into LDS ----
+      bool strand_ok[2] = {true, true};
+      uint32_t any_n = 0;
+      for (uint32_t b0 = 0; b0 < L; b0 += 256u) {
+        const uint32_t idx = b0 + 4u * ln;
+        if (idx < L) {
+          uint32_t code, nflag;
+          encode4(load_u32_unaligned(p.bases + off + idx), code, nflag);  // may run up to 3 bytes past the read: masked below
+          const uint32_t nb = L - idx;
+          const uint32_t keep = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+          nflag &= keep;
+          code &= keep & ~(nflag * 3u);  // N -> A (src/utils.h:92)
+          const uint32_t byte_addr = (idx >> 4) * 4u + (3u - ((idx >> 2) & 3u));
+          ((uint8_t *)pkw)[byte_addr] = (uint8_t)pack4(code);
+          ((uint8_t *)nkw)[byte_addr] = (uint8_t)pack4(nflag * 3u);
+          any_n |= nflag;
+        }
+      }
+      const bool has_n = __any(any_n != 0);
+      if (has_n) {  // rare: the ambiguous-base gate (src/utils.h:108-114, src/filter.c:180-182)
+        uint32_t n_fwd_amb = 0, n_rev_amb = 0;
+        for (uint32_t b0 = 0; b0 < L; b0 += 256u) {
+          const uint32_t idx = b0 + 4u * ln;
+          if (idx < L) {
+            uint32_t code, nflag;
+            encode4(load_u32_unaligned(p.bases + off + idx), code, nflag);
+            const uint32_t nb = L - idx;
+            nflag &= nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+            for (uint32_t q = 0; q < 4u; ++q) {
+              const uint32_t isn = (nflag >> (8u * q)) & 1u;
+              n_fwd_amb += isn & (uint32_t)(idx + q >= (uint32_t)kK);
+              n_rev_amb += isn & (uint32_t)(L - 1u - (idx + q) >= (uint32_t)kK);
+            }
+          }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+          n_fwd_amb += __shfl_xor(n_fwd_amb, d);
+          n_rev_amb += __shfl_xor(n_rev_amb, d);
+        }
+        strand_ok[0] = n_fwd_amb <= (uint32_t)p.e;
+        strand_ok[1] = n_rev_amb <= (uint32_t)p.e;
+      }
+      wave_sync_lds();
+      // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
+      int last_used = 0;
+      for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
+      for (int j0 = 0; j0 < S; j0 += kWave) {
+        const int j = j0 + (int)ln;
+        if (j < S) {
+          const uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
+          const uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
+          const uint32_t hf = (uint32_t)(pw >> (64 - 2 * kK - sh)) & kHashMask;
+          uint32_t nm = 0;
+          if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
+          const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);
+          const uint32_t hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+          uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
+          if (strand_ok[0] && j <= last_used) __builtin_memcpy(&qf, p.lookup + hf, 8);
+          if (strand_ok[1] && S - 1 - j <= last_used) __builtin_memcpy(&qr, p.lookup + hr, 8);
+          if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
+          if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
+        }
+      }
+      wave_sync_lds();
+      // ---- seed selection (src/filter.c:3-43 + the stable sort of :204) ----
+      const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
+      uint32_t s_start, s_lo, s_freq;
+      const uint32_t pre_g = select_seeds_lanes<R>(p, S, strand_ok, sf, smax, dp_w, take_bits, s_start, s_lo, s_freq);
+      if (ln < 2u * kSeeds && !strand_ok[ln / kSeeds]) s_freq = 0;
+      unsigned long long pre_read = 0;
+      {
+        const uint32_t t = pre_g + dpp_or_zero<0x111, 0xF>(pre_g) + dpp_or_zero<0x112, 0xF>(pre_g);  // lanes 2 and 5: strand sums
+        if (strand_ok[0]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 2);
+        if (strand_ok[1]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 5);
+      }
+      wave_sync_lds();  // the seed table is dead: its space takes the candidates
+      // ---- lists -> candidates, one strand after the other ----
+      uint32_t kept0 = 0, kept1 = 0;
+      bool slow = false;
+#pragma unroll 1
+      for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
+        if (!(strand ? strand_ok[1] : strand_ok[0])) continue;
+        uint32_t cv = 0;
+        const uint32_t kept = dense_strand<R>(p, strand * kSeeds, s_start, s_lo, s_freq, bitmap, flg, scatter, cv);
+        if (kept == 0xFFFFFFFFu) {
+          slow = true;
+          break;
+        }
+        cand_lds[strand * (uint32_t)kWave + ln] = cv;
+        if (strand) kept1 = kept; else kept0 = kept;
+      }
+      if (slow) {
+        queue_slow(read);
+        continue;
+      }
+      pre_sum += pre_read;
+      // ---- back to (sequence, position), remove_out_ranged_candidates (src/filter.c:133-144), hand-over ----
+#pragma unroll 1
+      for (uint32_t strand = 0; strand < 2u; ++strand) {
+        const uint32_t kept = strand ? kept1 : kept0;
+        uint64_t out = 0;
+        bool ok = false;
+        if (ln < kept) {
+          const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];  // written by this same lane
+          uint32_t sq = p.blkseq[v >> kDenseBlkShift];
+          while (sq + 1u < p.n_seq && p.goff[sq + 1u] <= v) ++sq;
+          const uint32_t pos = v - p.goff[sq];
+          const uint32_t slen = p.seq_len[sq];
+          ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+          out = (((uint64_t)sq << 32) | pos) - (uint64_t)p.e;
+        }
+        const uint64_t mo = __ballot(ok);
+        const uint32_t n_out = (uint32_t)__popcll(mo);
+        uint32_t base = 0;
+        if (n_out > 0) {
+          if (n_out <= chunk.left) {
+            base = chunk.next;
+            chunk.next += n_out, chunk.left -= n_out;
+          } else {
+            pad_chunk(p, chunk);
+            if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+            base = bcast0(base);
+            chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+          }
+          if ((unsigned long long)base + n_out > p.cand_cap) {
+            if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+          } else if (ok) {
+            const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
+            p.cand[at] = out;
+            p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
+          }
+        }
+        if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
+        cand_sum += n_out;
+      }
+    }
+    wave_sync_lds();
+    const uint2 entry = blk_entries[ln];
+    wave_sync_lds();
+    if (ln < 2u * kReadBlock && r0 + ln / 2u < p.n_reads && entry.x != kBlkSkip) {
+      __builtin_nontemporal_store(entry.x, &p.cand_begin[r0 * 2u + ln]);
+      __builtin_nontemporal_store(entry.y, &p.cand_count[r0 * 2u + ln]);
+    }
+  }
+  pad_chunk(p, chunk);
+  for (uint32_t i = ln; i < qchunk.left; i += kWave)
+    if (qchunk.next + i < p.slow_cap) p.slow_queue[qchunk.next + i] = kInvalidRead;
+  if (ln == 0) {
+    if (pre_sum) atomicAdd(&p.stats[0], pre_sum);
+    if (cand_sum) atomicAdd(&p.stats[1], cand_sum);
+  }
+}
+
+}  // namespace femk

@@ -10,7 +10,7 @@ _HIP = None
 #: every symbol include/fem_hip.h declares
 ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
-    "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index",
+    "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records",
@@ -69,6 +69,7 @@ def load_hip():
     L.fem_dev_upload_index.argtypes = [vp, i32, i32, vp, u64, vp, u64]
     L.fem_dev_upload_reference.argtypes = [vp, C.c_uint32, C.POINTER(vp), vp]
     L.fem_dev_build_index.argtypes = [vp, i32, i32, vp, vp, u64, C.POINTER(u64)]
+    L.fem_dev_fetch_index.argtypes = [vp, vp, vp, u64]
     L.fem_dev_map_batch_submit.argtypes = [vp, C.c_int, C.POINTER(Params), C.POINTER(_ReadBatch)]
     L.fem_dev_map_batch_wait.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
     L.fem_dev_stage_reads.argtypes = [vp, C.c_int, C.POINTER(_ReadBatch)]
@@ -195,8 +196,7 @@ class Device:
             return int(n.value), None, None
         lookup = np.zeros((1 << (2 * k)) + 1, dtype=np.uint32)
         occ = np.zeros(max(int(n.value), 1), dtype=np.uint64)
-        self._check(self._L.fem_dev_build_index(self._h, k, step, lookup.ctypes.data, occ.ctypes.data, len(occ),
-                                                C.byref(n)))
+        self._check(self._L.fem_dev_fetch_index(self._h, lookup.ctypes.data, occ.ctypes.data, len(occ)))
         return int(n.value), lookup, occ[:n.value]
 
     @staticmethod

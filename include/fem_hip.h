@@ -123,6 +123,10 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
  * always set.  The result is byte-identical to the reference's index arrays. */
 int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_out, uint64_t *occ_out,
                         uint64_t occ_cap, uint64_t *n_occ_out);
+/* Copies the resident index arrays (uploaded or built) to the host: what save_index
+ * writes (src/index.c:133-168).  lookup_out holds 4^k+1 entries, occ_out occ_cap >= n_occ;
+ * either may be NULL.  `FEM index` builds once, sizes its buffers from *n_occ_out, then fetches. */
+int fem_dev_fetch_index(fem_dev *h, uint32_t *lookup_out, uint64_t *occ_out, uint64_t occ_cap);
 
 /* ---- mapping one batch (replaces the loop body src/map.c:27-49) ---- */
 /* submit = stage + map + start of the copy back; wait = finish + result.

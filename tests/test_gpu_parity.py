@@ -8,21 +8,25 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fast+generic", "hash+generic", "generic-only", "tiny-buffers", "tiny-buffers+hash"])
+@pytest.fixture(scope="module", params=["fast+generic", "hash+generic", "dense+generic", "generic-only", "tiny-buffers",
+                                        "tiny-buffers+hash", "tiny-buffers+dense"])
 def dev(request):
     # The library picks the seed kernel by itself: seed_fast_kernel<R, false> (lists in lanes) for sparse
-    # indexes, <R, true> (hash join) for dense ones, and the generic kernel for whatever those queue.  The two
-    # environment hooks (read by fem_dev_open) force the other forms so that every fixture runs through all three.
+    # indexes, <R, true> (64-bit hash join) for denser ones, seed_dense_kernel<R> (32-bit coordinates, bitmap join) for
+    # long lists, and the generic kernel for whatever those queue.  The environment hooks (read by fem_dev_open)
+    # force the other forms so that every fixture runs through all four.
     import os
     from fem_amd import Device
     os.environ["FEM_FORCE_GENERIC"] = "1" if request.param == "generic-only" else "0"
     os.environ["FEM_FORCE_HASH"] = "1" if "hash" in request.param else "0"
+    os.environ["FEM_FORCE_DENSE"] = "1" if "dense" in request.param else "0"
     # "tiny-buffers": candidate arrays, slow-read queue and arena start far too small, so every fixture goes through
     # the overflow flags, the growth of the buffers and the re-run of the batch in fem_dev_sync
     os.environ["FEM_TEST_TINY_BUFFERS"] = "1" if "tiny" in request.param else "0"
     d = Device(0)
     os.environ.pop("FEM_FORCE_GENERIC")
     os.environ.pop("FEM_FORCE_HASH")
+    os.environ.pop("FEM_FORCE_DENSE")
     os.environ.pop("FEM_TEST_TINY_BUFFERS")
     yield d
     d.close()
