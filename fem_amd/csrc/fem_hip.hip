@@ -275,7 +275,7 @@ femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
   l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 4u));
   l.dp_bits = take(n_groups * R * 8u);
   l.X = take(64u * 4u);
-  l.A = take(3u * 64u * 4u);
+  l.A = take(3u * 65u * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
   l.F = take(femk::dense_bitmap_words((int)R) * 4u);
   l.wave_bytes = o;
@@ -642,7 +642,7 @@ int refresh_dense(fem_dev *h) {
   uint32_t *d_bad = nullptr;
   HIP_TRY(h, hipMalloc((void **)&h->d_goff, goff.size() * sizeof(uint32_t)));
   HIP_TRY(h, hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)));
-  HIP_TRY(h, hipMalloc((void **)&h->d_occ32, (h->n_occ + 64) * sizeof(uint32_t)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)));
   HIP_TRY(h, hipMalloc((void **)&d_bad, sizeof(uint32_t)));
   HIP_TRY(h, hipMemset(d_bad, 0, sizeof(uint32_t)));
   HIP_TRY(h, hipMemcpy(h->d_goff, goff.data(), goff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -18,7 +18,8 @@
 //   * BITMAP JOIN IN LDS.  merge_candidate_locations + additional_qgram_filter (src/filter.c:80-131) keep a value
 //     iff a+1 values of the multiset lie in [v, v+e].  Two bits per 8-position slot (present / hit twice), set
 //     with one returning LDS atomic per entry: a value can only take part in a within-e pair if its slot was hit
-//     twice or a neighbouring slot is present.  One two-word LDS read covers the three slots.  The few flagged
+//     twice or a neighbouring slot is present.  One two-word LDS read covers the three slots (the table wraps:
+//     values in its first and last slot are always flagged).  The few flagged
 //     values (true hits + ~3 n^2 / slots chance ones) are compacted and the filter is evaluated exactly on them.
 //   * ONE CANDIDATE PER STRAND IS THE COMMON CASE.  If every survivor of the strand's three phase groups lies
 //     within e of the smallest, the staged greedy merge (src/filter.c:45-78, :209-213) leaves exactly that
@@ -100,204 +101,265 @@ __device__ __forceinline__ uint32_t dense_merge_group(uint32_t &cv, uint32_t nA,
   return nB;
 }
 
+// LDS atomics of the join: relaxed, wavefront scope (only this wave touches its bitmap)
+__device__ __forceinline__ uint32_t lds_or_rtn(uint32_t *w, uint32_t bits) {
+  return __hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// One strand.  Lane lane0 + g * R + t holds run t of phase group g: (start, lookup[h], frequency), runs in the
-// order of the stable frequency sort (src/filter.c:204).  Leaves the strand's candidates (global coordinates,
-// ascending, before the range clip) in lanes 0..n-1 of `cv` and returns n; 0xFFFFFFFF = hand the read to the
-// generic kernel.  `bitmap` is all-zero on entry and on exit.
+// Both strands of one read.  Lane strand * 3R + g * R + t holds run t of phase group g of that strand: (start,
+// lookup[h], frequency), runs in the order of the stable frequency sort (src/filter.c:204); strands that failed the
+// gates have frequency 0 everywhere.  The six (strand, group) units run one after the other in ONE rolled loop (the
+// code stays small, the scalar registers few), and the first chunk of every run of unit u + 1 is requested before
+// unit u is worked on: the occurrence loads of a read are one exposed round trip instead of six.  A unit is R
+// chunks (entries 0..63 of each run) plus, when some list is longer, ONE extra chunk that packs the overflow
+// (entries 64.. of all long runs).  Within a unit all LDS atomics are issued back to back, then all window reads.
+// Leaves each strand's candidates (global coordinates, ascending, before the range clip) in
+// cand_lds[strand * 64 + lane] and their counts in kept0/kept1; false = hand the read to the generic kernel.
+// `bitmap` is all-zero (but for its padding bits) on entry and on exit.
 // ---------------------------------------------------------------------------------------------------------
 template <int R>
-__device__ uint32_t dense_strand(const SeedParams &p, uint32_t lane0, uint32_t s_start, uint32_t s_lo, uint32_t s_freq,
-                                 uint32_t *bitmap, uint32_t *flg /* LDS [3][64] */, uint32_t *scatter /* LDS [64] */,
-                                 uint32_t &cv) {
+__device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
+                           uint32_t *flg /* LDS [3][65] */, uint32_t *scatter /* LDS [64] */, uint32_t *cand_lds,
+                           uint32_t &kept0, uint32_t &kept1) {
   const uint32_t ln = lane_id();
   constexpr uint32_t kSlots = dense_slots(R);
-  constexpr uint32_t kBitMask = 2u * kSlots - 2u;  // 2 * slot, as a bit index
+  constexpr uint32_t kSlotBits = kSlots == 32768u ? 15u : 14u;
+  constexpr uint32_t kFlgStride = (uint32_t)kWave + 1u;  // entry 64 of a group's array takes the overflow writes
+  constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;
   const uint32_t *occ32 = p.occ32;
-  uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value it has seen
-  uint64_t pass_mask[kStep] = {0, 0, 0};
-  uint32_t n_flagged[kStep] = {0, 0, 0};
-  bool any_pass = false;
-#pragma unroll
-  for (int g = 0; g < kStep; ++g) {
-    // ---- the group's runs as wave-uniform scalars ----
-    uint32_t f[R], lo[R], st[R];
-    uint32_t n_g = 0, f_max = 0;
+  kept0 = 0, kept1 = 0;
+  if (__builtin_amdgcn_ballot_w64(s_freq > kDenseMaxList)) return false;  // a list beyond two chunks: generic kernel
+  const uint32_t s_sf = s_start | (s_freq << 16);  // start < 1024, frequency <= 128: one readlane fetches both
+  uint32_t nxt[R];  // first chunk of every run of the next unit (raw table entries)
+  auto prefetch = [&](uint32_t u) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      const int j = (int)lane0 + g * R + t;
-      f[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_freq, j);
-      lo[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, j);
-      st[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_start, j);
-      f_max = f[t] > f_max ? f[t] : f_max;
-      n_g += f[t] < 0x10000u ? f[t] : 0x10000u;
+      const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t)) >> 16;
+      const uint32_t *bp = occ32 + (uint32_t)__builtin_amdgcn_readlane((int)s_lo, (int)(u * R + t));
+      nxt[t] = kDenseSent;
+      if (ln < fq) nxt[t] = bp[ln];
     }
-    if (n_g <= (uint32_t)p.a) continue;  // fewer than a+1 occurrences: nothing can pass the filter
-    if (n_g == f[R - 1]) continue;       // the last seed is merged only while the list has elements (src/filter.c:85)
-    if (f_max > kDenseMaxList) return 0xFFFFFFFFu;
-    // ---- load: chunk c of run t = entries 64 c + lane ----
-    uint32_t val[R][2];
-    uint32_t remap = 0;
+  };
+  // own pair of a value: LDS word and bit of its "present" flag ("twice" is the next bit)
+  auto pair_word = [&](uint32_t v) -> uint32_t * { return bitmap + ((__builtin_amdgcn_ubfe(v, 3u, kSlotBits) + 1u) >> 4); };
+  auto pair_bit = [&](uint32_t v) -> uint32_t { return 1u << (((__builtin_amdgcn_ubfe(v, 3u, kSlotBits) + 1u) << 1) & 31u); };
+  // window of a value: the word its left neighbour's pair sits in (the window's six bits span this word and the next)
+  auto window_word = [&](uint32_t v) -> uint32_t * { return bitmap + __builtin_amdgcn_ubfe(v, 7u, kSlotBits - 4u); };
+  prefetch(0);
+  uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
+  uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
+  uint32_t nf0 = 0, nf1 = 0, nf2 = 0;
+#pragma unroll 1
+  for (uint32_t u = 0; u < kUnits; ++u) {
+    const uint32_t g = u >= (uint32_t)kStep ? u - (uint32_t)kStep : u;
+    // ---- the unit's runs as wave-uniform scalars ----
+    uint32_t f[R], st[R];
+    uint32_t n_g = 0, n_ovf = 0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      val[t][0] = kDenseSent, val[t][1] = kDenseSent;
-      if (ln < f[t]) val[t][0] = occ32[lo[t] + ln];
-      if (f[t] > (uint32_t)kWave && ln + (uint32_t)kWave < f[t]) val[t][1] = occ32[lo[t] + (uint32_t)kWave + ln];
+      const uint32_t sf = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t));
+      f[t] = sf >> 16, st[t] = sf & 0xFFFFu;
+      n_g += f[t];
+      n_ovf += f[t] > (uint32_t)kWave ? f[t] - (uint32_t)kWave : 0u;
     }
+    uint32_t val[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-      remap |= (uint32_t)(val[t][0] >= kDenseRemap);
-      if (f[t] > (uint32_t)kWave) remap |= (uint32_t)(val[t][1] >= kDenseRemap);
-      val[t][0] -= st[t], val[t][1] -= st[t];  // (the sentinel stays above kDenseVLimit: start < 1024)
-    }
-    uint32_t max_u = 0;
-    bool any_u;
-    if (__builtin_expect(__any(remap != 0), 0)) {
-      // rare: entries within kDenseNear of a sequence start.  Resolve them exactly (pos >= start or dropped),
-      // then the maximum of U by a wave reduction (a dropped entry may sit at the end of a run).
-      uint32_t mx = 0, have_u = 0;
+    for (int t = 0; t < R; ++t) val[t] = nxt[t];
+    if (u + 1u < kUnits) prefetch(u + 1u);
+    if (n_ovf > (uint32_t)kWave) return false;  // (the bitmap is clean between units)
+    // fewer than a+1 occurrences: nothing can pass the filter; no list but the last seed's: it is merged only while
+    // the list has elements (src/filter.c:85)
+    const bool skip = n_g <= (uint32_t)p.a || n_g == f[R - 1];
+    uint32_t n_flag = 0;
+    uint32_t *flg_g = flg + g * kFlgStride;
+    if (!skip) {
+      // ---- the extra chunk: entries 64.. of the long runs, packed; its lanes carry their own start ----
+      uint32_t xval = kDenseSent, xst = 0;
+      bool x_last = false;
+      if (n_ovf) {
+        uint32_t pre = 0, idx = 0;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          const uint32_t o = f[t] > (uint32_t)kWave ? f[t] - (uint32_t)kWave : 0u;
+          if (o && ln >= pre) {
+            idx = (uint32_t)__builtin_amdgcn_readlane((int)s_lo, (int)(u * R + t)) + (uint32_t)kWave + (ln - pre);
+            xst = st[t], x_last = t == R - 1;
+          }
+          pre += o;
+        }
+        if (ln < n_ovf) xval = occ32[idx];
+      }
+      uint64_t remap = 0;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint32_t raw = val[t][c] + st[t];
+        remap |= __builtin_amdgcn_ballot_w64(val[t] >= kDenseRemap);
+        val[t] -= st[t];  // (the sentinel stays above kDenseVLimit: start < 1024)
+      }
+      if (n_ovf) {
+        remap |= __builtin_amdgcn_ballot_w64(xval >= kDenseRemap);
+        xval -= xst;
+      }
+      uint32_t max_u = 0;
+      bool any_u = true;
+      if (__builtin_expect(remap != 0 || n_ovf != 0, 0)) {
+        // entries within kDenseNear of a sequence start are resolved exactly (pos >= start or dropped); then, as with
+        // long lists, the maximum of U comes from a wave reduction (a dropped entry may sit at the end of a run)
+        uint32_t mx = 0, have_u = 0;
+        auto resolve = [&](uint32_t &v, uint32_t start) {
+          const uint32_t raw = v + start;
           if (raw >= kDenseRemap) {
             const uint32_t sq = (raw - kDenseRemap) >> 10, pos = raw & (kDenseNear - 1u);
-            val[t][c] = pos >= st[t] ? p.goff[sq] + pos - st[t] : kDenseSent;
+            v = pos >= start ? p.goff[sq] + pos - start : kDenseSent;
           }
-          if (t < R - 1 && val[t][c] < kDenseVLimit) mx = val[t][c] > mx ? val[t][c] : mx, have_u = 1;
+        };
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          if (remap) resolve(val[t], st[t]);
+          if (t < R - 1 && val[t] < kDenseVLimit) mx = val[t] > mx ? val[t] : mx, have_u = 1;
+        }
+        if (n_ovf) {
+          if (remap) resolve(xval, xst);
+          if (!x_last && xval < kDenseVLimit) mx = xval > mx ? xval : mx, have_u = 1;
+        }
+        any_u = __builtin_amdgcn_ballot_w64(have_u != 0) != 0;
+        max_u = wave_max_u32(mx);
+      } else {
+        // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
+#pragma unroll
+        for (int t = 0; t < R - 1; ++t) {
+          const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
+          max_u = f[t] && lastv > max_u ? lastv : max_u;
         }
       }
-      any_u = __any(have_u != 0);
-      max_u = wave_max_u32(mx);
-    } else {
-      // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
-      any_u = true;
+      if (any_u) {
+        // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
+        val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
+        if (n_ovf) xval = x_last && xval > max_u ? kDenseSent : xval;
+        // ---- insert.  Slot s (8 positions) sits at bit pair s + 1: pair 0 and pair kSlots + 1 are padding whose
+        //      "present" bits are permanently set, so values in the first / last slot are always flagged (the table
+        //      wraps there; the exact filter below decides) ----
+        uint32_t old[R], xold = 0;
 #pragma unroll
-      for (int t = 0; t < R - 1; ++t) {
-        if (f[t] == 0) continue;
-        const uint32_t lastv = f[t] > (uint32_t)kWave ? (uint32_t)__builtin_amdgcn_readlane((int)val[t][1], (int)((f[t] - 1u) & 63u))
-                                                      : (uint32_t)__builtin_amdgcn_readlane((int)val[t][0], (int)(f[t] - 1u));
-        max_u = lastv > max_u ? lastv : max_u;
-      }
-    }
-    if (!any_u) continue;
-    // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
+        for (int t = 0; t < R; ++t) {
+          old[t] = 0;
+          if (val[t] < kDenseVLimit) old[t] = lds_or_rtn(pair_word(val[t]), pair_bit(val[t]));
+        }
+        if (n_ovf && xval < kDenseVLimit) xold = lds_or_rtn(pair_word(xval), pair_bit(xval));
+        uint64_t coll = 0;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) val[R - 1][c] = val[R - 1][c] <= max_u ? val[R - 1][c] : kDenseSent;
-    // ---- insert ----
-    uint32_t mirrored = 0;
+        for (int t = 0; t < R; ++t) coll |= __builtin_amdgcn_ballot_w64((old[t] & pair_bit(val[t])) != 0u);
+        if (n_ovf) coll |= __builtin_amdgcn_ballot_w64((xold & pair_bit(xval)) != 0u);
+        if (coll) {  // some slot took a second value (every true hit does): mark "twice"
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
+          for (int t = 0; t < R; ++t)
+            if (old[t] & pair_bit(val[t])) (void)lds_or_rtn(pair_word(val[t]), pair_bit(val[t]) << 1);
+          if (n_ovf && (xold & pair_bit(xval))) (void)lds_or_rtn(pair_word(xval), pair_bit(xval) << 1);
+        }
+        wave_sync_lds();
+        // ---- flag: own slot hit twice, or a neighbouring slot present; compact the flagged values ----
+        uint32_t w0[R], w1[R], xw0 = 0, xw1 = 0;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
-        const uint32_t v = val[t][c];
-        if (v < kDenseVLimit) {
-          const uint32_t b = (v >> 2) & kBitMask;  // 2 * slot: bit index of present(slot - 1) in the offset layout
-          const uint32_t bi = b + 2u;              // present(slot), twice(slot) = bi + 1
-          const uint32_t bit = 1u << (bi & 31u);
-          const uint32_t old = atomicOr(&bitmap[bi >> 5], bit);
-          if (old & bit) atomicOr(&bitmap[bi >> 5], bit << 1);
-          if (b == 0u || b == kBitMask) {  // the table wraps: mirror the edge slots into the padding slots
-            if (b == 0u) atomicOr(&bitmap[(2u * kSlots + 2u) >> 5], 1u << ((2u * kSlots + 2u) & 31u));
-            else atomicOr(&bitmap[0], 1u);
-            mirrored = 1;
+        for (int t = 0; t < R; ++t) {
+          const uint32_t *w = window_word(val[t]);  // (sentinel lanes read some word too: masked below)
+          w0[t] = w[0], w1[t] = w[1];
+        }
+        if (n_ovf) {
+          const uint32_t *w = window_word(xval);
+          xw0 = w[0], xw1 = w[1];
+        }
+        auto flag_chunk = [&](uint32_t v, uint32_t a0, uint32_t a1) {
+          const uint32_t x = __builtin_amdgcn_alignbit(a1, a0, (v >> 2) & 30u);  // bits 0..4: present/twice of slot-1, slot, slot+1
+          const bool fl = (x & 0x19u) != 0u && v < kDenseVLimit;
+          const uint64_t m = __builtin_amdgcn_ballot_w64(fl);
+          uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_flag));
+          pos = pos < (uint32_t)kWave ? pos : (uint32_t)kWave;
+          if (fl) flg_g[pos] = v;
+          n_flag += (uint32_t)__popcll(m);
+        };
+#pragma unroll
+        for (int t = 0; t < R; ++t) flag_chunk(val[t], w0[t], w1[t]);
+        if (n_ovf) flag_chunk(xval, xw0, xw1);
+        wave_sync_lds();
+        // ---- leave the bitmap clean: every lane clears the two words of its window (its own bits are in one of
+        //      them), then the padding pairs get their permanent bits back ----
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          if (val[t] < kDenseVLimit) {
+            uint32_t *w = window_word(val[t]);
+            w[0] = 0u, w[1] = 0u;
           }
         }
-      }
-    }
-    wave_sync_lds();
-    // ---- flag: own slot hit twice, or a neighbouring slot present; compact the flagged values ----
-    uint32_t n_flag = 0;
-    uint32_t *flg_g = flg + g * kWave;
-    uint32_t wf[R][2];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        wf[t][c] = 0;
-        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
-        const uint32_t v = val[t][c];
-        bool flag = false;
-        if (v < kDenseVLimit) {
-          const uint32_t b = (v >> 2) & kBitMask;
-          wf[t][c] = b >> 5;
-          const uint32_t w0 = bitmap[b >> 5], w1 = bitmap[(b >> 5) + 1u];
-          const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, b);  // bits 0..5: present/twice of slot-1, slot, slot+1
-          flag = (x & 0x19u) != 0u;
+        if (n_ovf && xval < kDenseVLimit) {
+          uint32_t *w = window_word(xval);
+          w[0] = 0u, w[1] = 0u;
         }
-        const uint64_t m = __ballot(flag);
-        const uint32_t pos = n_flag + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (flag && pos < (uint32_t)kWave) flg_g[pos] = v;
-        n_flag += (uint32_t)__popcll(m);
+        wave_sync_lds();
+        if (ln == 0) bitmap[0] = 1u, bitmap[(kSlots + 1u) >> 4] = 1u << (((kSlots + 1u) << 1) & 31u);
+        wave_sync_lds();
+        if (n_flag > (uint32_t)kWave) return false;
       }
     }
-    wave_sync_lds();
-    // ---- leave the bitmap clean (every lane clears the two words of its window: covers its own bits) ----
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c == 1 && f[t] <= (uint32_t)kWave) continue;
-        if (val[t][c] < kDenseVLimit) bitmap[wf[t][c]] = 0u, bitmap[wf[t][c] + 1u] = 0u;
+    if (n_flag > (uint32_t)p.a) {
+      // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
+      const bool have = ln < n_flag;
+      const uint32_t fv = have ? flg_g[ln] : 0u;
+      uint32_t cnt = 0;
+      for (uint32_t j = 0; j < n_flag; ++j) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+        cnt += (uint32_t)(x - fv <= e);
+      }
+      const bool pass = have && cnt > (uint32_t)p.a;
+      const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+      if (pm != 0) {
+        if (g == 0) pm0 = pm, nf0 = n_flag;
+        else if (g == 1) pm1 = pm, nf1 = n_flag;
+        else pm2 = pm, nf2 = n_flag;
+        cmin = pass && fv < cmin ? fv : cmin;
+        cmax = pass && fv > cmax ? fv : cmax;
       }
     }
-    if (__builtin_expect(__any(mirrored != 0), 0)) {
-      if (ln == 0) bitmap[0] = 0u, bitmap[(2u * kSlots + 2u) >> 5] = 0u;
+    if (g != (uint32_t)kStep - 1u) continue;
+    // ---- the strand's three groups are done: its candidates ----
+    uint32_t kept = 0, cv = 0;
+    if ((pm0 | pm1 | pm2) != 0) {
+      const uint32_t lo_all = wave_min_u32(cmin), hi_all = wave_max_u32(cmax);
+      if (hi_all - lo_all <= e) {  // every survivor within e of the smallest: the greedy merges keep exactly that one
+        cv = ln == 0 ? lo_all : 0u;
+        kept = 1;
+      } else {
+        // general case: per group, survivors sorted into lanes and merged greedily (src/filter.c:45-78)
+#pragma unroll 1
+        for (uint32_t gg = 0; gg < (uint32_t)kStep; ++gg) {
+          const uint64_t pm = gg == 0 ? pm0 : gg == 1 ? pm1 : pm2;
+          const uint32_t nfl = gg == 0 ? nf0 : gg == 1 ? nf1 : nf2;
+          if (pm == 0) continue;
+          const uint32_t nF = (uint32_t)__popcll(pm);
+          const bool mine = (pm >> ln) & 1ull;
+          const uint32_t fv = ln < nfl ? flg[gg * kFlgStride + ln] : 0u;
+          uint32_t rank = 0;
+          for (uint64_t m = pm; m;) {  // rank among the survivors (ties by lane)
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, j);
+            rank += (uint32_t)(x < fv || (x == fv && (uint32_t)j < ln));
+          }
+          wave_sync_lds();
+          if (mine) scatter[rank] = fv;
+          wave_sync_lds();
+          const uint32_t fs = ln < nF ? scatter[ln] : 0u;
+          kept = dense_merge_group(cv, kept, fs, nF, e);
+          if (kept == 0xFFFFFFFFu) return false;
+        }
+      }
     }
-    wave_sync_lds();
-    if (n_flag > (uint32_t)kWave) return 0xFFFFFFFFu;
-    if (n_flag <= (uint32_t)p.a) continue;
-    // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
-    const bool have = ln < n_flag;
-    const uint32_t fv = have ? flg_g[ln] : 0u;
-    uint32_t cnt = 0;
-    for (uint32_t j = 0; j < n_flag; ++j) {
-      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
-      cnt += (uint32_t)(x - fv <= e);
-    }
-    const bool pass = have && cnt > (uint32_t)p.a;
-    const uint64_t pm = __ballot(pass);
-    if (pm == 0) continue;
-    pass_mask[g] = pm;
-    n_flagged[g] = n_flag;
-    any_pass = true;
-    cmin = pass && fv < cmin ? fv : cmin;
-    cmax = pass && fv > cmax ? fv : cmax;
+    cand_lds[(u >= (uint32_t)kStep ? (uint32_t)kWave : 0u) + ln] = cv;
+    if (u >= (uint32_t)kStep) kept1 = kept; else kept0 = kept;
+    cmin = 0xFFFFFFFFu, cmax = 0u;
+    pm0 = pm1 = pm2 = 0, nf0 = nf1 = nf2 = 0;
   }
-  if (!any_pass) return 0;
-  const uint32_t lo_all = wave_min_u32(cmin), hi_all = wave_max_u32(cmax);
-  if (hi_all - lo_all <= e) {  // every survivor within e of the smallest: the greedy merges keep exactly that one
-    cv = ln == 0 ? lo_all : 0u;
-    return 1;
-  }
-  // ---- general case: per group, survivors sorted into lanes and merged greedily (src/filter.c:45-78) ----
-  uint32_t nA = 0;
-  cv = 0;
-#pragma unroll
-  for (int g = 0; g < kStep; ++g) {
-    const uint64_t pm = pass_mask[g];
-    if (pm == 0) continue;
-    const uint32_t nF = (uint32_t)__popcll(pm);
-    const bool mine = (pm >> ln) & 1ull;
-    const uint32_t fv = ln < n_flagged[g] ? flg[g * kWave + ln] : 0u;
-    uint32_t rank = 0;
-    for (uint64_t m = pm; m;) {  // rank among the survivors (ties by lane)
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, j);
-      rank += (uint32_t)(x < fv || (x == fv && (uint32_t)j < ln));
-    }
-    wave_sync_lds();
-    if (mine) scatter[rank] = fv;
-    wave_sync_lds();
-    const uint32_t fs = ln < nF ? scatter[ln] : 0u;
-    nA = dense_merge_group(cv, nA, fs, nF, e);
-    if (nA == 0xFFFFFFFFu) return nA;
-  }
-  return nA;
+  return true;
 }
 
 constexpr int dense_waves(int R) { return R <= 6 ? 5 : 4; }
@@ -320,6 +382,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
   uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
   uint32_t *cand_lds = (uint32_t *)(wbase + p.lay.sf);  // 2 x 64 candidates over the seed table (dead by then)
   for (uint32_t i = ln; i < dense_bitmap_words(R); i += kWave) bitmap[i] = 0;
+  wave_sync_lds();
+  if (ln == 0) bitmap[0] = 1u, bitmap[(dense_slots(R) + 1u) >> 4] = 1u << (((dense_slots(R) + 1u) << 1) & 31u);  // padding pairs: see dense_join
   const uint32_t smax = p.lay.smax;
   unsigned long long pre_sum = 0, cand_sum = 0;
   SlotChunk chunk, qchunk;
@@ -407,27 +471,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
         strand_ok[1] = n_rev_amb <= (uint32_t)p.e;
       }
       wave_sync_lds();
+#if defined(FEM_ABLATE) && FEM_ABLATE == 0
+      continue;
+#endif
       // ---- hashes + CSR lookups: lane j owns seed j of the + strand and seed S-1-j of the - strand ----
       int last_used = 0;
       for (int si = 0; si < kStep; ++si) last_used = max(last_used, kStep * ((S - si) / kStep - kLg) + si);
-      for (int j0 = 0; j0 < S; j0 += kWave) {
-        const int j = j0 + (int)ln;
-        if (j < S) {
-          const uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
-          const uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
-          const uint32_t hf = (uint32_t)(pw >> (64 - 2 * kK - sh)) & kHashMask;
-          uint32_t nm = 0;
-          if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
-          const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);
-          const uint32_t hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-          uint2 qf = make_uint2(0u, 0u), qr = make_uint2(0u, 0u);
-          if (strand_ok[0] && j <= last_used) __builtin_memcpy(&qf, p.lookup + hf, 8);
-          if (strand_ok[1] && S - 1 - j <= last_used) __builtin_memcpy(&qr, p.lookup + hr, 8);
-          if (strand_ok[0]) sf[j] = make_uint2(qf.x, qf.y - qf.x);
-          if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr.x, qr.y - qr.x);
+      // (two rounds of 64 seeds go through the table together: one exposed round trip for reads up to 139 bases)
+      for (int j0 = 0; j0 < S; j0 += 2 * kWave) {
+        uint2 qf[2], qr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = j0 + h * kWave + (int)ln;
+          qf[h] = make_uint2(0u, 0u), qr[h] = make_uint2(0u, 0u);
+          if (j < S) {
+            const uint32_t w = (uint32_t)j >> 4, sh = 2u * ((uint32_t)j & 15u);
+            const uint64_t pw = ((uint64_t)pkw[w] << 32) | pkw[w + 1];
+            const uint32_t hf = (uint32_t)(pw >> (64 - 2 * kK - sh)) & kHashMask;
+            uint32_t nm = 0;
+            if (has_n) nm = (uint32_t)((((uint64_t)nkw[w] << 32) | nkw[w + 1]) >> (64 - 2 * kK - sh)) & kHashMask;
+            const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);
+            const uint32_t hr = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            if (strand_ok[0] && j <= last_used) __builtin_memcpy(&qf[h], p.lookup + hf, 8);
+            if (strand_ok[1] && S - 1 - j <= last_used) __builtin_memcpy(&qr[h], p.lookup + hr, 8);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = j0 + h * kWave + (int)ln;
+          if (j < S) {
+            if (strand_ok[0]) sf[j] = make_uint2(qf[h].x, qf[h].y - qf[h].x);
+            if (strand_ok[1]) sf[smax + (uint32_t)(S - 1 - j)] = make_uint2(qr[h].x, qr[h].y - qr[h].x);
+          }
         }
       }
       wave_sync_lds();
+#if defined(FEM_ABLATE) && FEM_ABLATE == 1
+      continue;
+#endif
       // ---- seed selection (src/filter.c:3-43 + the stable sort of :204) ----
       const uint32_t dp_w = widest <= 16u ? 16u : widest <= 32u ? 32u : 64u;
       uint32_t s_start, s_lo, s_freq;
@@ -439,23 +520,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
         if (strand_ok[0]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 2);
         if (strand_ok[1]) pre_read += (uint32_t)__builtin_amdgcn_readlane((int)t, 5);
       }
+#if defined(FEM_ABLATE) && FEM_ABLATE == 2
+      if (s_freq != 0xFFFFFFFFu) continue;
+#endif
       wave_sync_lds();  // the seed table is dead: its space takes the candidates
       // ---- lists -> candidates, one strand after the other ----
       uint32_t kept0 = 0, kept1 = 0;
-      bool slow = false;
-#pragma unroll 1
-      for (uint32_t strand = 0; strand < 2u && !slow; ++strand) {
-        if (!(strand ? strand_ok[1] : strand_ok[0])) continue;
-        uint32_t cv = 0;
-        const uint32_t kept = dense_strand<R>(p, strand * kSeeds, s_start, s_lo, s_freq, bitmap, flg, scatter, cv);
-        if (kept == 0xFFFFFFFFu) {
-          slow = true;
-          break;
-        }
-        cand_lds[strand * (uint32_t)kWave + ln] = cv;
-        if (strand) kept1 = kept; else kept0 = kept;
-      }
-      if (slow) {
+      if (!dense_join<R>(p, s_start, s_lo, s_freq, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
         queue_slow(read);
         continue;
       }

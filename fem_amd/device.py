@@ -45,7 +45,8 @@ class _BatchRecords(C.Structure):
 
 
 def hip_library_path():
-    return os.path.join(_HERE, "csrc", "libfemhip.so")
+    # FEM_HIP_LIBRARY: another build of the same library (ablation / tuning builds under gpurun_out/, measurement only)
+    return os.environ.get("FEM_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libfemhip.so")
 
 
 def load_hip():

@@ -1,6 +1,6 @@
 """Regenerates the rocprofv3 summaries under profiles/ for one bench workload (run on the GPU box, from the repo root):
 
-    python3 profiles/make_profiles.py c2        # -> profiles/r01_c2_kernel_stats.csv, profiles/r01_c2_hbm_traffic.json
+    python3 profiles/make_profiles.py c2        # -> profiles/r02_c2_kernel_stats.csv, profiles/r02_c2_hbm_traffic.json
 
 One `--kernel-trace --stats` run for the per-kernel durations, then one `--pmc` run per counter group (PMC runs never
 carry trace options).  Every run profiles the same command: python3 bench.py --no-cpu --workload <wl>.
@@ -23,7 +23,9 @@ PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slot
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
     ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"],
 ]
-KERNELS = ("seed_fast_kernel", "seed_filter_kernel", "verify_kernel", "count_mappings_kernel", "bucket_summary_kernel")
+KERNELS = ("seed_dense_kernel", "seed_fast_kernel", "seed_filter_kernel", "verify_kernel", "count_mappings_kernel",
+           "bucket_summary_kernel", "trace_fast_kernel", "trace_kernel", "gather_kernel", "sort_kernel", "compact_kernel")
+ROUND = os.environ.get("FEM_PROFILE_ROUND", "r02")
 
 
 def run(cmd, log):
@@ -55,7 +57,7 @@ def main():
     # 1. durations
     d = os.path.join(out, "trace")
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench, os.path.join(out, "trace.log"))
-    shutil.copy(newest(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(ROOT, "profiles", "r01_%s_kernel_stats.csv" % wl))
+    shutil.copy(newest(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (ROUND, wl)))
     bench_line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")]
     reads_per_launch = None
     if bench_line:
@@ -85,7 +87,7 @@ def main():
 
     summary = {
         "command": env_note + "  (one rocprofv3 --pmc pass per counter group; the durations come from a separate "
-                   "--kernel-trace --stats pass, profiles/r01_%s_kernel_stats.csv)" % wl,
+                   "--kernel-trace --stats pass, profiles/%s_%s_kernel_stats.csv)" % (ROUND, wl),
         "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch as reported by rocprofv3 (gfx950 caveat: FETCH_SIZE "
                  "under-reports wide coalesced reads by up to 2x, MI355X_MICROARCH.md section HBM; Infinity-Cache hits are "
                  "counted); SQ_*_CYCLES summed over the chip's shader engines",
@@ -93,9 +95,9 @@ def main():
         "counter_groups": PMC_GROUPS,
         "kernels": kernels,
     }
-    with open(os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % wl), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "%s_%s_hbm_traffic.json" % (ROUND, wl)), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
-    print("wrote profiles/r01_%s_kernel_stats.csv and profiles/r01_%s_hbm_traffic.json" % (wl, wl))
+    print("wrote profiles/%s_%s_kernel_stats.csv and profiles/%s_%s_hbm_traffic.json" % (ROUND, wl, ROUND, wl))
 
 
 if __name__ == "__main__":
