@@ -43,7 +43,13 @@ constexpr uint32_t kDenseBlkShift = 20;        // blkseq[] granularity: first se
 constexpr uint32_t kDenseMaxList = 128u;       // entries of one seed's list this kernel takes (two chunks)
 
 // bitmap geometry: two bits per slot of 8 positions; slots are offset by one so that a window never starts below 0
-constexpr uint32_t dense_slots(int R) { return R >= 7 ? 32768u : 16384u; }
+#ifndef FEM_DENSE_SLOTS_LO
+#define FEM_DENSE_SLOTS_LO 16384u
+#endif
+#ifndef FEM_DENSE_SLOTS_HI
+#define FEM_DENSE_SLOTS_HI 32768u
+#endif
+constexpr uint32_t dense_slots(int R) { return R >= 7 ? FEM_DENSE_SLOTS_HI : FEM_DENSE_SLOTS_LO; }
 constexpr uint32_t dense_bitmap_words(int R) { return dense_slots(R) / 16u + 2u; }
 
 // ---- derived tables (built once per index upload) ----
@@ -124,7 +130,7 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
                            uint32_t &kept0, uint32_t &kept1) {
   const uint32_t ln = lane_id();
   constexpr uint32_t kSlots = dense_slots(R);
-  constexpr uint32_t kSlotBits = kSlots == 32768u ? 15u : 14u;
+  constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : kSlots == 32768u ? 15u : kSlots == 16384u ? 14u : 13u;
   constexpr uint32_t kFlgStride = (uint32_t)kWave + 1u;  // entry 64 of a group's array takes the overflow writes
   constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;
@@ -240,22 +246,33 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         // ---- insert.  Slot s (8 positions) sits at bit pair s + 1: pair 0 and pair kSlots + 1 are padding whose
         //      "present" bits are permanently set, so values in the first / last slot are always flagged (the table
         //      wraps there; the exact filter below decides) ----
-        uint32_t old[R], xold = 0;
+        uint32_t hit[R], xhit = 0;  // the own "present" bit if the slot already had a value, else 0
+        uint64_t vmask[R], xvmask = 0;  // lanes that hold a real entry
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          old[t] = 0;
-          if (val[t] < kDenseVLimit) old[t] = lds_or_rtn(pair_word(val[t]), pair_bit(val[t]));
+          hit[t] = 0;
+          vmask[t] = __builtin_amdgcn_ballot_w64(val[t] < kDenseVLimit);
+          if (val[t] < kDenseVLimit) {
+            const uint32_t bit = pair_bit(val[t]);
+            hit[t] = lds_or_rtn(pair_word(val[t]), bit) & bit;
+          }
         }
-        if (n_ovf && xval < kDenseVLimit) xold = lds_or_rtn(pair_word(xval), pair_bit(xval));
+        if (n_ovf) {
+          xvmask = __builtin_amdgcn_ballot_w64(xval < kDenseVLimit);
+          if (xval < kDenseVLimit) {
+            const uint32_t bit = pair_bit(xval);
+            xhit = lds_or_rtn(pair_word(xval), bit) & bit;
+          }
+        }
         uint64_t coll = 0;
 #pragma unroll
-        for (int t = 0; t < R; ++t) coll |= __builtin_amdgcn_ballot_w64((old[t] & pair_bit(val[t])) != 0u);
-        if (n_ovf) coll |= __builtin_amdgcn_ballot_w64((xold & pair_bit(xval)) != 0u);
+        for (int t = 0; t < R; ++t) coll |= __builtin_amdgcn_ballot_w64(hit[t] != 0u);
+        if (n_ovf) coll |= __builtin_amdgcn_ballot_w64(xhit != 0u);
         if (coll) {  // some slot took a second value (every true hit does): mark "twice"
 #pragma unroll
           for (int t = 0; t < R; ++t)
-            if (old[t] & pair_bit(val[t])) (void)lds_or_rtn(pair_word(val[t]), pair_bit(val[t]) << 1);
-          if (n_ovf && (xold & pair_bit(xval))) (void)lds_or_rtn(pair_word(xval), pair_bit(xval) << 1);
+            if (hit[t]) (void)lds_or_rtn(pair_word(val[t]), hit[t] << 1);
+          if (n_ovf && xhit) (void)lds_or_rtn(pair_word(xval), xhit << 1);
         }
         wave_sync_lds();
         // ---- flag: own slot hit twice, or a neighbouring slot present; compact the flagged values ----
@@ -269,18 +286,18 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
           const uint32_t *w = window_word(xval);
           xw0 = w[0], xw1 = w[1];
         }
-        auto flag_chunk = [&](uint32_t v, uint32_t a0, uint32_t a1) {
+        auto flag_chunk = [&](uint32_t v, uint32_t a0, uint32_t a1, uint64_t real) {
           const uint32_t x = __builtin_amdgcn_alignbit(a1, a0, (v >> 2) & 30u);  // bits 0..4: present/twice of slot-1, slot, slot+1
-          const bool fl = (x & 0x19u) != 0u && v < kDenseVLimit;
-          const uint64_t m = __builtin_amdgcn_ballot_w64(fl);
+          const bool near = (x & 0x19u) != 0u;
+          const uint64_t m = __builtin_amdgcn_ballot_w64(near) & real;
           uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_flag));
           pos = pos < (uint32_t)kWave ? pos : (uint32_t)kWave;
-          if (fl) flg_g[pos] = v;
+          if (near && v < kDenseVLimit) flg_g[pos] = v;
           n_flag += (uint32_t)__popcll(m);
         };
 #pragma unroll
-        for (int t = 0; t < R; ++t) flag_chunk(val[t], w0[t], w1[t]);
-        if (n_ovf) flag_chunk(xval, xw0, xw1);
+        for (int t = 0; t < R; ++t) flag_chunk(val[t], w0[t], w1[t], vmask[t]);
+        if (n_ovf) flag_chunk(xval, xw0, xw1, xvmask);
         wave_sync_lds();
         // ---- leave the bitmap clean: every lane clears the two words of its window (its own bits are in one of
         //      them), then the padding pairs get their permanent bits back ----
@@ -362,7 +379,13 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
   return true;
 }
 
-constexpr int dense_waves(int R) { return R <= 6 ? 5 : 4; }
+#ifndef FEM_DENSE_WAVES_LO
+#define FEM_DENSE_WAVES_LO 5
+#endif
+#ifndef FEM_DENSE_WAVES_HI
+#define FEM_DENSE_WAVES_HI 4
+#endif
+constexpr int dense_waves(int R) { return R <= 6 ? FEM_DENSE_WAVES_LO : FEM_DENSE_WAVES_HI; }
 
 template <int R>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_waves(R), 8))) seed_dense_kernel(SeedParams p) {
