@@ -277,6 +277,8 @@ femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
   l.X = take(64u * 4u);
   l.A = take(3u * 65u * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
+  l.rb = take((femk::kReadBlock + 2u) * 8u);  // the block's read offsets
+  l.picked = take(64u * 8u);                   // (goff, length) of up to 64 sequences
   l.F = take(femk::dense_bitmap_words((int)R) * 4u);
   l.wave_bytes = o;
   return l;

@@ -404,6 +404,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
   uint32_t *bitmap = (uint32_t *)(wbase + p.lay.F);
   uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
   uint32_t *cand_lds = (uint32_t *)(wbase + p.lay.sf);  // 2 x 64 candidates over the seed table (dead by then)
+  uint64_t *boff = (uint64_t *)(wbase + p.lay.rb);      // offsets of the block's reads (kReadBlock + 1)
+  uint2 *seqtab = (uint2 *)(wbase + p.lay.picked);      // (goff, length) of the first 64 sequences
+  const bool small_ref = p.n_seq <= (uint32_t)kWave;
+  seqtab[ln] = ln < p.n_seq ? make_uint2(p.goff[ln], p.seq_len[ln]) : make_uint2(0xFFFFFFFFu, 0u);
   for (uint32_t i = ln; i < dense_bitmap_words(R); i += kWave) bitmap[i] = 0;
   wave_sync_lds();
   if (ln == 0) bitmap[0] = 1u, bitmap[(dense_slots(R) + 1u) >> 4] = 1u << (((dense_slots(R) + 1u) << 1) & 31u);  // padding pairs: see dense_join
@@ -434,11 +438,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
     if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
     const uint32_t r0 = p.read_begin + pull;
     if (ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+    // the block's kReadBlock + 1 offsets come in with one load (lane i: read r0 + i) and sit in LDS; the first 256
+    // characters of read rb + 1 are requested before read rb is worked on (one register per lane)
+    {
+      const uint32_t last = p.n_reads - r0 < kReadBlock ? p.n_reads - r0 : kReadBlock;
+      if (ln <= last) boff[ln] = p.read_off[r0 + ln];
+      wave_sync_lds();
+    }
+    uint32_t chars_next = 0;
+    {
+      const uint64_t o0 = boff[0];
+      const uint32_t l0 = (uint32_t)(boff[1] - o0);
+      if (4u * ln < l0) chars_next = load_u32_unaligned(p.bases + o0 + 4u * ln);
+    }
     for (uint32_t rb = 0; rb < kReadBlock && r0 + rb < p.n_reads; ++rb) {
       const uint32_t read = r0 + rb;
-      const uint64_t off = p.read_off[read];
-      const uint32_t L = (uint32_t)(p.read_off[read + 1] - off);
+      const uint64_t off = __builtin_amdgcn_readfirstlane((uint32_t)boff[rb]) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(boff[rb] >> 32)) << 32);
+      const uint64_t off1 = __builtin_amdgcn_readfirstlane((uint32_t)boff[rb + 1u]) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(boff[rb + 1u] >> 32)) << 32);
+      const uint32_t L = (uint32_t)(off1 - off);
       const int S = (int)L - kK + 1;  // num_seeds_in_read
+      const uint32_t chars0 = chars_next;
+      if (rb + 1u < kReadBlock && r0 + rb + 1u < p.n_reads) {
+        const uint64_t off2 = __builtin_amdgcn_readfirstlane((uint32_t)boff[rb + 2u]) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(boff[rb + 2u] >> 32)) << 32);
+        chars_next = 0;
+        if (4u * ln < (uint32_t)(off2 - off1)) chars_next = load_u32_unaligned(p.bases + off1 + 4u * ln);
+      }
       // ---- gates (src/filter.c:161-172) + the shapes on which the reference DP is undefined ----
       bool shape_ok = S > 0 && R <= S / kStep;
       if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
@@ -458,7 +482,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
         const uint32_t idx = b0 + 4u * ln;
         if (idx < L) {
           uint32_t code, nflag;
-          encode4(load_u32_unaligned(p.bases + off + idx), code, nflag);  // may run up to 3 bytes past the read: masked below
+          encode4(b0 == 0u ? chars0 : load_u32_unaligned(p.bases + off + idx), code, nflag);  // may run up to 3 bytes past the read: masked below
           const uint32_t nb = L - idx;
           const uint32_t keep = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
           nflag &= keep;
@@ -560,12 +584,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
         const uint32_t kept = strand ? kept1 : kept0;
         uint64_t out = 0;
         bool ok = false;
-        if (ln < kept) {
-          const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];  // written by this same lane
-          uint32_t sq = p.blkseq[v >> kDenseBlkShift];
+        if (kept == 0) {
+          if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(0u, 0u);
+          continue;
+        }
+        const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];  // written by this same lane
+        uint32_t sq = 0, pos = 0, slen = 0;
+        if (small_ref) {
+          // at most 64 sequences: their coordinates sit in the lanes; one ballot per candidate finds its sequence
+          const uint2 tab = seqtab[ln];
+          for (uint32_t i = 0; i < kept; ++i) {
+            const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
+            const uint32_t s_i = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tab.x <= vi)) - 1u;  // (vi >= goff[0] always)
+            const uint32_t g_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.x, (int)s_i);
+            const uint32_t l_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.y, (int)s_i);
+            if (ln == i) sq = s_i, pos = vi - g_i, slen = l_i;
+          }
+        } else if (ln < kept) {
+          sq = p.blkseq[v >> kDenseBlkShift];
           while (sq + 1u < p.n_seq && p.goff[sq + 1u] <= v) ++sq;
-          const uint32_t pos = v - p.goff[sq];
-          const uint32_t slen = p.seq_len[sq];
+          pos = v - p.goff[sq];
+          slen = p.seq_len[sq];
+        }
+        if (ln < kept) {
           ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
           out = (((uint64_t)sq << 32) | pos) - (uint64_t)p.e;
         }
