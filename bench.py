@@ -1,65 +1,304 @@
 #!/usr/bin/env python3
 """bench.py — mapped Mreads/s of the FEM hot path (seeding + candidate filter + banded Myers) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the device hot path (libfemhip.so: seed/filter kernel + verify kernel) over one batch of
-synthetic reads that is already resident in HBM, plus the reduction of the five MappingStats counters over ranks
-(RCCL through torch.distributed when N > 1).  Reads shard over ranks (weak scaling: every rank maps its own
-`reads_per_gpu` reads, global read index = rank * reads_per_gpu + i); the index and reference are replicated.
+N > 1: bench.py starts its N ranks itself (children made before anything touches the GPU), or runs as one rank when
+it is already under torch.distributed.run (RANK / WORLD_SIZE in the environment).  One rank per GPU.
 
-Workloads (BASELINE.json `configs`, SURVEY.md §8(d)):
-    c2 (default)  5 Mbp reference, 10 M x 100 bp reads, e=3   — the configuration the metric is quoted on
-    c3            24 x 125 Mbp reference, 100 bp reads, e=3   — HBM-resident index (opt-in: --workload c3)
-    c5            24 x 125 Mbp reference, 150 bp reads, e=7   — (opt-in: --workload c5)
-Rank 0 prints ONE JSON line.
+One step = one batch of `--batch` (2.5 M) synthetic reads through the DEVICE PIPELINE of libfemhip.so:
+    library-owned pinned host staging --H2D--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
+with three batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
+`value` is that rate.  The kernels alone, replayed on a batch already resident in HBM (what round 1 reported), are
+`config.kernel_only_mreads`; the end-to-end command line (FASTQ -> SAM) is `e2e_cli`.
+
+Workloads (BASELINE.json `configs`, SURVEY.md 8d):
+    c2   5 Mbp reference, 100 bp reads, e=3        the configuration the metric is quoted on: `value`, all N
+    c3   24 x 125 Mbp reference, 100 bp, e=3       HBM-resident index; N = 1 runs it too (20 steps x 2.5 M = BASELINE's 50 M)
+    c5   same reference, 150 bp, e=7               N = 1 runs it too (20 steps x 2.5 M = BASELINE's 50 M)
+`roofline` is the dominant kernel of c3 when c3 ran (the bandwidth-relevant configuration), else of c2;
+`roofline_by_workload` has all of them.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable by a copy)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (a device copy reaches ~6.3 TB/s)
+N_SLOTS, DEPTH = 4, 3  # batch slots of the library, batches in flight
 
 WORKLOADS = {
-    "c2": dict(seed=2, seq_lens=[5_000_000], reads=10_000_000, L=100, e=3,
-               name="C2: 10M synthetic 100 bp reads, e=3, 5 Mbp random reference, k=12 step=3"),
-    "c3": dict(seed=3, seq_lens=[125_000_000] * 24, reads=20_000_000, L=100, e=3,
+    "c2": dict(seed=2, seq_lens=[5_000_000], L=100, e=3,
+               name="C2: synthetic 100 bp reads, e=3, 5 Mbp random reference, k=12 step=3"),
+    "c3": dict(seed=3, seq_lens=[125_000_000] * 24, L=100, e=3,
                name="C3: synthetic 100 bp reads, e=3, 24x125 Mbp random reference, k=12 step=3"),
-    "c5": dict(seed=5, seq_lens=[125_000_000] * 24, reads=10_000_000, L=150, e=7,
+    "c5": dict(seed=5, seq_lens=[125_000_000] * 24, L=150, e=7,
                name="C5: synthetic 150 bp reads, e=7, 24x125 Mbp random reference, k=12 step=3"),
 }
+KERNEL_IDS = {"seed": 0, "verify_kernel": 1, "seed_filter_kernel": 2, "count_mappings_kernel": 6}
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as children of a process that has not touched the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one
+    (a one-GPU box shows all of the host's CPUs in the mask but schedules only its share)."""
+    n_aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5)))
+    return n, n_aff, quota
+
+
+class Rank:
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads):
+    """Pipeline measurement + resident-kernel replay of one workload on this rank's device.  `data` = (text, off, lens)."""
+    import numpy as np
+    from fem_amd import host
+    w = WORKLOADS[key]
+    L, e, a, k, step = w["L"], w["e"], 1, 12, 3
+    text, off, lens = data
+    # a different batch in every slot, generated straight into the library's pinned staging buffers
+    t0 = time.time()
+    for s in range(N_SLOTS):
+        hb, ho = dev.acquire_stage(batch, batch * L + 8, slot=s)
+        host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=(rk.rank * N_SLOTS + s) * batch,
+                         threads=threads, out=hb, out_offsets=ho)
+    log("rank %d %s: %d x %d reads generated into pinned staging in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
+
+    def fence():
+        if rk.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    d2h_bytes = [0]
+
+    def submit(i):
+        s = i % N_SLOTS
+        dev.commit_stage(batch, L, slot=s)       # asynchronous H2D of the slot's batch
+        dev.map_staged(e=e, a=a, k=k, step=step, slot=s)
+
+    def retire(i):
+        r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits, D2H of the per-candidate outcome into pinned memory
+        d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
+        return r.stats
+
+    def pipeline(n):
+        tot = np.zeros(5, dtype=np.uint64)
+        last = None
+        for i in range(n):
+            if i >= DEPTH:
+                last = retire(i - DEPTH)
+                tot += last
+            submit(i)
+        for i in range(max(0, n - DEPTH), n):
+            last = retire(i)
+            tot += last
+        return tot, last
+
+    pipeline(max(warmup, 1))
+    stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
+    dev.set_timing(True)
+    dev.reset_timing()
+    fence()
+    t_start = time.perf_counter()
+    job, last_stats = pipeline(steps)
+    if rk.world > 1:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
+        stats_dev.copy_(torch.from_numpy(job.astype(np.int64)))
+        dist.all_reduce(stats_dev)
+        job = stats_dev.cpu().numpy().astype(np.uint64)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    dev.set_timing(False)
+    if rk.world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kt = {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}
+
+    # the kernels alone on a batch already resident in HBM (slot 0 as staged by the last pipeline step that used it)
+    dev.reset_timing()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_rep = 3
+    for _ in range(n_rep):
+        dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
+        dev.fetch_stats(slot=0)
+    torch.cuda.synchronize()
+    kernel_only = batch * n_rep / (time.perf_counter() - t1) / 1e6
+
+    seed_name = dev.seed_kernel(e=e, a=a, k=k, step=step)
+    per_launch = {}
+    for name, (ms, n) in kt.items():
+        per_launch[seed_name.split("<")[0] if name == "seed" else name] = (ms / max(n, 1), n / steps)
+    # algorithmic bytes (SURVEY.md 8d): B = N*L + 16*(L-k+1)*N + 8*P + (L+2e)*C + 16*M, from the path's own counters
+    N, P, Cn, M = batch, int(last_stats[2]), int(last_stats[3]), int(last_stats[4])
+    S = L - k + 1
+    seed_bytes = N * L + 16 * S * N + 8 * P      # read bases + one 8-byte lookup pair per seed and strand + occurrences
+    verify_bytes = (L + 2 * e) * Cn + 16 * M     # reference window per verification + result record
+    dominant = max(per_launch, key=lambda n_: per_launch[n_][0] * per_launch[n_][1])
+    dom_ms, dom_launches = per_launch[dominant]
+    dom_bytes = (verify_bytes if dominant == "verify_kernel" else seed_bytes) / max(dom_launches, 1.0)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+            "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)}
+    # HBM-side bytes of that kernel: NOT measured in this run.  They come from the committed rocprofv3 --pmc passes
+    # of this same command (profiles/r02_<wl>_hbm_traffic.json: FETCH_SIZE + WRITE_SIZE), scaled to this batch size.
+    tpath = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % key)
+    if os.path.exists(tpath):
+        try:
+            prof = json.load(open(tpath))
+            for kname, ctr in prof["kernels"].items():
+                if dominant in kname and "FETCH_SIZE" in ctr and ctr["FETCH_SIZE"]["mean_per_launch"] > 1e3:
+                    kib = ctr["FETCH_SIZE"]["mean_per_launch"] + ctr.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
+                    roof["traffic"] = int(kib * 1024 * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
+                    roof["traffic_source"] = "committed profile profiles/r02_%s_hbm_traffic.json, rescaled (not measured in this run)" % key
+        except Exception as ex:  # a malformed profile file must not break the measurement
+            log("could not read %s: %s" % (tpath, ex))
+    value = rk.world * batch * steps / elapsed / 1e6
+    return {
+        "workload": w["name"], "value": round(value, 3), "ms_per_step": round(elapsed * 1e3 / steps, 3), "steps": steps,
+        "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
+        "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
+        "h2d_bytes_per_step": batch * L + 8 * (batch + 1), "d2h_bytes_per_step": d2h_bytes[0],
+        "counters": {"reads": int(job[0]), "mapped_reads": int(job[1]), "pre_filter": int(job[2]),
+                     "candidates": int(job[3]), "mappings": int(job[4])},
+        "counters_last_step_per_gpu": [int(x) for x in last_stats],
+        "algorithmic_bytes_per_step_per_gpu": seed_bytes + verify_bytes,
+        "kernel_ms_per_launch": {n_: round(v[0], 4) for n_, v in per_launch.items()},
+        "kernel_launches_per_step": {n_: round(v[1], 2) for n_, v in per_launch.items()},
+        "roofline": roof,
+    }
+
+
+def cpu_baseline(w, data, n_sample, dev, threads):
+    """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of the
+    same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
+    import numpy as np
+    from fem_amd import host
+    from oracle import fem_oracle as fo
+    text, off, lens = data
+    L, e = w["L"], w["e"]
+    bases, offsets = host.synth_reads(w["seed"], text, off, lens, n_sample, L, e, first_read=0, threads=threads)
+    ref = fo.Reference([text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)])
+    t0 = time.time()
+    idx = fo.OracleIndex(ref)
+    t_index = time.time() - t0
+    sample = fo.ReadBatch.from_arrays(bases, offsets)
+    t0 = time.perf_counter()
+    h = fo.map_reads(ref, idx, sample, e=e, a=1, threads=threads, stages=fo.STAGE_SEED | fo.STAGE_VERIFY, keep_handle=True)
+    dt = time.perf_counter() - t0
+    st = np.zeros(5, np.uint64)
+    fo.lib().fo_result_stats(h, st.ctypes.data)
+    fo.free_result(h)
+    got = dev.map_batch(bases, offsets, e=e, a=1, slot=1).stats  # the same sample through the device path
+    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "port",
+            "sample": "%d reads of the C2 workload, seeding+filter+verification, %d threads (every core this process may use)" % (n_sample, threads),
+            "seconds": round(dt, 3), "index_build_seconds": round(t_index, 2),
+            "counters_match_device": bool(np.array_equal(got, st))}
+
+
+def e2e_cli(w, data, n_reads, threads):
+    """`FEM index` + `FEM map` on generated FASTA / FASTQ files: the mapping-phase time the reference prints itself
+    ("Time:", src/FEM_map.c:172,219), FASTQ -> SAM."""
+    import re
+    from fem_amd import host
+    text, off, lens = data
+    L, e = w["L"], w["e"]
+    exe = os.path.join(ROOT, "fem_amd", "csrc", "FEM")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="fem_e2e_", dir=base)
+    try:
+        fa, fq, ix, sam = (os.path.join(d, n) for n in ("ref.fa", "reads.fq", "ref.idx", "out.sam"))
+        host.write_fasta(fa, text, off, lens)
+        bases, _ = host.synth_reads(w["seed"], text, off, lens, n_reads, L, e, first_read=0, threads=threads)
+        host.write_fastq(fq, bases, L, n_reads)
+        r = subprocess.run([exe, "index", "12", "3", fa, ix], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "FEM index failed: " + r.stderr[-300:]}
+        t0 = time.perf_counter()
+        env = dict(os.environ, FEM_STAGE_TIMES="1")
+        r = subprocess.run([exe, "map", "-e", str(e), "-t", str(threads), "--ref", fa, "--index", ix, "--read1", fq, "-o", sam],
+                           capture_output=True, text=True, timeout=600, env=env)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "FEM map failed: " + r.stderr[-300:]}
+        m = re.search(r"Time: ([0-9.]+)s", r.stderr)
+        st = re.search(r"stage busy seconds: (.*)", r.stderr)
+        secs = float(m.group(1)) if m else None
+        return {"value": round(n_reads / secs / 1e6, 3) if secs else None, "unit": "Mreads/s",
+                "what": "FEM map mapping phase (its own 'Time:' line): FASTQ parse -> device -> SAM text -> file, %d reads of C2, -t %d, files in %s"
+                        % (n_reads, threads, base or "tmp"),
+                "seconds": secs, "wall_seconds_incl_load": round(wall, 3), "sam_bytes": os.path.getsize(sam),
+                "stage_busy": st.group(1) if st else None}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the same workload timed on the host cores")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="the workload `value` is measured on")
+    ap.add_argument("--batch", type=int, default=2_500_000, help="reads per step and GPU")
+    ap.add_argument("--extra", default="auto", help="comma list of further workloads measured on rank 0 when N = 1 "
+                                                    "(auto = c3,c5 next to c2; none)")
+    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
+    ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.batch < 1:
+        sys.exit("bench.py: --steps >= 1, --warmup >= 0, --batch >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-
+    rk = Rank()
+    if rk.world != args.gpus:
+        args.gpus = rk.world
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -67,176 +306,106 @@ def main():
     # Rehearsal hooks for a one-GPU box (never set by the driver): FEM_BENCH_ONE_GPU=1 puts every rank on GPU 0,
     # FEM_BENCH_BACKEND=gloo reduces the counters over gloo instead of RCCL (RCCL refuses two ranks on one GPU).
     backend = os.environ.get("FEM_BENCH_BACKEND", "nccl")
-    if os.environ.get("FEM_BENCH_ONE_GPU") == "1":
-        local_rank = 0
+    local_rank = 0 if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else rk.local_rank
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if rk.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rk.rank, world_size=rk.world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rk.rank, world_size=rk.world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from fem_amd import Device, host
+    cores, n_aff, quota = usable_cores()
+    if "FEM_BENCH_THREADS" in os.environ:
+        cores = max(1, int(os.environ["FEM_BENCH_THREADS"]))
+    threads = max(1, cores // (rk.world if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else 1))
+    gen_threads = max(1, min(threads, 32))
+    log("rank %d: %d host threads (affinity mask %d CPUs, cgroup quota %s)" % (rk.rank, threads, n_aff, quota))
 
-    w = WORKLOADS[args.workload]
-    n_reads = args.reads or w["reads"]
-    L, e, a, k, step = w["L"], w["e"], 1, 12, 3
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    extras = []
+    if rk.world == 1 and args.extra != "none":
+        extras = [x for x in (["c3", "c5"] if args.extra == "auto" else args.extra.split(",")) if x in WORKLOADS and x != args.workload]
+        if args.extra == "auto" and args.workload != "c2":
+            extras = []
 
-    t0 = time.time()
-    text, off, lens = host.synth_reference(w["seed"], w["seq_lens"], threads=threads)
-    dev = Device(local_rank)
-    dev.upload_reference([text[int(o):int(o) + int(l)] for o, l in zip(off, lens)])
-    n_occ, _, _ = dev.build_index(k, step, fetch=False)
-    log("rank %d: reference %d bp in %d sequences, index %d entries built on device in %.1fs"
-        % (rank, int(lens.astype(np.uint64).sum()), len(lens), n_occ, time.time() - t0))
-    t0 = time.time()
-    bases, offsets = host.synth_reads(w["seed"], text, off, lens, n_reads, L, e, first_read=rank * n_reads, threads=threads)
-    log("rank %d: %d reads generated in %.1fs" % (rank, n_reads, time.time() - t0))
-    t0 = time.time()
-    dev.stage_reads(bases, offsets, slot=0)
-    h2d_s = time.time() - t0
+    results, data_cache = {}, {}
+    dev = None
+    bw = {}
+    for key in [args.workload] + extras:
+        w = WORKLOADS[key]
+        ref_key = (w["seed"] if key == "c2" else 3, tuple(w["seq_lens"]))  # c3 and c5 share one reference (seed 3)
+        t0 = time.time()
+        if ref_key not in data_cache:
+            data_cache.clear()
+            if dev is not None:
+                dev.close()
+            text, off, lens = host.synth_reference(ref_key[0], w["seq_lens"], threads=gen_threads)
+            dev = Device(local_rank)
+            dev.upload_reference([text[int(o):int(o) + int(l)] for o, l in zip(off, lens)])
+            n_occ, _, _ = dev.build_index(12, 3, fetch=False)
+            data_cache[ref_key] = (text, off, lens, n_occ)
+            log("rank %d %s: reference %d bp in %d sequences, index %d entries built on device in %.1fs"
+                % (rk.rank, key, int(lens.astype(np.uint64).sum()), len(lens), n_occ, time.time() - t0))
+            if not bw:
+                bw = {"device_copy_gbs": round(dev.copy_bandwidth(1 << 30, 10), 1), "pinned_h2d_gbs": round(dev.h2d_bandwidth(1 << 28, 8), 1)}
+        text, off, lens, n_occ = data_cache[ref_key]
+        steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, 1)
+        res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads)
+        res["index_entries"] = n_occ
+        results[key] = res
+        log("rank %d %s: pipeline %.1f Mreads/s, kernels only %.1f, %s" % (rk.rank, key, res["value"], res["kernel_only_mreads"], res["kernel_ms_per_launch"]))
 
-    stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
-
-    def step_once():
-        dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
-        return dev.fetch_stats(slot=0)  # waits for the kernels (and re-runs the batch if a scratch buffer had to grow)
-
-    def reduce_stats(st):
-        # MappingStats reduction (reference src/FEM_map.c:200-212: once per job, after the last batch) = one 40-byte
-        # RCCL all-reduce
-        if world == 1:
-            return st
-        stats_dev.copy_(torch.from_numpy(st.astype(np.int64)))
-        dist.all_reduce(stats_dev)
-        return stats_dev.cpu().numpy().astype(np.uint64)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step_once()
-    dev.set_timing(True)
-    dev.reset_timing()
-    fence()
-    t_start = time.perf_counter()
-    job_stats = np.zeros(5, dtype=np.uint64)
-    for _ in range(args.steps):
-        local_stats = step_once()
-        job_stats += local_stats.astype(np.uint64)
-    total_stats = reduce_stats(job_stats)  # (inside the timed region: it is the path's one exchange)
-    fence()
-    elapsed = time.perf_counter() - t_start
-    dev.set_timing(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # per-kernel HIP-event totals over the timed region
-    fast_ms, fast_n = dev.kernel_time(0)   # seed_fast_kernel<R, ...>
-    ver_ms, ver_n = dev.kernel_time(1)     # verify_kernel
-    gen_ms, gen_n = dev.kernel_time(2)     # seed_filter_kernel (generic form: queued reads)
-    cnt_ms, cnt_n = dev.kernel_time(6)     # count_mappings_kernel (per-read counts + counters)
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = world * n_reads * args.steps / elapsed / 1e6
-
-    # algorithmic bytes (SURVEY.md §8(d)): B = N*L + 16*(L-k+1)*N + 8*P + (L+2e)*C + 16*M, from the path's own counters
-    N, P, Cn, M = n_reads, int(local_stats[2]), int(local_stats[3]), int(local_stats[4])
-    S = L - k + 1
-    seed_bytes = N * L + 16 * S * N + 8 * P      # read bases + one 8-byte lookup pair per seed and strand + occurrences
-    verify_bytes = (L + 2 * e) * Cn + 16 * M     # reference window per verification + result record
-    step_ms = {"seed_fast_kernel": fast_ms / args.steps, "seed_filter_kernel": gen_ms / args.steps,
-               "verify_kernel": ver_ms / args.steps, "count_mappings_kernel": cnt_ms / args.steps}
-    launches = {"seed_fast_kernel": fast_n / args.steps, "seed_filter_kernel": gen_n / args.steps,
-                "verify_kernel": ver_n / args.steps, "count_mappings_kernel": cnt_n / args.steps}
-    dominant = max(step_ms, key=step_ms.get)
-    # the two seed kernels split the same reads: the dominant one is charged the seeding bytes of the whole batch
-    dom_bytes_step = verify_bytes if dominant == "verify_kernel" else seed_bytes
-    n_launch = max(launches[dominant], 1.0)
-    dom_ms = step_ms[dominant] / n_launch          # mean duration of one launch
-    dom_bytes = dom_bytes_step / n_launch          # algorithmic bytes of one launch
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    per_launch = {k_: (step_ms[k_] / max(launches[k_], 1.0)) for k_ in step_ms}
-
-    if rank != 0:
-        if world > 1:
+    if rk.rank != 0:
+        if rk.world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
-    # (FETCH_SIZE, WRITE_SIZE; summaries committed under profiles/), scaled to this run's reads per launch.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            prof = json.load(open(tpath))
-            for kname, ctr in prof["kernels"].items():
-                if dominant.split("_kernel")[0] in kname and "FETCH_SIZE" in ctr and ctr["FETCH_SIZE"]["mean_per_launch"] > 1e3:
-                    kib = ctr["FETCH_SIZE"]["mean_per_launch"] + ctr.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
-                    traffic = int(kib * 1024 * (n_reads / n_launch) / prof["reads_per_launch"])
-        except Exception as ex:  # a malformed profile file must not break the measurement
-            log("could not read %s: %s" % (tpath, ex))
-
+    head = results[args.workload]
+    roof_key = "c3" if "c3" in results else args.workload
     out = {
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
-        "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64/u32 integer + 32-bit Myers bit-vectors", "data": "synthetic",
-        "config": {"workload": w["name"], "reads_per_gpu": n_reads, "read_len": L, "e": e, "a": a, "k": k, "step": step,
-                   "index_entries": n_occ, "parallelism": "reads sharded x%d, index replicated" % world,
-                   # MappingStats of the whole job (all ranks, all timed steps), as the reference prints them at its end
-                   "counters": {"reads": int(total_stats[0]), "mapped_reads": int(total_stats[1]),
-                                "pre_filter": int(total_stats[2]), "candidates": int(total_stats[3]),
-                                "mappings": int(total_stats[4])},
-                   "counters_per_step_per_gpu": [int(x) for x in local_stats],
-                   "algorithmic_bytes_per_step_per_gpu": seed_bytes + verify_bytes,
-                   "kernel_ms_per_launch": {k_: round(v_, 4) for k_, v_ in per_launch.items()},
-                   "kernel_launches_per_step": {k_: round(v_, 2) for k_, v_ in launches.items()},
-                   "h2d_stage_s": round(h2d_s, 3)},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
+        "value": head["value"], "unit": "Mreads/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic",
+        "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline")},
+                       value_is="device pipeline: pinned host staging -> H2D -> kernels -> D2H of fem_batch_result, %d batches in flight, "
+                                "a different batch per slot" % DEPTH,
+                       parallelism="reads sharded x%d, index replicated" % rk.world, bandwidths=bw),
+        "roofline": dict(results[roof_key]["roofline"], workload=roof_key),
+        "roofline_by_workload": {k_: v_["roofline"] for k_, v_ in results.items()},
+        "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
+                                                           "reads_per_step_per_gpu", "kernel_ms_per_launch", "counters_last_step_per_gpu",
+                                                           "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "d2h_bytes_per_step")}
+                                 for k_, v_ in results.items()},
     }
-
-    if not args.no_cpu and world == 1:
-        out["cpu_baseline"] = cpu_baseline(w, text, off, lens, min(args.cpu_sample, n_reads), bases, offsets, dev, e, a)
-    print(json.dumps(out), flush=True)
+    c2_data = None
+    if (not args.no_cpu or not args.no_e2e) and rk.world == 1:
+        w2 = WORKLOADS["c2"]
+        if (w2["seed"], tuple(w2["seq_lens"])) in data_cache:
+            c2_data = data_cache[(w2["seed"], tuple(w2["seq_lens"]))][:3]
+        else:
+            dev.close()
+            t2 = host.synth_reference(w2["seed"], w2["seq_lens"], threads=gen_threads)
+            dev = Device(local_rank)
+            dev.upload_reference([t2[0][int(o):int(o) + int(l)] for o, l in zip(t2[1], t2[2])])
+            dev.build_index(12, 3, fetch=False)
+            c2_data = t2
+    if not args.no_cpu and rk.world == 1:
+        out["cpu_baseline"] = cpu_baseline(WORKLOADS["c2"], c2_data, args.cpu_sample, dev, threads)
+        out["cpu_baseline"].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota)
     dev.close()
-    if world > 1:
+    if not args.no_e2e and rk.world == 1 and args.e2e_reads > 0:
+        try:
+            out["e2e_cli"] = e2e_cli(WORKLOADS["c2"], c2_data, args.e2e_reads, threads)
+        except Exception as ex:
+            out["e2e_cli"] = {"error": repr(ex)}
+    print(json.dumps(out), flush=True)
+    if rk.world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def cpu_baseline(w, text, off, lens, n_sample, bases, offsets, dev, e, a):
-    """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of
-    the same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
-    from oracle import fem_oracle as fo
-    cores = min(len(os.sched_getaffinity(0)), 16)  # the CPU share of a one-GPU box
-    L = w["L"]
-    ref = fo.Reference([text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)])
-    t0 = time.time()
-    idx = fo.OracleIndex(ref)
-    t_index = time.time() - t0
-    sample = fo.ReadBatch.from_arrays(bases[:n_sample * L + 8], offsets[:n_sample + 1])
-    t0 = time.perf_counter()
-    h = fo.map_reads(ref, idx, sample, e=e, a=a, threads=cores, stages=fo.STAGE_SEED | fo.STAGE_VERIFY, keep_handle=True)
-    dt = time.perf_counter() - t0
-    st = np.zeros(5, np.uint64)
-    fo.lib().fo_result_stats(h, st.ctypes.data)
-    fo.free_result(h)
-    # the same sample through the device path must give the same five counters
-    got = dev.map_batch(bases[:n_sample * L + 8], offsets[:n_sample + 1], e=e, a=a, slot=1).stats
-    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same workload, seeding+filter+verification, %d threads" % (n_sample, cores),
-            "seconds": round(dt, 3), "index_build_seconds": round(t_index, 2),
-            "counters_match_device": bool(np.array_equal(got, st))}
 
 
 if __name__ == "__main__":

@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fem_index_build.hip.h"
@@ -43,6 +46,11 @@ struct Slot {
   uint64_t n_bases = 0;
   uint32_t max_len = 0;
   bool staged = false;
+  // pinned host staging lent to the parser (fem_dev_acquire_stage)
+  char *h_bases = nullptr;
+  size_t h_bases_cap = 0;
+  uint64_t *h_off = nullptr;
+  size_t h_off_cap = 0;
   // outputs on the device
   uint64_t *d_cand = nullptr;
   uint32_t *d_meta = nullptr;
@@ -121,6 +129,11 @@ struct fem_dev {
   bool no_dense = false;       // FEM_NO_DENSE=1: never run seed_dense_kernel (measurement / A-B hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
   std::vector<hipEvent_t> event_pool;
+  // The slots' streams overlap copies with kernels, but the kernels of different batches run one after the other
+  // (each batch's first kernel waits for the previous batch's last): two batches' seed kernels side by side only
+  // evict each other's index lines, and per-kernel event times stay those of a kernel that has the chip to itself.
+  hipEvent_t ev_kernels_done = nullptr;
+  bool have_kernels_done = false;
 };
 
 namespace {
@@ -503,6 +516,7 @@ int launch_batch(fem_dev *h, Slot &s) {
 
   if (s.n_reads) {
     int rc;
+    if (h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
     femk::VerifyParams vp{};
     vp.bases = s.bases(), vp.read_off = s.d_off;
     vp.plane[0] = h->d_plane[0], vp.plane[1] = h->d_plane[1], vp.plane[2] = h->d_plane[2], vp.seq_off = h->d_seq_off;
@@ -590,6 +604,8 @@ int launch_batch(fem_dev *h, Slot &s) {
       hipLaunchKernelGGL(femk::count_mappings_kernel, dim3(blocks), dim3(256), 0, s.stream, cp);
     });
     if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_kernels_done, s.stream));
+    h->have_kernels_done = true;
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.mapped = true;
@@ -662,6 +678,25 @@ int refresh_dense(fem_dev *h) {
   return FEM_OK;
 }
 
+// The RCCL communicator of fem_dev_allreduce_stats (one process, one handle per GPU): kept across calls.
+struct CommSet {
+  std::vector<int> devs;
+  std::vector<ncclComm_t> comms;
+  std::vector<uint64_t *> bufs;
+};
+std::mutex g_comm_mu;
+CommSet *g_comm = nullptr;
+void destroy_comm_set() {  // caller holds g_comm_mu
+  if (!g_comm) return;
+  for (size_t i = 0; i < g_comm->devs.size(); ++i) {
+    (void)hipSetDevice(g_comm->devs[i]);
+    if (g_comm->bufs[i]) (void)hipFree(g_comm->bufs[i]);
+    if (g_comm->comms[i]) ncclCommDestroy(g_comm->comms[i]);
+  }
+  delete g_comm;
+  g_comm = nullptr;
+}
+
 int check_slot(fem_dev *h, int slot) {
   if (!h) return FEM_ERR_INVALID;
   if (slot < 0 || slot >= kSlots) return fail(h, FEM_ERR_INVALID, "slot out of range");
@@ -708,6 +743,10 @@ int fem_dev_open(int device, fem_dev **out) {
       return FEM_ERR_HIP;
     }
   }
+  if (hipEventCreateWithFlags(&h->ev_kernels_done, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return FEM_ERR_HIP;
+  }
   const char *fg = getenv("FEM_FORCE_GENERIC");
   h->force_generic = fg && fg[0] == '1';
   const char *fh = getenv("FEM_FORCE_HASH");
@@ -724,6 +763,10 @@ int fem_dev_open(int device, fem_dev **out) {
 
 int fem_dev_close(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    if (g_comm && std::find(g_comm->devs.begin(), g_comm->devs.end(), h->device) != g_comm->devs.end()) destroy_comm_set();
+  }
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (auto &s : h->slot) {
@@ -733,13 +776,14 @@ int fem_dev_close(fem_dev *h) {
                     (void *)s.d_arena, (void *)s.d_slow})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
-                    (void *)s.h_end})
+                    (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     delete s.tail;
     s.tail = nullptr;
   }
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
                   (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq})
@@ -859,41 +903,94 @@ int fem_dev_fetch_index(fem_dev *h, uint32_t *lookup_out, uint64_t *occ_out, uin
   return FEM_OK;
 }
 
+int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, char **bases, uint64_t **offsets) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  if (!bases || !offsets) return fail(h, FEM_ERR_INVALID, "null output pointer");
+  if (n_reads_cap > 0x3FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^30 reads in one batch");
+  Slot &s = h->slot[slot];
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(s.stream));  // the previous batch's copy out of these buffers is done
+  drain_timing(h, s);
+  if ((rc = pinned_realloc(h, &s.h_bases, &s.h_bases_cap, (size_t)n_bases_cap + 64))) return rc;
+  if ((rc = pinned_realloc(h, &s.h_off, &s.h_off_cap, (size_t)n_reads_cap + 1))) return rc;
+  s.staged = false, s.mapped = false, s.synced = false;
+  *bases = s.h_bases, *offsets = s.h_off;
+  return FEM_OK;
+}
+
+int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_len) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!s.h_bases || !s.h_off) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
+  if (n_reads + 1 > s.h_off_cap) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
+  if (max_len > kMaxReadLen)
+    return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
+  const uint64_t n_bases = n_reads ? s.h_off[n_reads] : 0;
+  if (n_reads && (s.h_off[0] != 0 || n_bases + 64 > s.h_bases_cap)) return fail(h, FEM_ERR_INVALID, "staged offsets must start at 0 and end inside the buffer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), s.h_bases, n_bases, hipMemcpyHostToDevice, s.stream));
+  if (n_reads) HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  s.n_reads = n_reads, s.n_bases = n_bases, s.max_len = max_len;
+  s.staged = true, s.mapped = false, s.synced = false;
+  return FEM_OK;
+}
+
 int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
   if (!reads || (reads->n_reads && (!reads->bases || !reads->offsets))) return fail(h, FEM_ERR_INVALID, "null read batch");
   if (reads->n_reads > 0x3FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^30 reads in one batch");
-  Slot &s = h->slot[slot];
-  HIP_TRY(h, hipSetDevice(h->device));
-  HIP_TRY(h, hipStreamSynchronize(s.stream));
-  drain_timing(h, s);
   const uint64_t n = reads->n_reads;
   const uint64_t base0 = n ? reads->offsets[0] : 0;
+  if (n && reads->offsets[n] < base0) return fail(h, FEM_ERR_INVALID, "read offsets must be ascending");
   const uint64_t n_bases = n ? reads->offsets[n] - base0 : 0;
-  uint32_t max_len = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    uint64_t len = reads->offsets[i + 1] - reads->offsets[i];
-    if (reads->offsets[i + 1] < reads->offsets[i]) return fail(h, FEM_ERR_INVALID, "read offsets must be ascending");
-    if (len > kMaxReadLen)
-      return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
-    max_len = std::max<uint32_t>(max_len, (uint32_t)len);
-  }
-  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
-  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
-  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), reads->bases + base0, n_bases, hipMemcpyHostToDevice, s.stream));
-  if (base0 == 0) {
-    HIP_TRY(h, hipMemcpyAsync(s.d_off, reads->offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(h, hipStreamSynchronize(s.stream));
+  char *hb = nullptr;
+  uint64_t *ho = nullptr;
+  if ((rc = fem_dev_acquire_stage(h, slot, n, n_bases, &hb, &ho))) return rc;
+  // copy + check in a few host threads: relative offsets, longest read, order
+  const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(hw ? hw : 1), 8ull, n / 65536 + 1}));
+  std::vector<uint32_t> t_max(n_thr, 0);
+  std::atomic<int> bad{0};
+  auto work = [&](unsigned t) {
+    const uint64_t r_lo = n * t / n_thr, r_hi = n * (t + 1) / n_thr;
+    uint32_t mx = 0;
+    for (uint64_t i = r_lo; i < r_hi; ++i) {
+      const uint64_t o0 = reads->offsets[i], o1 = reads->offsets[i + 1];
+      if (o1 < o0) {
+        bad.store(1);
+        return;
+      }
+      const uint64_t len = o1 - o0;
+      if (len > kMaxReadLen) {
+        bad.store(2);
+        return;
+      }
+      mx = std::max<uint32_t>(mx, (uint32_t)len);
+      ho[i] = o0 - base0;
+    }
+    if (r_hi == n) ho[n] = reads->offsets[n] - base0;
+    if (r_hi > r_lo) memcpy(hb + (reads->offsets[r_lo] - base0), reads->bases + reads->offsets[r_lo], reads->offsets[r_hi] - reads->offsets[r_lo]);
+    t_max[t] = mx;
+  };
+  if (n_thr == 1) {
+    work(0);
   } else {
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) rel[i] = reads->offsets[i] - base0;
-    HIP_TRY(h, hipMemcpyAsync(s.d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
   }
-  s.n_reads = n, s.n_bases = n_bases, s.max_len = max_len;
-  s.staged = true, s.mapped = false, s.synced = false;
-  return FEM_OK;
+  if (n == 0) ho[0] = 0;
+  if (bad.load() == 1) return fail(h, FEM_ERR_INVALID, "read offsets must be ascending");
+  if (bad.load() == 2)
+    return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
+  uint32_t max_len = 0;
+  for (uint32_t m : t_max) max_len = std::max(max_len, m);
+  return fem_dev_commit_stage(h, slot, n, max_len);
 }
 
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p) {
@@ -1052,6 +1149,15 @@ int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fe
 
 int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out) { return fem_dev_fetch(h, slot, out); }
 
+const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
+  if (!h || !params_ok(p)) return "";
+  const int R = p->e + 1 + p->a;
+  const bool use_fast = !h->force_generic && p->k == femk::kK && p->step == femk::kStep && R >= 1 && R <= femk::kMaxR;
+  if (!use_fast) return "seed_filter_kernel";
+  if (h->d_occ32) return "seed_dense_kernel";
+  return (h->force_hash || (double)h->n_occ > (double)h->n_lookup) ? "seed_fast_kernel<hash>" : "seed_fast_kernel<lean>";
+}
+
 int fem_dev_set_timing(fem_dev *h, int on) {
   if (!h) return FEM_ERR_INVALID;
   h->timing = on != 0;
@@ -1099,6 +1205,34 @@ int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per
   return FEM_OK;
 }
 
+int fem_dev_h2d_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s) {
+  if (!h || !gb_per_s || bytes == 0 || iters <= 0) return FEM_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  void *a = nullptr, *b = nullptr;
+  HIP_TRY(h, hipHostMalloc(&a, bytes, hipHostMallocDefault));
+  if (hipMalloc(&b, bytes) != hipSuccess) {
+    (void)hipHostFree(a);
+    return fail(h, FEM_ERR_NOMEM, "h2d bandwidth probe: out of memory");
+  }
+  memset(a, 1, bytes);
+  hipStream_t st = h->slot[0].stream;
+  hipEvent_t e0 = get_event(h), e1 = get_event(h);
+  (void)hipMemcpyAsync(b, a, bytes, hipMemcpyHostToDevice, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) (void)hipMemcpyAsync(b, a, bytes, hipMemcpyHostToDevice, st);
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipStreamSynchronize(st);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  h->event_pool.push_back(e0);
+  h->event_pool.push_back(e1);
+  (void)hipHostFree(a);
+  (void)hipFree(b);
+  if (e != hipSuccess) return fail(h, FEM_ERR_HIP, hipGetErrorString(e));
+  *gb_per_s = ms > 0 ? ((double)bytes * iters) / (ms * 1e6) : 0.0;
+  return FEM_OK;
+}
+
 #ifdef FEM_STAMPS
 // diagnostic build only: read and clear the seed kernel's per-phase cycle totals
 int fem_dbg_stamps(uint64_t *out, int n) {
@@ -1119,33 +1253,47 @@ int fem_dev_allreduce_stats(fem_dev *const *hs, int n, uint64_t *stats) {
     devs[i] = hs[i]->device;
   }
   fem_dev *h0 = hs[0];
-  std::vector<ncclComm_t> comms(n);
-  if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return fail(h0, FEM_ERR_RCCL, "ncclCommInitAll failed");
-  std::vector<uint64_t *> bufs(n, nullptr);
+  std::lock_guard<std::mutex> lock(g_comm_mu);
+  // one communicator per job: created on the first call, reused while the same devices take part
+  if (!g_comm || g_comm->devs != devs) {
+    destroy_comm_set();
+    CommSet *cs = new (std::nothrow) CommSet();
+    if (!cs) return fail(h0, FEM_ERR_NOMEM, "out of host memory");
+    cs->devs = devs;
+    cs->comms.assign(n, nullptr);
+    cs->bufs.assign(n, nullptr);
+    if (ncclCommInitAll(cs->comms.data(), n, devs.data()) != ncclSuccess) {
+      delete cs;
+      return fail(h0, FEM_ERR_RCCL, "ncclCommInitAll failed");
+    }
+    g_comm = cs;
+    for (int i = 0; i < n; ++i)
+      if (hipSetDevice(devs[i]) != hipSuccess || hipMalloc((void **)&cs->bufs[i], 5 * sizeof(uint64_t)) != hipSuccess) {
+        destroy_comm_set();
+        return fail(h0, FEM_ERR_HIP, "allreduce: allocating the counter buffers failed");
+      }
+  }
+  CommSet &cs = *g_comm;
   int rc = FEM_OK;
   for (int i = 0; i < n && rc == FEM_OK; ++i) {
-    if (hipSetDevice(devs[i]) != hipSuccess || hipMalloc((void **)&bufs[i], 5 * sizeof(uint64_t)) != hipSuccess ||
-        hipMemcpy(bufs[i], stats + 5 * i, 5 * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipSetDevice(devs[i]) != hipSuccess ||
+        hipMemcpyAsync(cs.bufs[i], stats + 5 * i, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, hs[i]->slot[0].stream) != hipSuccess)
       rc = fail(h0, FEM_ERR_HIP, "allreduce: staging the counters failed");
   }
   if (rc == FEM_OK) {
     ncclGroupStart();
     for (int i = 0; i < n; ++i) {
       (void)hipSetDevice(devs[i]);
-      if (ncclAllReduce(bufs[i], bufs[i], 5, ncclUint64, ncclSum, comms[i], hs[i]->slot[0].stream) != ncclSuccess)
+      if (ncclAllReduce(cs.bufs[i], cs.bufs[i], 5, ncclUint64, ncclSum, cs.comms[i], hs[i]->slot[0].stream) != ncclSuccess)
         rc = fail(h0, FEM_ERR_RCCL, "ncclAllReduce failed");
     }
     if (ncclGroupEnd() != ncclSuccess) rc = fail(h0, FEM_ERR_RCCL, "ncclGroupEnd failed");
   }
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n && rc == FEM_OK; ++i) {
     (void)hipSetDevice(devs[i]);
-    if (rc == FEM_OK) {
-      if (hipStreamSynchronize(hs[i]->slot[0].stream) != hipSuccess ||
-          hipMemcpy(stats + 5 * i, bufs[i], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(h0, FEM_ERR_HIP, "allreduce: reading the counters back failed");
-    }
-    if (bufs[i]) (void)hipFree(bufs[i]);
-    ncclCommDestroy(comms[i]);
+    if (hipStreamSynchronize(hs[i]->slot[0].stream) != hipSuccess ||
+        hipMemcpy(stats + 5 * i, cs.bufs[i], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(h0, FEM_ERR_HIP, "allreduce: reading the counters back failed");
   }
   return rc;
 }

@@ -1115,6 +1115,12 @@ void fem_synth_reference(uint64_t seed, uint32_t n_seq, const uint64_t *seq_off,
 void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
                      uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
                      int n_threads) {
+  fem_synth_reads_ex(seed, ref_text, seq_off, seq_len, n_seq, first_read, n_reads, L, e, bases_out, nullptr, n_threads);
+}
+
+void fem_synth_reads_ex(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
+                        uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
+                        uint8_t *n_err_out, int n_threads) {
   static const char acgt[4] = {'A', 'C', 'G', 'T'};
   if (n_threads < 1) n_threads = 1;
   // sequences long enough to hold a read, weighted by the number of admissible start positions
@@ -1131,6 +1137,7 @@ void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_of
       char *dst = bases_out + (uint64_t)r * L;
       if (total == 0) {
         for (uint32_t i = 0; i < L; ++i) dst[i] = acgt[rng.below(4)];
+        if (n_err_out) n_err_out[r] = 0;
         continue;
       }
       const uint64_t pick = rng.below(total);
@@ -1139,9 +1146,12 @@ void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_of
       memcpy(buf.data(), ref_text + seq_off[s] + start, span);
       size_t cur = span;
       const int n_err = (int)rng.below((uint64_t)e + 1);
+      if (n_err_out) n_err_out[r] = (uint8_t)n_err;
       for (int k = 0; k < n_err; ++k) {
         const uint64_t kind = rng.below(10);
-        const size_t pos = 1 + (size_t)rng.below(cur > 2 ? cur - 2 : 1);
+        // a uniform interior offset of the READ: inside the first L bases, so that the truncation to L
+        // never cuts an error off (round 1 drew from the whole L + e window: ~e/2L of the errors fell behind the cut)
+        const size_t pos = 1 + (size_t)rng.below(L > 2 ? L - 2 : 1);
         if (kind < 6) {  // substitution by a different base
           const char old = buf[pos];
           char nb;

@@ -124,6 +124,10 @@ void fem_synth_reference(uint64_t seed, uint32_t n_seq, const uint64_t *seq_off,
 void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
                      uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
                      int n_threads);
+/* the same, and the number of edits put into each read (n_err_out may be NULL) */
+void fem_synth_reads_ex(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
+                        uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
+                        uint8_t *n_err_out, int n_threads);
 
 /* Writes reads as FASTQ ("@r<index>", constant quality 'I') or a reference as FASTA (60 columns); for the
  * end-to-end measurements and tests.  Returns 0 or <0. */

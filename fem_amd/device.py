@@ -12,9 +12,10 @@ ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
-    "fem_dev_stage_reads", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
-    "fem_dev_fetch_records",
+    "fem_dev_stage_reads", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
+    "fem_dev_h2d_bandwidth",
     "fem_dev_allreduce_stats",
 ]
 
@@ -74,40 +75,48 @@ def load_hip():
     L.fem_dev_map_batch_submit.argtypes = [vp, C.c_int, C.POINTER(Params), C.POINTER(_ReadBatch)]
     L.fem_dev_map_batch_wait.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
     L.fem_dev_stage_reads.argtypes = [vp, C.c_int, C.POINTER(_ReadBatch)]
+    L.fem_dev_acquire_stage.argtypes = [vp, C.c_int, u64, u64, C.POINTER(vp), C.POINTER(vp)]
+    L.fem_dev_commit_stage.argtypes = [vp, C.c_int, u64, C.c_uint32]
     L.fem_dev_map_staged.argtypes = [vp, C.c_int, C.POINTER(Params)]
     L.fem_dev_sync.argtypes = [vp, C.c_int]
     L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
     L.fem_dev_fetch.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
     L.fem_dev_fetch_records.argtypes = [vp, C.c_int, C.POINTER(_BatchRecords)]
+    L.fem_dev_seed_kernel.restype = C.c_char_p
+    L.fem_dev_seed_kernel.argtypes = [vp, C.POINTER(Params)]
     L.fem_dev_set_timing.argtypes = [vp, C.c_int]
     L.fem_dev_reset_timing.argtypes = [vp]
     L.fem_dev_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
     L.fem_dev_copy_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
+    L.fem_dev_h2d_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_allreduce_stats.argtypes = [C.POINTER(vp), C.c_int, vp]
     _HIP = L
     return L
 
 
-def _copy(ptr, n, dtype):
+def _copy(ptr, n, dtype, copy=True):
     n = int(n)
     if n == 0 or not ptr:
         return np.zeros(0, dtype=dtype)
     buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+    a = np.frombuffer(buf, dtype=dtype, count=n)
+    return a.copy() if copy else a
 
 
 class BatchResult:
-    """Host copy of fem_batch_result."""
+    """fem_batch_result: host copies of the arrays, or (copy=False) views of the handle's pinned result buffers,
+    valid until the slot is staged or mapped again."""
 
-    def __init__(self, r):
+    def __init__(self, r, copy=True):
         n2 = 2 * int(r.n_reads)
         nc = int(r.n_candidates)
         self.n_reads = int(r.n_reads)
-        self.cand_begin = _copy(r.cand_begin, n2, np.uint32)
-        self.cand_count = _copy(r.cand_count, n2, np.uint32)
-        self.cand = _copy(r.cand, nc, np.uint64)
-        self.ed = _copy(r.ed, nc, np.uint8)
-        self.end = _copy(r.end, nc, np.int16)
+        self.n_candidates = nc
+        self.cand_begin = _copy(r.cand_begin, n2, np.uint32, copy)
+        self.cand_count = _copy(r.cand_count, n2, np.uint32, copy)
+        self.cand = _copy(r.cand, nc, np.uint64, copy)
+        self.ed = _copy(r.ed, nc, np.uint8, copy)
+        self.end = _copy(r.end, nc, np.int16, copy)
         self.stats = np.array(list(r.stats), dtype=np.uint64)
 
     def per_strand(self):
@@ -210,6 +219,18 @@ class Device:
         b, keep = self._batch(bases, offsets)
         self._check(self._L.fem_dev_stage_reads(self._h, slot, C.byref(b)))
 
+    def acquire_stage(self, n_reads_cap, n_bases_cap, slot=0):
+        """The slot's pinned staging buffers as numpy views (bases uint8[n_bases_cap + 64], offsets uint64[n_reads_cap + 1]):
+        a parser (or a generator) writes the batch straight into them; commit_stage() then starts the H2D copy."""
+        pb, po = C.c_void_p(), C.c_void_p()
+        self._check(self._L.fem_dev_acquire_stage(self._h, slot, n_reads_cap, n_bases_cap, C.byref(pb), C.byref(po)))
+        bases = np.frombuffer((C.c_char * (int(n_bases_cap) + 64)).from_address(pb.value), dtype=np.uint8)
+        offs = np.frombuffer((C.c_char * (8 * (int(n_reads_cap) + 1))).from_address(po.value), dtype=np.uint64)
+        return bases, offs
+
+    def commit_stage(self, n_reads, max_len, slot=0):
+        self._check(self._L.fem_dev_commit_stage(self._h, slot, n_reads, max_len))
+
     def map_staged(self, e=3, a=1, k=12, step=3, slot=0):
         p = Params(k, step, e, a)
         self._check(self._L.fem_dev_map_staged(self._h, slot, C.byref(p)))
@@ -222,10 +243,14 @@ class Device:
         self._check(self._L.fem_dev_fetch_stats(self._h, slot, st.ctypes.data))
         return st
 
-    def fetch(self, slot=0):
+    def fetch(self, slot=0, copy=True):
         r = _BatchResult()
         self._check(self._L.fem_dev_fetch(self._h, slot, C.byref(r)))
-        return BatchResult(r)
+        return BatchResult(r, copy)
+
+    def seed_kernel(self, e=3, a=1, k=12, step=3):
+        p = Params(k, step, e, a)
+        return self._L.fem_dev_seed_kernel(self._h, C.byref(p)).decode()
 
     def fetch_records(self, slot=0):
         """The device mapping tail: sorted records with CIGAR and MD (fem_dev_fetch_records)."""
@@ -251,6 +276,11 @@ class Device:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self._L.fem_dev_kernel_time(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, int(n.value)
+
+    def h2d_bandwidth(self, nbytes=1 << 28, iters=8):
+        g = C.c_double()
+        self._check(self._L.fem_dev_h2d_bandwidth(self._h, nbytes, iters, C.byref(g)))
+        return g.value
 
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
         g = C.c_double()

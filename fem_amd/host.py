@@ -58,6 +58,7 @@ def lib():
         L.fem_sam_header.argtypes = [C.POINTER(TailRef), C.POINTER(vp), C.POINTER(u64)]
         L.fem_synth_reference.argtypes = [u64, C.c_uint32, vp, vp, vp, C.c_int]
         L.fem_synth_reads.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
+        L.fem_synth_reads_ex.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, vp, C.c_int]
         L.fem_synth_write_fastq.argtypes = [C.c_char_p, vp, C.c_uint32, u64, u64]
         L.fem_synth_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint32]
         L.free = C.CDLL(None).free
@@ -87,12 +88,24 @@ def synth_reference(seed, seq_lens, threads=8):
     return text, off, lens
 
 
-def synth_reads(seed, text, off, lens, n_reads, L, e, first_read=0, threads=8):
-    """n_reads reads of length L drawn from the reference with 0..e edits -> (bases uint8[n*L(+8)], offsets uint64[n+1])."""
-    bases = np.zeros(n_reads * L + 8, dtype=np.uint8)
-    lib().fem_synth_reads(seed, text.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens), first_read, n_reads,
-                          L, e, bases.ctypes.data, threads)
-    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
+def synth_reads(seed, text, off, lens, n_reads, L, e, first_read=0, threads=8, out=None, out_offsets=None, n_err=None):
+    """n_reads reads of length L drawn from the reference with 0..e edits -> (bases uint8[n*L(+8)], offsets uint64[n+1]).
+    Uniform start, edit count uniform in 0..e, each edit 60 % substitution / 20 % insertion / 20 % deletion at a uniform
+    interior offset of the read, 50 % reverse-complemented.  `out` / `out_offsets`: write into these
+    arrays (e.g. the pinned staging views of Device.acquire_stage); `n_err`: uint8[n_reads] receiving the edit counts."""
+    bases = np.zeros(n_reads * L + 8, dtype=np.uint8) if out is None else out
+    assert bases.dtype == np.uint8 and len(bases) >= n_reads * L
+    ne = 0
+    if n_err is not None:
+        assert n_err.dtype == np.uint8 and len(n_err) >= n_reads
+        ne = n_err.ctypes.data
+    lib().fem_synth_reads_ex(seed, text.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens), first_read, n_reads,
+                             L, e, bases.ctypes.data, ne, threads)
+    if out_offsets is None:
+        offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
+    else:
+        offsets = out_offsets
+        offsets[:n_reads + 1] = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
     return bases, offsets
 
 

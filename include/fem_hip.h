@@ -134,9 +134,22 @@ int fem_dev_fetch_index(fem_dev *h, uint32_t *lookup_out, uint64_t *occ_out, uin
 int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fem_read_batch *reads);
 int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out);
 
-/* The same in separate phases, for callers that keep reads resident in HBM
- * (bench.py measures fem_dev_map_staged with the inputs already on the device). */
-int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads); /* host -> HBM */
+/* The same in separate phases. */
+/* Copies the caller's batch into the slot's pinned staging buffers (several host threads), checks it
+ * (offsets ascending, reads within fem_dev_limits) and starts the asynchronous copy to HBM.  Returns without
+ * waiting for the copy; the caller's buffers are free again on return. */
+int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads);
+/* Zero-copy form (north_star: "reads streamed in pinned batches"; the reusable SequenceBatch ring of
+ * src/input_queue.c:34-51): the library lends the slot's PINNED staging buffers, the FASTQ parser writes the
+ * batch straight into them, commit starts the asynchronous H2D copy and returns at once.
+ *   acquire: waits until the slot is idle, grows the buffers to n_reads_cap + 1 offsets and n_bases_cap
+ *            characters (+ 64 bytes of slack the caller may overrun), returns them; valid until the next acquire.
+ *   commit:  the batch is complete: n_reads reads, offsets[0] == 0, offsets ascending, offsets[n_reads]
+ *            characters, longest read max_len (the parser knows it; no per-read host work happens here).
+ *            A wrong max_len / offset table is the caller's bug: the kernels trust them. */
+int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, char **bases,
+                          uint64_t **offsets);
+int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_len);
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p);          /* kernels only, asynchronous */
 int fem_dev_sync(fem_dev *h, int slot);                                     /* wait; re-runs on scratch overflow */
 int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* sync + the five counters */
@@ -144,6 +157,11 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);             /* s
 /* sync + the mapping tail on the device (replaces process_mappings, src/map.c:50-54 -> src/align.c:56-92, up to
  * the point where the reference packs a bam1_t): sorted records with CIGAR and MD.  Independent of fem_dev_fetch. */
 int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
+
+/* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident
+ * index ("seed_dense_kernel", "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or "seed_filter_kernel"); the
+ * generic seed_filter_kernel always follows for whatever that one queues.  Static string. */
+const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
 
 /* ---- measurement ---- */
 /* With timing on, every kernel launch is bracketed by HIP events on the stream
@@ -159,10 +177,14 @@ int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);
 /* Achieved device-to-device copy bandwidth in GB/s over `bytes` (roofline cross-check). */
 int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s);
+/* Achieved pinned-host-to-device bandwidth in GB/s (what bounds the read stream). */
+int fem_dev_h2d_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s);
 
 /* ---- multi-GPU (replaces the thread reduction src/FEM_map.c:200-212) ---- */
 /* Sums the five MappingStats counters of n handles (one per GPU of this
- * process) with one RCCL all-reduce; stats is n x 5, reduced in place. */
+ * process) with one RCCL all-reduce; stats is n x 5, reduced in place.  The
+ * communicator is created on the first call and kept until one of its
+ * handles is closed. */
 int fem_dev_allreduce_stats(fem_dev *const *h, int n, uint64_t *stats);
 
 #ifdef __cplusplus

@@ -3,7 +3,7 @@
     python3 profiles/make_profiles.py c2        # -> profiles/r02_c2_kernel_stats.csv, profiles/r02_c2_hbm_traffic.json
 
 One `--kernel-trace --stats` run for the per-kernel durations, then one `--pmc` run per counter group (PMC runs never
-carry trace options).  Every run profiles the same command: python3 bench.py --no-cpu --workload <wl>.
+carry trace options).  Every run profiles the same command: python3 bench.py --no-cpu --no-e2e --extra none --workload <wl>.
 This script itself never touches the GPU; rocprofv3 gets the python interpreter directly after `--`.
 """
 import csv
@@ -51,8 +51,8 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "profiles_" + wl)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
-    bench = [sys.executable, "bench.py", "--no-cpu", "--workload", wl]
-    env_note = "rocprofv3 ... -- python3 bench.py --no-cpu --workload " + wl
+    bench = [sys.executable, "bench.py", "--no-cpu", "--no-e2e", "--extra", "none", "--workload", wl]
+    env_note = "rocprofv3 ... -- python3 bench.py --no-cpu --no-e2e --extra none --workload " + wl
 
     # 1. durations
     d = os.path.join(out, "trace")
@@ -62,8 +62,9 @@ def main():
     reads_per_launch = None
     if bench_line:
         b = json.loads(bench_line[-1])
-        launches = max(b["config"]["kernel_launches_per_step"].get("seed_fast_kernel", 1.0), 1.0)
-        reads_per_launch = int(b["config"]["reads_per_gpu"] / launches)
+        lps = b["config"]["kernel_launches_per_step"]
+        launches = max(lps.get("seed_dense_kernel", lps.get("seed_fast_kernel", 1.0)), 1.0)
+        reads_per_launch = int(b["config"]["reads_per_step_per_gpu"] / launches)
 
     # 2. counters, one pass per group
     kernels = {}
