@@ -7,6 +7,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <cctype>
@@ -376,7 +379,7 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
       f->in->seek_mem(len);
       return finish_seqset(none, out);
     }
-    size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
+    const size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
     if (m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
       const size_t span = hi - lo;
       int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, span / (1u << 20) + 1));
@@ -411,6 +414,223 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
   }
   int frc = finish_seqset(parts, out);
   return frc ? frc : rc;
+}
+
+// ---- the same batch in two phases: scan + size, then copy straight into the caller's buffers ----
+namespace {
+struct RangeCount {
+  uint64_t n = 0, bases = 0, names = 0;
+  uint32_t max_len = 0;
+  bool ok = true;
+};
+// One strict 4-line FASTQ record at p (blank lines in front skipped).  false: not that shape (or end of range).
+struct FqRec {
+  const char *name, *seq, *qual;
+  size_t name_len, len;
+  size_t next;
+};
+// Positions of the next (up to) four '\n' in [p, hi): one sweep of 32-byte compares instead of four memchr calls on
+// lines a few dozen bytes long (the call overhead was most of the parser's time).  Returns how many were found.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline int newlines4_avx2(const char *m, size_t p, size_t hi, size_t out[4]) {
+  int k = 0;
+  const __m256i nl = _mm256_set1_epi8('\n');
+  while (p + 32 <= hi) {
+    uint32_t mask = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(m + p)), nl));
+    while (mask) {
+      out[k++] = p + (size_t)__builtin_ctz(mask);
+      if (k == 4) return 4;
+      mask &= mask - 1;
+    }
+    p += 32;
+  }
+  for (; p < hi; ++p)
+    if (m[p] == '\n') {
+      out[k++] = p;
+      if (k == 4) return 4;
+    }
+  return k;
+}
+#endif
+inline int newlines4(const char *m, size_t p, size_t hi, size_t out[4]) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return newlines4_avx2(m, p, hi, out);
+#endif
+  int k = 0;
+  while (k < 4 && p < hi) {
+    const char *q = (const char *)memchr(m + p, '\n', hi - p);
+    if (!q) break;
+    out[k++] = (size_t)(q - m);
+    p = (size_t)(q - m) + 1;
+  }
+  return k;
+}
+inline bool next_fq(const char *m, size_t &p, size_t hi, FqRec &r, bool &bad) {
+  while (p < hi && m[p] == '\n') ++p;
+  if (p >= hi) return false;
+  if (m[p] != '@') {
+    bad = true;
+    return false;
+  }
+  size_t nl[4];
+  const int k = newlines4(m, p, hi, nl);
+  if (k < 3) return bad = true, false;
+  const char *e0 = m + nl[0], *s1 = e0 + 1, *e1 = m + nl[1], *s2 = e1 + 1, *e2 = m + nl[2], *s3 = e2 + 1;
+  if (s2 >= m + hi || *s2 != '+') return bad = true, false;
+  const char *e3 = k == 4 ? m + nl[3] : m + hi;  // last line of the file without a newline
+  size_t name_len = 0;
+  while (m + p + 1 + name_len < e0 && !isspace((unsigned char)m[p + 1 + name_len])) ++name_len;
+  size_t sl = (size_t)(e1 - s1), ql = (size_t)(e3 - s3);
+  if (sl > 1 && s1[sl - 1] == '\r') --sl;  // kseq strips a trailing CR
+  if (ql > 1 && s3[ql - 1] == '\r') --ql;
+  if (sl != ql) return bad = true, false;  // multi-line or truncated: let the exact parser decide
+  if (sl > 0 && (s1[0] == '>' || s1[0] == '@' || s1[0] == '+')) return bad = true, false;
+  r.name = m + p + 1, r.name_len = name_len, r.seq = s1, r.qual = s3, r.len = sl;
+  p = (size_t)(e3 - m) + (e3 < m + hi ? 1 : 0);
+  return true;
+}
+}  // namespace
+
+struct fem_batch_plan {
+  bool fast = false;
+  const char *m = nullptr;          // fast: file offset x is at m[x] (the file's window buffer, or its mapping)
+  std::vector<size_t> cut;          // fast: byte ranges of the threads
+  std::vector<RangeCount> count;    // fast: what each range holds
+  size_t end = 0;                   // fast: where the stream continues
+  fem_seqset held{};                // slow: the parsed batch
+  int rc = 0;                       // slow: the reader's status (reported by plan)
+};
+
+int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_batch_plan **plan_out, fem_batch_shape *shape) {
+  if (!f || !plan_out || !shape) return -1;
+  if (n_threads < 1) n_threads = 1;
+  *plan_out = nullptr;
+  memset(shape, 0, sizeof *shape);
+  fem_batch_plan *pl = new (std::nothrow) fem_batch_plan();
+  if (!pl) return -4;
+  const size_t pos0 = f->in->tell();
+  if (f->map && f->fast_ok && f->last_char == 0) {
+    // (Reading the window out of the page cache with pread by all threads, into a reusable buffer, was tried in place of
+    // faulting the mapping in: 3 GB/s on tmpfs against 18 GB/s through the mapping.)
+    const char *m = f->map;
+    const size_t len = f->map_len;
+    size_t lo = pos0;
+    while (lo < len && m[lo] != '@' && m[lo] != '>') ++lo;  // kseq skips to the first header character
+    if (lo >= len) {  // end of input: an empty batch
+      f->in->seek_mem(len);
+      pl->fast = true, pl->m = m, pl->end = len, pl->cut.assign(2, len), pl->count.assign(1, RangeCount());
+      shape->has_qual = 1;
+      *plan_out = pl;
+      return 0;
+    }
+    const size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
+    if (m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
+      const size_t span = hi - lo;
+      const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, span / (1u << 18) + 1));
+      pl->cut.assign((size_t)nt + 1, hi);
+      pl->cut[0] = lo;
+      for (int t = 1; t < nt; ++t) pl->cut[(size_t)t] = std::min(hi, next_fastq_record(m, len, lo + span * (size_t)t / (size_t)nt));
+      for (int t = 1; t <= nt; ++t) pl->cut[(size_t)t] = std::max(pl->cut[(size_t)t], pl->cut[(size_t)t - 1]);
+      pl->count.assign((size_t)nt, RangeCount());
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+      for (int t = 0; t < nt; ++t) {
+        RangeCount c;
+        size_t p = pl->cut[(size_t)t];
+        const size_t h = pl->cut[(size_t)t + 1];
+        FqRec r;
+        bool bad = false;
+        while (next_fq(m, p, h, r, bad)) {
+          if (r.len == 0) continue;  // zero-length records are skipped (src/sequence_batch.c:50-52)
+          ++c.n, c.bases += r.len, c.names += r.name_len;
+          c.max_len = std::max<uint32_t>(c.max_len, (uint32_t)std::min<size_t>(r.len, 0xFFFFFFFFu));
+        }
+        c.ok = !bad;
+        pl->count[(size_t)t] = c;
+      }
+      bool ok = true;
+      for (const RangeCount &c : pl->count) ok = ok && c.ok;
+      if (ok) {
+        for (const RangeCount &c : pl->count) {
+          shape->n_reads += c.n, shape->n_bases += c.bases, shape->n_name_bytes += c.names;
+          shape->max_len = std::max(shape->max_len, c.max_len);
+        }
+        shape->has_qual = 1;
+        pl->fast = true, pl->m = m, pl->end = hi;
+        f->in->seek_mem(hi);
+        *plan_out = pl;
+        return 0;
+      }
+    }
+    f->fast_ok = false;  // FASTA, multi-line FASTQ or malformed input: the exact sequential reader takes over
+    f->in->seek_mem(pos0);
+  }
+  pl->rc = fem_seqfile_read_bytes(f, approx_bytes, n_threads, &pl->held);
+  if (pl->rc != 0 && pl->rc != -2 && pl->rc != -3) {  // allocation failure
+    int rc = pl->rc;
+    fem_batch_plan_free(pl);
+    return rc;
+  }
+  shape->n_reads = pl->held.n;
+  shape->n_bases = pl->held.n ? pl->held.off[pl->held.n] : 0;
+  shape->n_name_bytes = pl->held.n ? pl->held.name_off[pl->held.n] : 0;
+  for (uint64_t i = 0; i < pl->held.n; ++i)
+    shape->max_len = std::max<uint32_t>(shape->max_len, (uint32_t)std::min<uint64_t>(pl->held.off[i + 1] - pl->held.off[i], 0xFFFFFFFFu));
+  shape->has_qual = pl->held.quals != nullptr || pl->held.n == 0;
+  *plan_out = pl;
+  return pl->rc;  // -2 / -3: "Didn't reach the end of sequence file"; the records read so far are still in the plan
+}
+
+int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *pl, int n_threads, char *bases, uint64_t *off, char *quals, char *names,
+                     uint64_t *name_off) {
+  if (!f || !pl || !bases || !off || !names || !name_off) return -1;
+  if (n_threads < 1) n_threads = 1;
+  if (!pl->fast) {
+    const fem_seqset &h = pl->held;
+    const uint64_t nb = h.n ? h.off[h.n] : 0, nn = h.n ? h.name_off[h.n] : 0;
+    if (nb) memcpy(bases, h.bases, nb);
+    if (quals && h.quals && nb) memcpy(quals, h.quals, nb);
+    if (nn) memcpy(names, h.names, nn);
+    for (uint64_t i = 0; i <= h.n; ++i) off[i] = h.n ? h.off[i] : 0, name_off[i] = h.n ? h.name_off[i] : 0;
+    memset(bases + nb, 0, 64);
+    fem_batch_plan_free(pl);
+    return 0;
+  }
+  const char *m = pl->m;
+  const int nt = (int)pl->count.size();
+  std::vector<uint64_t> r0((size_t)nt + 1, 0), b0((size_t)nt + 1, 0), n0((size_t)nt + 1, 0);
+  for (int t = 0; t < nt; ++t) {
+    r0[(size_t)t + 1] = r0[(size_t)t] + pl->count[(size_t)t].n;
+    b0[(size_t)t + 1] = b0[(size_t)t] + pl->count[(size_t)t].bases;
+    n0[(size_t)t + 1] = n0[(size_t)t] + pl->count[(size_t)t].names;
+  }
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+  for (int t = 0; t < nt; ++t) {
+    size_t p = pl->cut[(size_t)t];
+    const size_t h = pl->cut[(size_t)t + 1];
+    uint64_t r = r0[(size_t)t], b = b0[(size_t)t], nm = n0[(size_t)t];
+    FqRec rec;
+    bool bad = false;
+    while (next_fq(m, p, h, rec, bad)) {
+      if (rec.len == 0) continue;
+      off[r] = b, name_off[r] = nm;
+      memcpy(bases + b, rec.seq, rec.len);
+      if (quals) memcpy(quals + b, rec.qual, rec.len);
+      memcpy(names + nm, rec.name, rec.name_len);
+      ++r, b += rec.len, nm += rec.name_len;
+    }
+  }
+  off[r0[(size_t)nt]] = b0[(size_t)nt];
+  name_off[r0[(size_t)nt]] = n0[(size_t)nt];
+  memset(bases + b0[(size_t)nt], 0, 64);
+  fem_batch_plan_free(pl);
+  return 0;
+}
+
+void fem_batch_plan_free(fem_batch_plan *pl) {
+  if (!pl) return;
+  fem_seqset_free(&pl->held);
+  delete pl;
 }
 
 void fem_seqset_free(fem_seqset *s) {
@@ -785,8 +1005,13 @@ struct TextBuf {
   char *p = nullptr;
   size_t n = 0, cap = 0;
   bool failed = false;
+  bool fixed = false;  // a stretch of somebody else's buffer, sized from an upper bound: never reallocated
   bool room(size_t extra) {
     if (n + extra <= cap) return true;
+    if (fixed) {
+      failed = true;
+      return false;
+    }
     const size_t want = std::max(cap + cap / 2, n + extra + (size_t)(1u << 20));
     char *q = (char *)realloc(p, want);
     if (!q) {
@@ -1064,6 +1289,78 @@ int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_
     }
   }
   return join_parts(parts, n_threads, text, text_len);
+}
+
+int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rv, int n_threads,
+                          char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted) {
+  if (!ref || !reads || !rv || !buf || !cap || !parts) return -1;
+  if (rv->n_reads > reads->n) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const uint64_t n = rv->n_reads;
+  const uint64_t total = n ? rv->rec_begin[n] : 0;
+  size_t max_rname = 0;
+  for (uint32_t i = 0; i < ref->n_seq; ++i) max_rname = std::max(max_rname, (size_t)(ref->name_off[i + 1] - ref->name_off[i]));
+  std::vector<uint64_t> lo((size_t)n_threads + 1, n), need((size_t)n_threads + 1, 0);
+  for (int k = 0; k <= n_threads; ++k) {  // contiguous read ranges holding about the same number of records
+    if (k == 0) lo[0] = 0;
+    else if (k < n_threads)
+      lo[(size_t)k] = (uint64_t)(std::lower_bound(rv->rec_begin, rv->rec_begin + n, (uint32_t)(total * (uint64_t)k / (uint64_t)n_threads)) - rv->rec_begin);
+  }
+  uint64_t asserted = 0;
+  bool failed = false;
+#pragma omp parallel num_threads(n_threads) reduction(+ : asserted)
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    // an upper bound of this thread's text (what append_sam_line asks room for, record by record)
+    for (int k = t; k < n_threads; k += nt) {
+      uint64_t b = 0;
+      for (uint64_t r = lo[(size_t)k]; r < lo[(size_t)k + 1]; ++r) {
+        const uint32_t rb = rv->rec_begin[r], re = rv->rec_begin[r + 1];
+        if (rb == re) continue;
+        const uint64_t name_len = reads->name_off[r + 1] - reads->name_off[r], len = reads->off[r + 1] - reads->off[r];
+        b += (uint64_t)(re - rb) * (name_len + max_rname + 2 * len + 96) + 11ull * (rv->cigar_off[re] - rv->cigar_off[rb]) + (rv->md_off[re] - rv->md_off[rb]);
+      }
+      need[(size_t)k + 1] = b;
+    }
+#pragma omp barrier
+#pragma omp single
+    {
+      for (int k = 0; k < n_threads; ++k) need[(size_t)k + 1] += need[(size_t)k];
+      if (need[(size_t)n_threads] + 1 > *cap) {
+        const uint64_t want = need[(size_t)n_threads] + need[(size_t)n_threads] / 8 + (1u << 20);
+        char *q = (char *)realloc(*buf, want);
+        if (q) *buf = q, *cap = want;
+        else failed = true;
+      }
+    }  // (implicit barrier)
+    if (!failed) {
+      for (int k = t; k < n_threads; k += nt) {
+        TextBuf o;
+        o.p = *buf + need[(size_t)k], o.n = 0, o.cap = (size_t)(need[(size_t)k + 1] - need[(size_t)k]);
+        o.fixed = true;
+        for (uint64_t r = lo[(size_t)k]; r < lo[(size_t)k + 1]; ++r) {
+          const uint32_t b = rv->rec_begin[r], e_ = rv->rec_begin[r + 1];
+          if (b == e_) continue;  // unmapped reads produce no record (src/map.c:50)
+          const char *fwd = reads->bases + reads->off[r];
+          const uint32_t len = (uint32_t)(reads->off[r + 1] - reads->off[r]);
+          const char *qual = reads->quals ? reads->quals + reads->off[r] : nullptr;
+          const char *name = reads->names + reads->name_off[r];
+          const size_t name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
+          for (uint32_t j = b; j < e_; ++j) {
+            Record rec;
+            rec.flag = rv->flag[j], rec.tid = rv->tid[j], rec.pos0 = rv->pos0[j], rec.nm = rv->nm[j];
+            if (rec.flag & 0x8000u) ++asserted, rec.flag &= 0x7FFFu;
+            append_sam_line(o, *ref, name, name_len, rec, rv->cigar + rv->cigar_off[j], rv->cigar_off[j + 1] - rv->cigar_off[j],
+                            rv->md + rv->md_off[j], rv->md_off[j + 1] - rv->md_off[j], j == b, fwd, len, qual);
+          }
+        }
+        parts[k].offset = need[(size_t)k], parts[k].length = o.n;
+      }
+    }
+  }
+  if (failed) return -4;
+  if (n_asserted) *n_asserted = asserted;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,6 +44,24 @@ int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out);
 int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_seqset *out);
 void fem_seqset_free(fem_seqset *s);
 
+/* The same batch in two phases, so that the fields land where the caller wants them without an intermediate copy
+ * (FEM map points `bases` / `off` at the device library's PINNED staging buffers, include/fem_hip.h
+ * fem_dev_acquire_stage; the reference's reader fills a reusable SequenceBatch, src/input_queue.c:53-79).
+ *   plan: delimits whole records covering about approx_bytes (0 = the rest) and sizes the batch: plain 4-line FASTQ
+ *         is only scanned (all threads); anything else is parsed by the sequential kseq-rule reader and held.
+ *   fill: copies characters, offsets (off[0] = 0), qualities, names into the caller's buffers (all threads) and frees
+ *         the plan.  quals may be NULL.  bases needs n_bases + 64 bytes (64 zero bytes follow the last read). */
+typedef struct fem_batch_plan fem_batch_plan;
+typedef struct {
+  uint64_t n_reads, n_bases, n_name_bytes;
+  uint32_t max_len;
+  int32_t has_qual; /* every record carried qualities */
+} fem_batch_shape;
+int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_batch_plan **plan, fem_batch_shape *shape);
+int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *plan, int n_threads, char *bases, uint64_t *off, char *quals,
+                     char *names, uint64_t *name_off);
+void fem_batch_plan_free(fem_batch_plan *plan);
+
 /* ---------------- index files (src/index.c:100-168) ---------------- */
 /* int32 k | int32 step | uint32 lookup[4^k+1] | size_t n | uint64 occ[n] */
 int fem_index_save(const char *path, int32_t k, int32_t step, const uint32_t *lookup, uint64_t n_occ, const uint64_t *occ);
@@ -111,6 +129,16 @@ typedef struct {
 } fem_record_view;
 int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rec, int n_threads,
                     char **text, uint64_t *text_len);
+/* The same text without the concatenation: thread t formats its share of the reads into its own stretch of *buf (a
+ * caller-owned buffer, reused from batch to batch and grown here with realloc when too small), parts[t] = {offset,
+ * length} of that stretch (n_threads entries; the text is the parts in order).  *n_asserted counts records on which
+ * the reference would have tripped an assertion (src/align.c:366-368): written with their 0x8000 marker bit cleared
+ * from FLAG and CIGAR `*`. */
+typedef struct {
+  uint64_t offset, length;
+} fem_text_part;
+int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rec, int n_threads,
+                          char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted);
 /* "@SQ\tSN:%s\tLN:%d\n" per sequence (src/output_queue.c:104-108). *text is malloc'd. */
 int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len);
 

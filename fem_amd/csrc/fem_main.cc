@@ -2,12 +2,18 @@
 // src/FEM_map.c).  Same verbs, flags, index file format and SAM output; the per-read hot path runs on the GPU
 // through libfemhip.so (include/fem_hip.h).  There is no CPU mapping path in this binary: without a GPU it fails.
 //
-// New, optional: `--gpus N` (map) shards read batches over N GPUs of this node; `--batch N` sets reads per batch.
+// New, optional: `--gpus N` (map) spreads read batches over N GPUs of this node (whichever GPU has a free slot takes the
+// next batch; record order in the SAM file follows completion, parity is modulo record order); `--batch N` sets reads
+// per batch.
+#include <errno.h>
+#include <fcntl.h>
 #include <getopt.h>
+#include <unistd.h>
 #include <malloc.h>
 #include <sys/resource.h>
 #include <sys/time.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -145,36 +151,87 @@ int index_main(int argc, char **argv) {
 }
 
 // ---------------------------------------------------------------- FEM map (src/FEM_map.c:57-227)
-struct Batch {
-  uint64_t id = 0;
-  fem_seqset reads{};
-  bool last = false;
-};
-
+//
+// The reference runs 1 reader + T mapping threads + 1 writer over two queues (src/FEM_map.c:172-198,
+// src/input_queue.c, src/output_queue.c).  Here the T mapping threads are the GPUs:
+//
+//   reader     parses the next FASTQ window (all -t threads) STRAIGHT INTO the pinned staging buffers of a free
+//              (GPU, slot) pair — whichever GPU has one free, so the GPUs balance by themselves
+//   worker[g]  one thread per GPU, the only one that talks to that GPU's handle: starts H2D + kernels of a filled
+//              slot (asynchronous), keeps two batches in flight, then fetches the finished batch's records
+//              (sort + traceback + CIGAR/MD run on the device, fem_dev_fetch_records)
+//   formatter  renders the records as SAM text (all -t threads) into a reusable buffer
+//   writer     writes the text
+// A slot goes  free -> filled -> in flight -> fetched -> formatted -> free  and there are four per GPU.
 template <typename T>
-class Channel {  // bounded hand-off between pipeline stages
+class Channel {  // unbounded hand-off between pipeline stages (the number of slots bounds what is in flight)
  public:
-  explicit Channel(size_t cap) : cap_(cap) {}
   void push(T v) {
-    std::unique_lock<std::mutex> l(m_);
-    not_full_.wait(l, [&] { return q_.size() < cap_; });
-    q_.push_back(std::move(v));
-    not_empty_.notify_one();
+    {
+      std::lock_guard<std::mutex> l(m_);
+      q_.push_back(std::move(v));
+    }
+    cv_.notify_one();
   }
   T pop() {
     std::unique_lock<std::mutex> l(m_);
-    not_empty_.wait(l, [&] { return !q_.empty(); });
+    cv_.wait(l, [&] { return !q_.empty(); });
     T v = std::move(q_.front());
     q_.pop_front();
-    not_full_.notify_one();
     return v;
+  }
+  bool try_pop(T &v) {
+    std::lock_guard<std::mutex> l(m_);
+    if (q_.empty()) return false;
+    v = std::move(q_.front());
+    q_.pop_front();
+    return true;
   }
 
  private:
   std::mutex m_;
-  std::condition_variable not_empty_, not_full_;
+  std::condition_variable cv_;
   std::deque<T> q_;
-  size_t cap_;
+};
+
+struct Growable {  // a reusable host array: only ever grows
+  char *p = nullptr;
+  uint64_t cap = 0;
+  bool reserve(uint64_t n) {
+    if (n <= cap) return true;
+    const uint64_t want = n + n / 8 + 4096;
+    char *q = (char *)realloc(p, want);
+    if (!q) return false;
+    p = q, cap = want;
+    return true;
+  }
+  ~Growable() { free(p); }
+};
+
+struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pair
+  int gpu = 0, slot = 0;
+  char *bases = nullptr;      // pinned staging lent by the device library (fem_dev_acquire_stage)
+  uint64_t *off = nullptr;
+  uint64_t reads_cap = 0, bases_cap = 0;
+  Growable quals, names, name_off;  // read names and qualities never go to the GPU
+  fem_batch_shape shape{};
+  uint64_t want_reads = 0, want_bases = 0;  // set by the reader when the staging buffers are too small
+  fem_batch_records rec{};                  // device tail's records (default path)
+  fem_batch_result res{};                   // per-candidate outcome (FEM_HOST_TAIL=1)
+  double t_submit = 0;
+};
+
+struct TextOut {  // one batch of SAM text: parts[i] of buf, in order
+  char *buf = nullptr;
+  uint64_t cap = 0;
+  std::vector<fem_text_part> parts;
+  bool owned_elsewhere = false;  // buf was malloc'd by fem_tail_sam: free it after writing
+};
+
+enum MsgKind { kFilled, kRecycle, kRegrow, kStop };
+struct Msg {
+  MsgKind kind = kStop;
+  BatchBuf *b = nullptr;
 };
 
 int map_main(int argc, char **argv) {
@@ -249,181 +306,297 @@ int map_main(int argc, char **argv) {
   }
 
   std::vector<fem_dev *> devs((size_t)n_gpus, nullptr);
-  for (int g = 0; g < n_gpus; ++g) {
-    int rc = fem_dev_open(g, &devs[(size_t)g]);
-    if (rc) return dev_fail(nullptr, "fem_dev_open (mapping runs on the GPU; no CPU path)", rc);
-    if ((rc = ref.upload(devs[(size_t)g]))) return dev_fail(devs[(size_t)g], "reference upload", rc);
-    if ((rc = fem_dev_upload_index(devs[(size_t)g], ik, istep, lookup, ((uint64_t)1 << (2 * ik)) + 1, occ, n_occ)))
-      return dev_fail(devs[(size_t)g], "index upload", rc);
+  // FEM_TEST_SHARE_GPU=1 (test hook for one-GPU boxes): all `--gpus N` workers open GPU 0, each with its own handle, and
+  // the counters are summed on the host (RCCL refuses two ranks on one device)
+  const char *sg = getenv("FEM_TEST_SHARE_GPU");
+  const bool share_gpu = sg && sg[0] == '1';
+  {  // one thread per GPU uploads the replicated reference + index (src/FEM_map.c:135-143)
+    std::vector<int> up_rc((size_t)n_gpus, 0);
+    std::vector<std::thread> up;
+    for (int g = 0; g < n_gpus; ++g)
+      up.emplace_back([&, g] {
+        int rc = fem_dev_open(share_gpu ? 0 : g, &devs[(size_t)g]);
+        if (!rc) rc = ref.upload(devs[(size_t)g]);
+        if (!rc) rc = fem_dev_upload_index(devs[(size_t)g], ik, istep, lookup, ((uint64_t)1 << (2 * ik)) + 1, occ, n_occ);
+        up_rc[(size_t)g] = rc;
+      });
+    for (auto &t : up) t.join();
+    for (int g = 0; g < n_gpus; ++g)
+      if (up_rc[(size_t)g]) return dev_fail(devs[(size_t)g], "device setup (mapping runs on the GPU; no CPU path)", up_rc[(size_t)g]);
   }
   free(lookup), free(occ);
 
-  FILE *out = fopen(out_path, "w");
-  if (!out) {
+  const int out_fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (out_fd < 0) {
     fprintf(stderr, "Cannot open output file %s\n", out_path);
     exit(EXIT_FAILURE);
   }
+  std::atomic<int> exit_code{0};
+  // The SAM text of a batch is a handful of stretches (one per formatter thread), written one after the other.  (Side
+  // by side with pwrite from four threads was tried: 2.8 GB/s on tmpfs against 5.5 GB/s from one thread.)
+  auto write_all = [&](const char *p, uint64_t n) -> bool {
+    while (n) {
+      ssize_t w = write(out_fd, p, n);
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) return false;
+      p += w, n -= (uint64_t)w;
+    }
+    return true;
+  };
   {
     char *hdr = nullptr;
     uint64_t hl = 0;
     fem_sam_header(&ref.view, &hdr, &hl);
-    fwrite(hdr, 1, hl, out);
+    if (!write_all(hdr, hl)) {
+      fprintf(stderr, "[FEM] write error on %s\n", out_path);
+      exit_code = EXIT_FAILURE;
+    }
     free(hdr);
   }
 
   double t_start = real_time();
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
-  // stage 4: one writer thread drains formatted SAM text (src/output_queue.c:60-91)
-  struct Text {
-    char *p;
-    uint64_t n;
-  };
-  Channel<Text> to_write(4);
-  // FEM_STAGE_TIMES=1: busy seconds of each pipeline stage on stderr at the end (reader, device wait, SAM text, writer)
+  int32_t n_slots = 4;
+  (void)fem_dev_limits(devs[0], nullptr, &n_slots);
+  // FEM_STAGE_TIMES=1: busy seconds of each pipeline stage on stderr at the end
   const char *st_env = getenv("FEM_STAGE_TIMES");
   const bool stage_times = st_env && st_env[0] == '1';
-  double busy_read = 0, busy_wait = 0, busy_text = 0, busy_write = 0;
-  std::thread writer([&] {
-    for (;;) {
-      Text t = to_write.pop();
-      if (!t.p) break;
-      double t0 = real_time();
-      fwrite(t.p, 1, t.n, out);
-      free(t.p);
-      busy_write += real_time() - t0;
-    }
-  });
-  // stage 1: one reader thread parses FASTQ into batches (src/input_queue.c:53-79)
-  Channel<Batch *> parsed(4);
-  std::thread reader([&] {
-    fem_seqfile *f = fem_seqfile_open(read_path);
-    uint64_t id = 0;
-    bool ok = f != nullptr;
-    if (!ok) fprintf(stderr, "Cannot find sequence file!");
-    for (;;) {
-      Batch *b = new Batch();
-      b->id = id++;
-      // batches are cut by bytes (~ batch_reads records of this file's shape); plain FASTQ is parsed by all threads
-      double t0 = real_time();
-      int rc = ok ? fem_seqfile_read_bytes(f, batch_bytes, n_threads, &b->reads) : -1;
-      busy_read += real_time() - t0;
-      if (rc != 0 && ok) fprintf(stderr, "Didn't reach the end of sequence file, which might be corrupted!");
-      if (rc != 0 || b->reads.n == 0) {
-        b->last = true;
-        parsed.push(b);
-        break;
-      }
-      parsed.push(b);
-    }
-    if (f) fem_seqfile_close(f);
-  });
-
-  // stage 2 (this thread): device submit / wait, batches dealt round-robin to GPUs, two slots per GPU;
-  // stage 3: mapping tail + SAM text of the previous batch overlaps the kernels of the next one.
-  struct InFlight {
-    Batch *b;
-    int gpu, slot;
-  };
-  std::deque<InFlight> flight;
-  uint64_t totals[5] = {0, 0, 0, 0, 0};
-  std::vector<uint64_t> per_gpu((size_t)n_gpus * 5, 0);
-  int exit_code = 0;
   const char *ht = getenv("FEM_HOST_TAIL");
   const bool host_tail = ht && ht[0] == '1';
-  auto retire = [&](InFlight f) {
-    double t0 = real_time();
-    uint64_t stats[5] = {0, 0, 0, 0, 0};
-    char *text = nullptr;
-    uint64_t len = 0;
-    int rc, fmt = 0;
-    if (host_tail) {  // FEM_HOST_TAIL=1: ordering / traceback / MD by libfemhost from the per-candidate outcome
-      fem_batch_result res;
-      rc = fem_dev_map_batch_wait(devs[(size_t)f.gpu], f.slot, &res);
-      if (!rc) {
-        fem_tail_input in{res.n_reads, res.cand_begin, res.cand_count, res.cand, res.ed, res.end};
-        fmt = fem_tail_sam(params.e, &ref.view, &f.b->reads, &in, n_threads, &text, &len);
-        memcpy(stats, res.stats, sizeof stats);
+  double busy_read = 0, busy_text = 0, busy_write = 0;
+  double t_first_slot = 0, t_first_filled = 0, t_reader_done = 0, t_workers_done = 0;
+  std::vector<double> busy_wait((size_t)n_gpus, 0.0);
+  std::atomic<uint64_t> n_asserted{0};
+
+  std::vector<BatchBuf> bufs((size_t)n_gpus * (size_t)n_slots);
+  Channel<BatchBuf *> free_q, text_q, regrown_q;
+  std::vector<Channel<Msg>> work_q((size_t)n_gpus);
+  Channel<TextOut *> text_free_q, write_q;
+  std::vector<TextOut> texts(3);
+  for (TextOut &t : texts) text_free_q.push(&t);
+  std::vector<uint64_t> per_gpu((size_t)n_gpus * 5, 0);
+
+  // ---- writer (src/output_queue.c:60-91) ----
+  std::thread writer([&] {
+    for (;;) {
+      TextOut *t = write_q.pop();
+      if (!t) break;
+      double t0 = real_time();
+      bool ok = true;
+      for (const fem_text_part &p : t->parts)
+        if (ok && p.length) ok = write_all(t->buf + p.offset, p.length);
+      if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
+      if (t->owned_elsewhere) {
+        free(t->buf);
+        t->buf = nullptr, t->cap = 0, t->owned_elsewhere = false;
       }
-    } else {  // default: the records come off the device, the host only renders text
-      fem_batch_records rec;
-      rc = fem_dev_fetch_records(devs[(size_t)f.gpu], f.slot, &rec);
-      busy_wait += real_time() - t0;
-      if (!rc) {
-        double t1 = real_time();
+      busy_write += real_time() - t0;
+      text_free_q.push(t);
+    }
+  });
+
+  // ---- formatter: records -> SAM text (src/align.c:546-632, src/output_queue.c:93-116) ----
+  std::thread formatter([&] {
+    for (;;) {
+      BatchBuf *b = text_q.pop();
+      if (!b) break;
+      double t0 = real_time();
+      TextOut *t = text_free_q.pop();
+      fem_seqset reads{};
+      reads.n = b->shape.n_reads, reads.bases = b->bases, reads.off = b->off, reads.quals = b->quals.p, reads.names = b->names.p;
+      reads.name_off = (uint64_t *)b->name_off.p;
+      int fmt;
+      if (host_tail) {  // FEM_HOST_TAIL=1: ordering / traceback / MD by libfemhost from the per-candidate outcome
+        fem_tail_input in{b->res.n_reads, b->res.cand_begin, b->res.cand_count, b->res.cand, b->res.ed, b->res.end};
+        char *text = nullptr;
+        uint64_t len = 0;
+        fmt = fem_tail_sam(params.e, &ref.view, &reads, &in, n_threads, &text, &len);
+        if (!fmt) {
+          free(t->buf);
+          t->buf = text, t->cap = len, t->owned_elsewhere = true;
+          t->parts.assign(1, fem_text_part{0, len});
+        }
+      } else {  // default: the records come off the device, the host only renders text
+        const fem_batch_records &rec = b->rec;
         fem_record_view rv{rec.n_reads, rec.n_records, rec.rec_begin, rec.flag, rec.tid, rec.pos0, rec.nm,
                            rec.cigar_off, rec.cigar, rec.md_off, rec.md};
-        fmt = fem_records_sam(&ref.view, &f.b->reads, &rv, n_threads, &text, &len);
-        busy_text += real_time() - t1;
-        memcpy(stats, rec.stats, sizeof stats);
+        t->parts.assign((size_t)n_threads, fem_text_part{0, 0});
+        uint64_t na = 0;
+        fmt = fem_records_sam_parts(&ref.view, &reads, &rv, n_threads, &t->buf, &t->cap, t->parts.data(), &na);
+        n_asserted += na;
       }
-    }
-    if (rc) {
-      exit_code = dev_fail(devs[(size_t)f.gpu], "mapping", rc);
-    } else {
+      busy_text += real_time() - t0;
       if (fmt != 0) {
-        fprintf(stderr, "[FEM] out of memory while formatting SAM records\n");
-        exit_code = EXIT_FAILURE;
-      } else {
-        to_write.push(Text{text, len});
+        if (!exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] out of memory while formatting SAM records\n");
+        t->parts.clear();
       }
-      for (int i = 0; i < 5; ++i) per_gpu[(size_t)f.gpu * 5 + (size_t)i] += stats[i];
-      fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - t0);
+      write_q.push(t);
+      fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - b->t_submit);
+      work_q[(size_t)b->gpu].push(Msg{kRecycle, b});  // the slot is free again once its GPU's thread has re-acquired it
     }
-    fem_seqset_free(&f.b->reads);
-    delete f.b;
-  };
-  uint64_t n_submitted = 0;
-  for (;;) {
-    Batch *b = parsed.pop();
-    if (b->last || exit_code) {
-      fem_seqset_free(&b->reads);
-      bool was_last = b->last;
-      delete b;
-      if (was_last) break;
-      continue;
-    }
-    if (!b->reads.quals) {
-      fprintf(stderr, "Reads without qualities (FASTA) are not supported: the SAM records need QUAL.\n");
+  });
+
+  // ---- one worker per GPU (the mapping threads of src/FEM_map.c:182-185) ----
+  std::vector<std::thread> workers;
+  for (int g = 0; g < n_gpus; ++g)
+    workers.emplace_back([&, g] {
+      fem_dev *h = devs[(size_t)g];
+      auto acquire = [&](BatchBuf *b, uint64_t reads_cap, uint64_t bases_cap) -> bool {
+        char *pb = nullptr;
+        uint64_t *po = nullptr;
+        int rc = fem_dev_acquire_stage(h, b->slot, reads_cap, bases_cap, &pb, &po);
+        if (rc) {
+          if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "staging buffers", rc);
+          return false;
+        }
+        b->bases = pb, b->off = po, b->reads_cap = reads_cap, b->bases_cap = bases_cap;
+        return true;
+      };
+      for (int s = 0; s < n_slots; ++s) {
+        BatchBuf *b = &bufs[(size_t)g * (size_t)n_slots + (size_t)s];
+        b->gpu = g, b->slot = s;
+        // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are
+        // unusual (the reader asks for larger buffers when a batch needs them)
+        if (acquire(b, batch_bytes / 32 + 16, batch_bytes / 2 + 4096)) free_q.push(b);
+      }
+      std::deque<BatchBuf *> flight;
+      auto retire = [&] {
+        BatchBuf *b = flight.front();
+        flight.pop_front();
+        double t0 = real_time();
+        int rc = host_tail ? fem_dev_map_batch_wait(h, b->slot, &b->res) : fem_dev_fetch_records(h, b->slot, &b->rec);
+        busy_wait[(size_t)g] += real_time() - t0;
+        if (rc) {
+          if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "mapping", rc);
+          work_q[(size_t)g].push(Msg{kRecycle, b});
+          return;
+        }
+        const uint64_t *st = host_tail ? b->res.stats : b->rec.stats;
+        for (int i = 0; i < 5; ++i) per_gpu[(size_t)g * 5 + (size_t)i] += st[i];
+        text_q.push(b);
+      };
+      for (;;) {
+        Msg m;
+        if (flight.empty()) {
+          m = work_q[(size_t)g].pop();
+        } else if (!work_q[(size_t)g].try_pop(m)) {
+          retire();  // nothing new to start: finish the oldest batch in flight
+          continue;
+        }
+        if (m.kind == kStop) break;
+        if (m.kind == kRecycle) {
+          if (acquire(m.b, m.b->reads_cap, m.b->bases_cap)) free_q.push(m.b);
+          continue;
+        }
+        if (m.kind == kRegrow) {
+          if (!acquire(m.b, m.b->want_reads, m.b->want_bases)) m.b->bases = nullptr;
+          regrown_q.push(m.b);
+          continue;
+        }
+        BatchBuf *b = m.b;  // kFilled
+        b->t_submit = real_time();
+        int rc = exit_code ? FEM_ERR_STATE : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
+        if (!rc) rc = fem_dev_map_staged(h, b->slot, &params);
+        if (rc) {
+          if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "batch submit", rc);
+          work_q[(size_t)g].push(Msg{kRecycle, b});
+          continue;
+        }
+        flight.push_back(b);
+        while (flight.size() > 2) retire();  // two batches in flight per GPU
+      }
+      while (!flight.empty()) retire();
+    });
+
+  // ---- reader (src/input_queue.c:53-79): this thread ----
+  {
+    fem_seqfile *f = fem_seqfile_open(read_path);
+    if (!f) {
+      fprintf(stderr, "Cannot find sequence file!");  // the reference exits here (src/sequence_batch.c:33-35)
       exit_code = EXIT_FAILURE;
-      fem_seqset_free(&b->reads);
-      delete b;
-      continue;
     }
-    int gpu = (int)(n_submitted % (uint64_t)n_gpus), slot = (int)((n_submitted / (uint64_t)n_gpus) % 2);
-    while (flight.size() >= (size_t)n_gpus * 2 ||
-           (!flight.empty() && flight.front().gpu == gpu && flight.front().slot == slot)) {
-      retire(flight.front());
-      flight.pop_front();
+    while (f && !exit_code) {
+      BatchBuf *b = free_q.pop();
+      double t0 = real_time();
+      if (t_first_slot == 0) t_first_slot = t0;
+      fem_batch_plan *plan = nullptr;
+      int rc = fem_seqfile_plan(f, batch_bytes, n_threads, &plan, &b->shape);
+      bool ok = plan != nullptr;
+      if (rc != 0) {  // the reference exits on a truncated file (src/sequence_batch.c:63-66): nothing of this batch is mapped
+        fprintf(stderr, "Didn't reach the end of sequence file, which might be corrupted!");
+        exit_code = EXIT_FAILURE;
+        ok = false;
+      }
+      if (ok && b->shape.n_reads > 0 && !b->shape.has_qual) {
+        fprintf(stderr, "Reads without qualities (FASTA) are not supported: the SAM records need QUAL.\n");
+        exit_code = EXIT_FAILURE;
+        ok = false;
+      }
+      if (ok && b->shape.n_reads > 0 && (b->shape.n_reads > b->reads_cap || b->shape.n_bases + 64 > b->bases_cap)) {
+        b->want_reads = b->shape.n_reads + b->shape.n_reads / 8, b->want_bases = b->shape.n_bases + b->shape.n_bases / 8 + 4096;
+        work_q[(size_t)b->gpu].push(Msg{kRegrow, b});
+        BatchBuf *back = regrown_q.pop();  // (one request at a time: it is ours)
+        ok = back->bases != nullptr;
+      }
+      if (ok && b->shape.n_reads > 0) {
+        ok = b->quals.reserve(b->shape.n_bases + 1) && b->names.reserve(b->shape.n_name_bytes + 1) &&
+             b->name_off.reserve((b->shape.n_reads + 1) * sizeof(uint64_t));
+        if (!ok) {
+          fprintf(stderr, "[FEM] out of memory while reading\n");
+          exit_code = EXIT_FAILURE;
+        }
+      }
+      if (!ok || b->shape.n_reads == 0) {
+        fem_batch_plan_free(plan);
+        busy_read += real_time() - t0;
+        break;  // end of input (or failure)
+      }
+      rc = fem_seqfile_fill(f, plan, n_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
+      busy_read += real_time() - t0;
+      if (rc) {
+        fprintf(stderr, "[FEM] reading failed\n");
+        exit_code = EXIT_FAILURE;
+        break;
+      }
+      if (t_first_filled == 0) t_first_filled = real_time();
+      work_q[(size_t)b->gpu].push(Msg{kFilled, b});
     }
-    fem_read_batch rb{b->reads.bases, b->reads.off, b->reads.n};
-    int rc = fem_dev_map_batch_submit(devs[(size_t)gpu], slot, &params, &rb);
-    if (rc) {
-      exit_code = dev_fail(devs[(size_t)gpu], "batch submit", rc);
-      fem_seqset_free(&b->reads);
-      delete b;
-      continue;
-    }
-    flight.push_back({b, gpu, slot});
-    ++n_submitted;
+    if (f) fem_seqfile_close(f);
+    t_reader_done = real_time();
   }
-  while (!flight.empty()) {
-    retire(flight.front());
-    flight.pop_front();
-  }
-  reader.join();
-  to_write.push(Text{nullptr, 0});
+  for (int g = 0; g < n_gpus; ++g) work_q[(size_t)g].push(Msg{kStop, nullptr});
+  for (auto &w : workers) w.join();
+  t_workers_done = real_time();
+  text_q.push(nullptr);
+  formatter.join();
+  write_q.push(nullptr);
   writer.join();
-  if (stage_times)
-    fprintf(stderr, "[FEM] stage busy seconds: reader %.3f, device wait %.3f, SAM text %.3f, writer %.3f\n", busy_read,
-            busy_wait, busy_text, busy_write);
-  fclose(out);
+  if (stage_times) {
+    double bw = 0;
+    for (double x : busy_wait) bw += x;
+    fprintf(stderr, "[FEM] stage busy seconds: reader %.3f, device wait %.3f, SAM text %.3f, writer %.3f\n", busy_read, bw,
+            busy_text, busy_write);
+    fprintf(stderr, "[FEM] timeline (s after the mapping phase began): first staging slot %.3f, first batch parsed %.3f, input read %.3f, "
+                    "devices done %.3f, output written %.3f\n", t_first_slot - t_start, t_first_filled - t_start, t_reader_done - t_start,
+            t_workers_done - t_start, real_time() - t_start);
+  }
+  if (close(out_fd) != 0 && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
+  for (TextOut &t : texts) free(t.buf);
+  if (n_asserted)
+    fprintf(stderr, "[FEM] %lu records on which the reference would have tripped an assertion (src/align.c:366-368) were "
+                    "written with CIGAR *\n", (unsigned long)n_asserted.load());
 
   // MappingStats reduction (src/FEM_map.c:200-212): across GPUs it is one RCCL all-reduce of 5 counters
-  if (n_gpus > 1) {
+  if (n_gpus > 1 && !exit_code && !share_gpu) {
     int rc = fem_dev_allreduce_stats(devs.data(), n_gpus, per_gpu.data());
     if (rc) exit_code = dev_fail(devs[0], "stats all-reduce", rc);
+  } else if (n_gpus > 1) {
+    for (int g = 1; g < n_gpus; ++g)
+      for (int i = 0; i < 5; ++i) per_gpu[(size_t)i] += per_gpu[(size_t)g * 5 + (size_t)i];
   }
+  uint64_t totals[5];
   for (int i = 0; i < 5; ++i) totals[i] = per_gpu[(size_t)i];
+  const double t_mapping = real_time() - t_start;  // (the reference's timer stops after the counter reduction, src/FEM_map.c:219)
   for (fem_dev *h : devs) fem_dev_close(h);
   if (exit_code) return exit_code;
   fprintf(stderr, "The number of read: %lu\n", (unsigned long)totals[0]);
@@ -431,7 +604,7 @@ int map_main(int argc, char **argv) {
   fprintf(stderr, "The number of candidate before additional q-gram filter: %lu\n", (unsigned long)totals[2]);
   fprintf(stderr, "The number of candidate: %lu\n", (unsigned long)totals[3]);
   fprintf(stderr, "The number of mapping: %lu\n", (unsigned long)totals[4]);
-  fprintf(stderr, "Time: %fs\n", real_time() - t_start);
+  fprintf(stderr, "Time: %fs\n", t_mapping);
   return 0;
 }
 

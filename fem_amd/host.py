@@ -29,6 +29,21 @@ class Records(C.Structure):
                 ("md_off", C.c_void_p), ("md", C.c_void_p)]
 
 
+class BatchShape(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_name_bytes", C.c_uint64), ("max_len", C.c_uint32),
+                ("has_qual", C.c_int32)]
+
+
+class RecordView(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_records", C.c_uint64), ("rec_begin", C.c_void_p), ("flag", C.c_void_p),
+                ("tid", C.c_void_p), ("pos0", C.c_void_p), ("nm", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar", C.c_void_p), ("md_off", C.c_void_p), ("md", C.c_void_p)]
+
+
+class TextPart(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint64)]
+
+
 def library_path():
     return os.path.join(_HERE, "csrc", "libfemhost.so")
 
@@ -47,6 +62,13 @@ def lib():
         L.fem_seqfile_read.argtypes = [vp, u64, C.POINTER(SeqSet)]
         L.fem_seqset_free.argtypes = [C.POINTER(SeqSet)]
         L.fem_seqfile_read_bytes.argtypes = [vp, u64, C.c_int, C.POINTER(SeqSet)]
+        L.fem_seqfile_plan.argtypes = [vp, u64, C.c_int, C.POINTER(vp), C.POINTER(BatchShape)]
+        L.fem_seqfile_fill.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.fem_batch_plan_free.argtypes = [vp]
+        L.fem_records_sam.argtypes = [C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(RecordView), C.c_int, C.POINTER(vp),
+                                      C.POINTER(u64)]
+        L.fem_records_sam_parts.argtypes = [C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(RecordView), C.c_int,
+                                            C.POINTER(vp), C.POINTER(u64), C.POINTER(TextPart), C.POINTER(u64)]
         L.fem_index_save.argtypes = [C.c_char_p, i32, i32, vp, u64, vp]
         L.fem_index_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(u64),
                                      C.POINTER(vp)]
@@ -185,6 +207,61 @@ def read_sequences_in_chunks(path, approx_bytes, threads=4):
     return out
 
 
+class PlannedBatch:
+    """One batch read in two phases (fem_seqfile_plan + fem_seqfile_fill) into caller-owned arrays."""
+
+    def __init__(self, shape, bases, off, quals, names, name_off):
+        self.n = int(shape.n_reads)
+        self.max_len = int(shape.max_len)
+        self.bases, self.off, self.quals, self.names_raw, self.name_off = bases, off, quals, names, name_off
+
+    def seq(self, i):
+        return self.bases[int(self.off[i]):int(self.off[i + 1])].tobytes()
+
+    def qual(self, i):
+        return self.quals[int(self.off[i]):int(self.off[i + 1])].tobytes()
+
+    def name(self, i):
+        return self.names_raw[int(self.name_off[i]):int(self.name_off[i + 1])].tobytes().decode()
+
+
+def read_planned_batches(path, approx_bytes, threads=4, alloc=None):
+    """All records of a file through the two-phase reader the command line uses; `alloc(n_reads, n_bases)` may hand
+    out the (bases uint8[n_bases + 64], off uint64[n_reads + 1]) arrays (e.g. pinned staging views)."""
+    L = lib()
+    f = L.fem_seqfile_open(path.encode())
+    if not f:
+        raise FileNotFoundError(path)
+    out = []
+    try:
+        while True:
+            plan, shape = C.c_void_p(), BatchShape()
+            rc = L.fem_seqfile_plan(f, approx_bytes, threads, C.byref(plan), C.byref(shape))
+            if rc != 0:
+                if plan:
+                    L.fem_batch_plan_free(plan)
+                raise ValueError("malformed sequence file %s (rc=%d)" % (path, rc))
+            if shape.n_reads == 0:
+                L.fem_batch_plan_free(plan)
+                break
+            n, nb = int(shape.n_reads), int(shape.n_bases)
+            if alloc:
+                bases, off = alloc(n, nb)
+            else:
+                bases, off = np.zeros(nb + 64, np.uint8), np.zeros(n + 1, np.uint64)
+            quals = np.zeros(nb + 1, np.uint8) if shape.has_qual else None
+            names = np.zeros(int(shape.n_name_bytes) + 1, np.uint8)
+            name_off = np.zeros(n + 1, np.uint64)
+            rc = L.fem_seqfile_fill(f, plan, threads, bases.ctypes.data, off.ctypes.data,
+                                    quals.ctypes.data if quals is not None else None, names.ctypes.data, name_off.ctypes.data)
+            if rc != 0:
+                raise ValueError("fem_seqfile_fill failed (%d)" % rc)
+            out.append(PlannedBatch(shape, bases, off, quals, names, name_off))
+    finally:
+        L.fem_seqfile_close(f)
+    return out
+
+
 def index_save(path, k, step, lookup, occ):
     lookup = np.ascontiguousarray(lookup, np.uint32)
     occ = np.ascontiguousarray(occ, np.uint64)
@@ -257,6 +334,44 @@ def tail_records(e, ref, read_bases, read_off, cand_begin, cand_count, cand, ed,
         return RecordArrays(r, n_reads)
     finally:
         lib().fem_records_free(C.byref(r))
+
+
+def records_sam(ref, names, read_bases, read_off, quals, rec, threads=1, parts=False):
+    """SAM text for records already computed (fem_records_sam, or the no-copy fem_records_sam_parts form).  `rec` has
+    rec_off/rec_begin, flag, tid, pos0, nm, cigar_off, cigar, md_off, md (RecordArrays or fem_amd.device.BatchRecords)."""
+    n_reads = len(read_off) - 1
+    bases = np.ascontiguousarray(read_bases, np.uint8)
+    off = np.ascontiguousarray(read_off, np.uint64)
+    q = np.ascontiguousarray(quals, np.uint8)
+    raw = [n.encode() for n in names]
+    name_off = np.zeros(n_reads + 1, np.uint64)
+    name_off[1:] = np.cumsum([len(r) for r in raw])
+    nm = np.frombuffer(b"".join(raw) + b"\0", np.uint8).copy()
+    s = SeqSet(n_reads, bases.ctypes.data, off.ctypes.data, q.ctypes.data, nm.ctypes.data, name_off.ctypes.data)
+    rb = np.ascontiguousarray(getattr(rec, "rec_begin", getattr(rec, "rec_off", None)), np.uint32)
+    arrs = [rb, np.ascontiguousarray(rec.flag, np.uint16), np.ascontiguousarray(rec.tid, np.uint32),
+            np.ascontiguousarray(rec.pos0, np.uint32), np.ascontiguousarray(rec.nm, np.uint8),
+            np.ascontiguousarray(rec.cigar_off, np.uint32), np.ascontiguousarray(rec.cigar, np.uint32),
+            np.ascontiguousarray(rec.md_off, np.uint32), np.ascontiguousarray(rec.md, np.uint8)]
+    rv = RecordView(n_reads, len(arrs[1]), *[a.ctypes.data for a in arrs])
+    L = lib()
+    if not parts:
+        p, n = C.c_void_p(), C.c_uint64()
+        rc = L.fem_records_sam(C.byref(ref.c), C.byref(s), C.byref(rv), threads, C.byref(p), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("fem_records_sam failed (%d)" % rc)
+        text = _copy(p.value, n.value, np.uint8).tobytes().decode()
+        L.free(p)
+        return text
+    buf, cap, na = C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+    pt = (TextPart * threads)()
+    rc = L.fem_records_sam_parts(C.byref(ref.c), C.byref(s), C.byref(rv), threads, C.byref(buf), C.byref(cap), pt, C.byref(na))
+    if rc != 0:
+        raise RuntimeError("fem_records_sam_parts failed (%d)" % rc)
+    whole = _copy(buf.value, cap.value, np.uint8)
+    text = b"".join(whole[int(x.offset):int(x.offset + x.length)].tobytes() for x in pt).decode()
+    L.free(buf)
+    return text, int(na.value)
 
 
 def sam_header(ref):

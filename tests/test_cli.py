@@ -92,3 +92,69 @@ def test_index_and_map_end_to_end(tmp_path, e, L, gz, batch):
                          "The number of candidate before additional q-gram filter", "The number of candidate",
                          "The number of mapping"], want.stats):
         assert "%s: %d\n" % (label, int(v)) in err  # src/FEM_map.c:214-218
+
+
+@pytest.mark.gpu
+def test_map_fails_loudly_on_missing_or_truncated_reads(tmp_path):
+    # the reference exits with EXIT_FAILURE in both cases (src/sequence_batch.c:33-35, 63-66): no statistics, no "Time:"
+    seqs, names, reads, rnames, quals, fa, fq = write_case(tmp_path, 5, 3, 100, 300, False)
+    index_path = str(tmp_path / "ref.idx")
+    assert run("index", "12", "3", fa, index_path).returncode == 0
+    r = run("map", "-e", "3", "-t", "2", "--ref", fa, "--index", index_path, "--read1", str(tmp_path / "nope.fq"), "-o",
+            str(tmp_path / "a.sam"))
+    assert r.returncode != 0 and b"Cannot find sequence file!" in r.stderr and b"Time:" not in r.stderr
+    data = open(fq, "rb").read()
+    cut = tmp_path / "cut.fq"
+    cut.write_bytes(data[:len(data) - 37])  # ends inside a quality line
+    r = run("map", "-e", "3", "-t", "2", "--ref", fa, "--index", index_path, "--read1", str(cut), "-o", str(tmp_path / "b.sam"),
+            "--batch", "50")
+    assert r.returncode != 0 and b"Didn't reach the end of sequence file" in r.stderr and b"Time:" not in r.stderr
+    r = run("map", "-e", "3", "-t", "2", "--ref", fa, "--index", index_path, "--read1", fq, "-o", "/nonexistent_dir/x.sam")
+    assert r.returncode != 0 and b"Cannot open output file" in r.stderr
+    r = run("map", "-e", "3", "-t", "2", "--ref", fa, "--index", index_path, "--read1", fq, "-o", "/dev/full")
+    assert r.returncode != 0 and b"write error" in r.stderr
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()  # (does not initialise the GPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [True, False])
+def test_map_on_several_gpus_gives_the_same_records_and_counters(tmp_path, shared):
+    # src/FEM_map.c:200-212: the mapping threads' counters are summed at the end; here one RCCL all-reduce over the GPUs.
+    # shared: three workers with a handle each on GPU 0 (FEM_TEST_SHARE_GPU=1) — the `--gpus N` pipeline (one thread per
+    # handle, batches dealt to whichever has a free slot) on a one-GPU box; not shared: two real GPUs + RCCL
+    if not shared and _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    seqs, names, reads, rnames, quals, fa, fq = write_case(tmp_path, 21, 3, 100, 900, False)
+    index_path = str(tmp_path / "ref.idx")
+    assert run("index", "12", "3", fa, index_path).returncode == 0
+    outs = []
+    for gpus in ("1", "3" if shared else "2"):
+        sam = str(tmp_path / ("g%s.sam" % gpus))
+        r = run("map", "-e", "3", "-t", "4", "--gpus", gpus, "--ref", fa, "--index", index_path, "--read1", fq, "-o", sam,
+                "--batch", "120", env={"FEM_TEST_SHARE_GPU": "1"} if shared else None)
+        assert r.returncode == 0, r.stderr.decode()
+        counters = [l for l in r.stderr.decode().splitlines() if l.startswith("The number of")]
+        outs.append((sorted(open(sam).read().splitlines()), counters))
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_allreduce_stats_over_two_handles():
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    import ctypes as C
+    from fem_amd import Device
+    from fem_amd.device import load_hip
+    a, b = Device(0), Device(1)
+    L = load_hip()
+    hs = (C.c_void_p * 2)(a._h, b._h)
+    for rep in range(2):  # the second call reuses the communicator
+        st = np.array([[1, 2, 3, 4, 5], [10, 20, 30, 40, 2 ** 40 + rep]], dtype=np.uint64)
+        assert L.fem_dev_allreduce_stats(hs, 2, st.ctypes.data) == 0
+        assert np.array_equal(st[0], st[1]) and st[0].tolist() == [11, 22, 33, 44, 2 ** 40 + rep + 5]
+    a.close()
+    b.close()

@@ -142,6 +142,79 @@ def test_parallel_fastq_reader_equals_sequential_reader(tmp_path):
     assert b"".join(p.bases.tobytes() for p in parts) == whole.bases.tobytes()
 
 
+def test_two_phase_reader_equals_sequential_reader(tmp_path):
+    # fem_seqfile_plan + fem_seqfile_fill (what `FEM map` uses to parse straight into the device library's pinned staging
+    # buffers) against the kseq-rule sequential reader: plain FASTQ (scanned twice, never copied in between), CRLF,
+    # '@' / '+' leading quality lines, blank lines, zero-length records, multi-line and gzip (held by the plan)
+    rng = np.random.default_rng(12)
+    n, L = 20_000, 100
+    recs = []
+    for i in range(n):
+        ln = L if i % 5 else int(rng.integers(1, 3 * L))
+        seq = util.rand_seq(rng, ln)
+        qual = bytes(rng.integers(33, 74, size=ln).astype(np.uint8))
+        recs.append(b"@q%d some comment\n" % i + seq + (b"\r\n" if i % 13 == 0 else b"\n") + b"+\n" + qual + (b"\n\n" if i % 17 == 0 else b"\n"))
+    recs.insert(3, b"@empty\n\n+\n\n")
+    fq = tmp_path / "two_phase.fq"
+    fq.write_bytes(b"".join(recs)[:-1])  # no newline at the end of the file
+    whole = host.read_sequences(str(fq))
+    assert whole.n == n
+    for approx, threads in ((0, 4), (300_000, 3), (1 << 20, 8), (64, 2)):
+        if approx == 64 and n > 5000:
+            continue
+        parts = host.read_planned_batches(str(fq), approx, threads=threads)
+        assert sum(p.n for p in parts) == n
+        assert b"".join(p.bases[:int(p.off[p.n])].tobytes() for p in parts) == whole.bases.tobytes()
+        assert b"".join(p.quals[:int(p.off[p.n])].tobytes() for p in parts) == whole.quals.tobytes()
+        assert b"".join(p.names_raw[:int(p.name_off[p.n])].tobytes() for p in parts) == whole.names_raw.tobytes()
+        assert all(int(p.off[0]) == 0 and p.max_len == int(np.diff(p.off.astype(np.int64)).max()) for p in parts)
+        assert all(not p.bases[int(p.off[p.n]):int(p.off[p.n]) + 64].any() for p in parts), "64 zero bytes behind the last read"
+    ml = tmp_path / "ml.fq"
+    ml.write_bytes(b"@a\nACGT\nACG\n+\nIIII\nIII\n@b x\nTTTT\n+\nJJJJ\n")
+    parts = host.read_planned_batches(str(ml), 8, threads=3)
+    assert [p.seq(i) for p in parts for i in range(p.n)] == [b"ACGTACG", b"TTTT"]
+    assert [p.name(i) for p in parts for i in range(p.n)] == ["a", "b"]
+    gzp = tmp_path / "two_phase.fq.gz"
+    with gzip.open(str(gzp), "wb", compresslevel=1) as f:
+        f.write(fq.read_bytes())
+    parts = host.read_planned_batches(str(gzp), 1 << 20, threads=4)
+    assert b"".join(p.bases[:int(p.off[p.n])].tobytes() for p in parts) == whole.bases.tobytes()
+    assert host.read_planned_batches(str(tmp_path / "two_phase.fq"), 0, threads=1)[0].n == n
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    assert host.read_planned_batches(str(empty), 0) == []
+    bad = tmp_path / "bad2.fq"
+    bad.write_bytes(b"@r0\nACGT\n+\nII\n")
+    with pytest.raises(ValueError):
+        host.read_planned_batches(str(bad), 0)
+
+
+def test_records_sam_parts_equals_the_concatenated_text():
+    e = 3
+    seqs, reads, ref, batch, res = oracle_case(9, e, n_reads=300)
+    names = ["read_%d" % i for i in range(len(reads))]
+    quals = ["".join(chr(33 + (i * 5 + j) % 41) for j in range(len(r))) for i, r in enumerate(reads)]
+    tref = host.TailReference(ref.text, ref.off, ref.len, names=["chrA", "a_much_longer_sequence_name", "c"])
+    q = np.frombuffer("".join(quals).encode(), np.uint8)
+    begin, count, cand, ed, end = as_device_layout(res)
+    want = host.tail_sam(e, tref, names, batch.bases, batch.off, q, begin, count, cand, ed, end, threads=2)
+
+    class Rec:
+        pass
+    rec = Rec()
+    rec.rec_begin, rec.flag, rec.tid, rec.pos0, rec.nm = res.rec_off, res.r_flag.copy(), res.r_tid, res.r_pos, res.r_nm
+    rec.cigar_off, rec.cigar, rec.md_off, rec.md = res.cig_off, res.cig, res.md_off, res.md
+    assert host.records_sam(tref, names, batch.bases, batch.off, q, rec, threads=3) == want
+    for threads in (1, 2, 7):
+        text, asserted = host.records_sam(tref, names, batch.bases, batch.off, q, rec, threads=threads, parts=True)
+        assert text == want and asserted == 0
+    # a record carrying the "reference would have asserted" marker (0x8000): the bit never reaches the FLAG column
+    j = int(res.rec_off[np.flatnonzero(np.diff(res.rec_off.astype(np.int64)))[0]])
+    rec.flag[j] |= 0x8000
+    text, asserted = host.records_sam(tref, names, batch.bases, batch.off, q, rec, threads=2, parts=True)
+    assert asserted == 1 and text == want
+
+
 def test_index_file_is_byte_compatible(tmp_path):
     rng = np.random.default_rng(2)
     ref = fo.Reference([util.rand_seq(rng, 30_000), util.rand_seq(rng, 999)])
