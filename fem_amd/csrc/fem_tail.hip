@@ -50,7 +50,7 @@ struct Params {
   uint64_t *s_cand;
   uint32_t *s_misc, *s_read;
   uint32_t *queue;  // reads with three or more hits
-  uint32_t *ctl;    // [0] queue length, [1] records of the overflow pass, [2] staging too small even there
+  uint32_t *ctl;    // [0] queue length, [1] records of the overflow pass, [2] staging too small even there, [3] length of rec_list
   uint64_t *g_keys;  // ordering scratch for reads with more hits than fit LDS (n_records each)
   uint32_t *g_idx;
   // traceback
@@ -61,6 +61,7 @@ struct Params {
   uint32_t ops_cap, md_cap;
   const uint32_t *ovf_queue;  // overflow pass: the records to redo, staged at index * cap
   uint32_t *ovf_out;          // first pass: where overflowing records are queued
+  uint32_t *rec_list;         // records trace_ident_kernel left to the walking kernels (ctl[3] of them); nullptr = all
   uint32_t *src_slot;         // per record: 0 = first-pass staging, else 1 + index in the overflow staging
   uint32_t *n_ops, *n_md;
   uint16_t *flag;
@@ -534,17 +535,132 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Traceback, first pass: the form nearly every record takes.  Same walk as trace_record, but the lane keeps one
-// packed word per column in LDS — the band bits (0 .. 2e) of D0 and HP and, in the same positions, whether the
-// reference character on that diagonal EQUALS the read character (the traceback and the MD tag compare characters,
-// not codes, src/align.c:355,523) — and reads the sequences straight from HBM, sixteen columns per load.
+// packed word per column in LDS — per diagonal of the band (0 .. 2e) two bits that say what the walk would do in
+// that cell: they fold D0, HP and whether the reference character on that diagonal EQUALS the read character (the
+// traceback and the MD tag compare characters, not codes, src/align.c:355,523) — and reads the sequences straight
+// from HBM, sixteen columns per load.
 // Character equality is derived from the code-equality mask Peq: for characters of the canonical alphabet
 // "ACGTN" it is the same thing, a reference character outside it (lower case, IUPAC) equals no canonical one, and
 // a read with such characters is left to the general kernel.  So is every walk that leaves the band, and every
 // record whose CIGAR or MD outgrows the staging; the general kernel (trace_kernel) redoes those from scratch.
 // ---------------------------------------------------------------------------------------------------------
-// The packed column word (3 x (2e+1) bits) is kept in as few LDS bytes as hold it — LDS per block is what limits the
+// The packed column word (2 x (2e+1) bits) is kept in as few LDS bytes as hold it — LDS per block is what limits the
 // waves per CU here, and the walk is a chain of dependent LDS reads that only more waves can hide: a low plane of
 // P0 words and, where needed, a high plane of P1 words; column c of lane l sits at [c * lanes + l] of each.
+// ---------------------------------------------------------------------------------------------------------
+// Traceback, pass zero: records with edit distance 0.  generate_alignment first compares the read with the reference
+// at its end position character by character (src/align.c:285-300) and, with no mismatch, emits `L M` without any
+// recurrence.  A zero-edit record (a quarter to a third of the records of the BASELINE workloads) almost always is
+// such a match — unless a reference character is lower case / IUPAC or the read has a non-canonical character, which
+// Myers (on codes) takes for equal and the character comparison does not.  One lane per record, no LDS: read
+// characters sixteen at a time (decoded to code-bit masks), the reference from its bit planes, compared on the one
+// diagonal.  Every other record (ed > 0, or a zero-edit record that is no character-exact match) is appended to
+// rec_list for the walking kernels.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lsb_mask4(uint32_t bytes01) {  // bytes of 0/1 -> their four bits, byte 0 in bit 0
+  return ((bytes01 & 0x01010101u) * 0x01020408u) >> 24;
+}
+constexpr uint32_t kIdentChunk = 1024;  // records one block classifies at a time (four per thread)
+__global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
+  __shared__ uint32_t lst[kIdentChunk], walk[kIdentChunk];
+  __shared__ uint32_t cnt, n_walk, walk_base;
+  const int sh = 2 * p.e;
+  // Records for the walking kernels gather in LDS and go out with ONE atomic on the list's cursor per chunk (one per
+  // wave cost 1.3 ms per 8.6 M records: same-address atomics complete at ~10 ns each).
+  auto flush_walk = [&]() {
+    __syncthreads();
+    if (threadIdx.x == 0) walk_base = n_walk ? atomicAdd(&p.ctl[3], n_walk) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_walk; i += 256u) p.rec_list[walk_base + i] = walk[i];
+    __syncthreads();
+    if (threadIdx.x == 0) n_walk = 0;
+    __syncthreads();
+  };
+  for (uint32_t base = blockIdx.x * kIdentChunk; base < p.n_records; base += gridDim.x * kIdentChunk) {
+    __syncthreads();
+    if (threadIdx.x == 0) cnt = 0, n_walk = 0;
+    __syncthreads();
+    // ---- classify: zero-edit records into the block's list (so that the comparison below runs on full waves),
+    //      the others into the walking kernels' list ----
+#pragma unroll
+    for (uint32_t k = 0; k < kIdentChunk / 256u; ++k) {
+      const uint32_t rec = base + k * 256u + threadIdx.x;
+      if (rec < p.n_records) {
+        if (((p.s_misc[rec] >> 16) & 0xFFu) == 0u) lst[atomicAdd(&cnt, 1u)] = rec;
+        else walk[atomicAdd(&n_walk, 1u)] = rec;
+      }
+    }
+    flush_walk();
+    const uint32_t n_zero = cnt;
+    for (uint32_t i0 = 0; i0 < n_zero; i0 += 256u) {
+      const uint32_t i = i0 + threadIdx.x;
+      const bool active = i < n_zero;
+      const uint32_t rec = active ? lst[i] : 0u;
+      bool done = false;
+      if (active) {
+        const uint32_t misc = p.s_misc[rec];
+        const uint32_t read = p.s_read[rec];
+        const uint64_t cand = p.s_cand[rec];
+        const int end = (int16_t)(misc & 0xFFFFu);
+        const uint32_t dir = (misc >> 24) & 1u;
+        const uint64_t off = p.read_off[read];
+        const int L = (int)(p.read_off[read + 1] - off);
+        const uint8_t *fwd = p.bases + off;
+        const uint32_t tid = (uint32_t)(cand >> 32);
+        const int start = end - L + 1;
+        const uint32_t digits = L >= 1000 ? 4u : L >= 100 ? 3u : L >= 10 ? 2u : 1u;
+        if (start >= 0 && start <= sh && L >= 1 && L < 10000 && p.ops_cap >= 1u && digits <= p.md_cap) {
+          const uint64_t ref0 = p.seq_off[tid] + (uint32_t)cand + (uint32_t)start;  // compared with text[0]
+          const uint32_t complement = dir ? 0x03030303u : 0u;
+          const uint32_t bit0 = (uint32_t)ref0 & 7u;
+          uint32_t diff = 0, odd_text = 0;
+          uint4 W0{}, W1{}, W2{}, W3{};
+          for (int col = 0; col < L; col += 16) {
+            const int sub = (col >> 4) % 7;  // 7 (bit offset) + 16 * 7 <= 128: one load per plane covers seven steps
+            if (sub == 0) {
+              const uint64_t at = (ref0 + (uint32_t)col) >> 3;
+              W0 = load_u128_unaligned(p.plane[0] + at), W1 = load_u128_unaligned(p.plane[1] + at);
+              W2 = load_u128_unaligned(p.plane[2] + at), W3 = load_u128_unaligned(p.plane[3] + at);
+            }
+            const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
+            const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
+                                   dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
+            const int ncol = L - col < 16 ? L - col : 16;
+            uint32_t m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t cw, nw, odd;
+              decode4(w[k], complement, cw, nw, odd);
+              const int nb = ncol - 4 * k;
+              odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
+              m0 |= lsb_mask4(cw) << (4 * k), m1 |= lsb_mask4(cw >> 1) << (4 * k), m2 |= lsb_mask4(nw) << (4 * k);
+            }
+            const uint32_t wbit = bit0 + 16u * (uint32_t)sub;  // (ref0 + 112 k) & 7 == ref0 & 7
+            const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);
+            diff |= ((bits_at(W0, wbit) ^ m0) | (bits_at(W1, wbit) ^ m1) | (bits_at(W2, wbit) ^ m2) | bits_at(W3, wbit)) & colmask;
+          }
+          if (diff == 0u && !(dir == 0 && odd_text)) {
+            const uint32_t rank = rec - p.rec_begin[read];
+            p.t_ops[(size_t)rec * p.ops_cap] = ((uint32_t)L << 4);  // L M
+            uint8_t *md = p.t_md + (size_t)rec * p.md_cap;
+            uint32_t v = (uint32_t)L;
+            for (uint32_t k = digits; k-- > 0; v /= 10u) md[k] = (uint8_t)('0' + v % 10u);
+            p.flag[rec] = (uint16_t)((dir ? 16u : 0u) | (rank ? 256u : 0u));
+            p.tid[rec] = tid;
+            p.pos0[rec] = (uint32_t)start + (uint32_t)cand;
+            p.nm[rec] = 0;
+            p.n_ops[rec] = 1u, p.n_md[rec] = digits;
+            p.src_slot[rec] = 0u;
+            done = true;
+          }
+        }
+      }
+      if (active && !done) walk[atomicAdd(&n_walk, 1u)] = rec;  // (at most n_zero <= kIdentChunk of them)
+    }
+    flush_walk();
+  }
+}
+
 struct NoPlane {};
 template <typename P0, typename P1>
 struct ColumnHistory {
@@ -576,9 +692,10 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
   uint16_t *ops = (uint16_t *)((uint8_t *)lds + (((size_t)p.max_len * nl * (sizeof(P0) + (ColumnHistory<P0, P1>::kTwo ? sizeof(P1) : 0)) + 3u) & ~(size_t)3u));
   const int e = p.e, sh = 2 * e, W = 2 * e + 1;
   const uint32_t band = (1u << W) - 1u;
-  for (uint32_t base = blockIdx.x * nl; base < p.n_records; base += gridDim.x * nl) {
-    const uint32_t rec = base + ln;
-    if (ln >= nl || rec >= p.n_records) continue;
+  const uint32_t n_list = p.rec_list ? p.ctl[3] : p.n_records;
+  for (uint32_t base = blockIdx.x * nl; base < n_list; base += gridDim.x * nl) {
+    if (ln >= nl || base + ln >= n_list) continue;
+    const uint32_t rec = p.rec_list ? p.rec_list[base + ln] : base + ln;
     const uint32_t read = p.s_read[rec], misc = p.s_misc[rec];
     const uint64_t cand = p.s_cand[rec];
     const int end = (int16_t)(misc & 0xFFFFu), ed = (int)((misc >> 16) & 0xFFu);
@@ -591,6 +708,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
     const uint8_t *pattern = p.ref_raw + pat_abs;
     int start = end - L + 1;
     bool punt = start < 0 || start > sh;  // (never: end lies in [L-1, L-1+2e])
+    uint32_t odd_ref = 0;  // some reference character of the window is none of "ACGTN"
 
     // ---- the recurrence (src/align.c:303-338), one packed word per column ----
     // Sixteen columns per step.  Reference side: bit planes of the base codes plus the "none of ACGTN" plane; one
@@ -621,7 +739,10 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       vp = hn | ~(x | hp);
       const uint32_t same = eq & ~__builtin_amdgcn_ubfe(bw, q, (uint32_t)W);  // the characters themselves are equal
       ident &= same >> start;
-      hist.put(col + q, (HistT)(d0 & band) | ((HistT)(hp & band) << W) | ((HistT)same << (2 * W)));
+      // What the walk asks of a cell is one of four things: match (D0 and equal characters), mismatch (not D0),
+      // insertion (D0, unequal, HP), deletion (D0, unequal, not HP) — two bits per diagonal, as planes
+      // P = match | deletion and Q = match | insertion (so: D0 = P | Q, equal characters = P & Q, HP where it matters = Q).
+      hist.put(col + q, (HistT)(d0 & (same | ~hp) & band) | ((HistT)(d0 & (same | hp) & band) << W));
     };
     for (int step = 0; step < n_steps; ++step) {
       const int col = step << 4, sub = step % kStepsPerPlaneLoad;
@@ -636,6 +757,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       if (step + 1 < n_steps) rw = text_chunk(col + 16);
       const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat_abs + 96 k) & 7 == pat_abs & 7
       const uint32_t b0 = bits_at(W0, wbit), b1 = bits_at(W1, wbit), b2 = bits_at(W2, wbit), bw = bits_at(W3, wbit);
+      odd_ref |= bw;
       const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
                              dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
       const int ncol = L - col < 16 ? L - col : 16;
@@ -690,6 +812,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       push_md('0' + v % 10u);
     };
     bool broken = false;
+    uint32_t lead = 0;  // leading read bases the walk never visited: exact matches when no odd reference character is near
     if (!punt && (ident & 1u)) {  // src/align.c:294-300
       push_op(kOpM, (uint32_t)L);
       push_number((uint32_t)L);
@@ -699,7 +822,8 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       uint32_t cur_op = kOpS, cur_n = 1;
       {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
         const HistT h = hist.get((uint32_t)t) >> bit;
-        const bool d = (uint32_t)h & 1u, same = (uint32_t)(h >> (2 * W)) & 1u, horiz = (uint32_t)(h >> W) & 1u;
+        const bool pp = (uint32_t)h & 1u, qq = (uint32_t)(h >> W) & 1u;
+        const bool d = pp || qq, same = pp && qq, horiz = qq;
         if (d && same) --t, cur_op = kOpM;
         else if (!d) --t, ++n_err;
         else if (horiz) --t, ++bit, ++n_err, ++start;
@@ -715,7 +839,8 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
           break;
         }
         const HistT h = hist.get((uint32_t)t) >> bit;
-        const bool d = (uint32_t)h & 1u, same = (uint32_t)(h >> (2 * W)) & 1u, horiz = (uint32_t)(h >> W) & 1u;
+        const bool pp = (uint32_t)h & 1u, qq = (uint32_t)(h >> W) & 1u;
+        const bool d = pp || qq, same = pp && qq, horiz = qq;
         const bool is_match = d && same, is_ins = d && !same && horiz, is_del = d && !same && !horiz;  // else: mismatch
         const uint32_t op = is_del ? kOpD : is_ins ? kOpI : kOpM;
         const bool absorbed = cur_op == kOpS && !is_match && !is_del;  // read-end errors pile up in the pseudo-run
@@ -733,6 +858,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
         }
       }
       if (!broken && !punt) {
+        if (t >= 0 && n_err == ed && odd_ref == 0u) lead = (uint32_t)(t + 1);
         if (t >= 0) {
           if (cur_op == kOpM || cur_op == kOpS)
             cur_op = kOpM, cur_n += (uint32_t)(t + 1);
@@ -753,8 +879,16 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
               punt = true;
               break;
             }
-            for (uint32_t i = 0; i < n; ++i, ++rp, ++tp) {
-              if ((uint32_t)(hist.get(tp) >> (2 * W + diag)) & 1u) {
+            uint32_t i = 0;
+            if (tp == 0 && lead) {
+              // The walk stopped with all ed edits found: the alignment's cost is ed, so these bases match on codes;
+              // with only canonical characters around, on characters too (the history is not read for them).
+              i = lead < n ? lead : n;
+              run += i, rp += (int)i, tp += i;
+            }
+            for (; i < n; ++i, ++rp, ++tp) {
+              const HistT hd = hist.get(tp) >> diag;
+              if ((uint32_t)hd & (uint32_t)(hd >> W) & 1u) {  // equal characters = P & Q
                 ++run;
               } else {
                 if (run) push_number(run), run = 0;
@@ -862,12 +996,12 @@ struct PinBuf {
 }  // namespace
 
 struct Tail::Impl {
-  DevBuf rec_begin, queue, ctl, u_cand, u_misc, s_cand, s_misc, s_read, t_ops, t_md, o_ops, o_md, ovf, src_slot, n_ops, n_md,
+  DevBuf rec_begin, queue, ctl, u_cand, u_misc, s_cand, s_misc, s_read, t_ops, t_md, o_ops, o_md, ovf, rec_list, src_slot, n_ops, n_md,
       flag, tid, pos0, nm, cigar_off, md_off, cigar, md, scan_tmp;
   PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   ~Impl() {
-    for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf,
+    for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf, &rec_list,
                       &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp})
       b->release();
     for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md})
@@ -910,8 +1044,8 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     return FEM_ERR_UNSUPPORTED;
   }
   const uint32_t lds_bytes = lanes * words_per_lane * 4u;
-  // first-pass kernel: one packed word per column (three fields of 2e+1 bits) + the run list
-  const uint32_t hist_bytes = (3u * (2u * (uint32_t)in.e + 1u) + 7u) / 8u;  // 1, 2, 2, 3, 4, 5, 5, 6 for e = 0..7
+  // first-pass kernel: one packed word per column (two fields of 2e+1 bits) + the run list
+  const uint32_t hist_bytes = (2u * (2u * (uint32_t)in.e + 1u) + 7u) / 8u;  // 1, 1, 2, 2, 3, 3, 4, 4 for e = 0..7
   const uint32_t fast_ops = std::min<uint32_t>(kOpsCap, 2u * (uint32_t)in.e + 2u);  // a sane walk opens <= 2 ed + 1 runs
   const uint32_t fast_per_lane = max_len * hist_bytes + fast_ops * 2u;
   const uint32_t fast_lanes = std::min<uint32_t>(64, (64u * 1024u - 4u) / fast_per_lane);
@@ -933,6 +1067,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   TAIL_TRY(m.t_ops.need(r1 * ops_cap * 4));
   TAIL_TRY(m.t_md.need(r1 * std::max<uint32_t>(md_cap, 12)));  // doubles as the ordering scratch (8 + 4 bytes per hit)
   TAIL_TRY(m.ovf.need(r1 * 4));
+  TAIL_TRY(m.rec_list.need(r1 * 4));
   TAIL_TRY(m.src_slot.need(r1 * 4));
   TAIL_TRY(m.n_ops.need(r1 * 4));
   TAIL_TRY(m.n_md.need(r1 * 4));
@@ -967,6 +1102,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   p.lanes = lanes, p.text_words = text_words, p.pat_words = pat_words, p.max_len = max_len, p.fast_lanes = fast_lanes, p.fast_ops = fast_ops;
   p.t_ops = m.t_ops.as<uint32_t>(), p.t_md = m.t_md.as<uint8_t>(), p.ops_cap = ops_cap, p.md_cap = md_cap;
   p.ovf_queue = nullptr, p.ovf_out = m.ovf.as<uint32_t>(), p.src_slot = m.src_slot.as<uint32_t>();
+  p.rec_list = m.rec_list.as<uint32_t>();
   p.n_ops = m.n_ops.as<uint32_t>(), p.n_md = m.n_md.as<uint32_t>();
   p.flag = m.flag.as<uint16_t>(), p.tid = m.tid.as<uint32_t>(), p.pos0 = m.pos0.as<uint32_t>(), p.nm = m.nm.as<uint8_t>();
 
@@ -985,6 +1121,9 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     hipLaunchKernelGGL(sort_kernel, dim3((uint32_t)n_cu * 4u), dim3(64), 0, stream, p);
     TAIL_TRY(hipGetLastError());
     TAIL_TRY(hipEventRecord(m.ev[1], stream));
+    // zero-edit records first (no recurrence); what they leave goes through the walking kernel
+    hipLaunchKernelGGL(trace_ident_kernel, dim3(std::min<uint32_t>((nr + kIdentChunk - 1u) / kIdentChunk, (uint32_t)n_cu * 8u)), dim3(256), 0, stream, p);
+    TAIL_TRY(hipGetLastError());
     const uint32_t blocks = std::min<uint32_t>((nr + fast_lanes - 1) / fast_lanes, (uint32_t)n_cu * 32u);
     switch (hist_bytes) {
       case 1: hipLaunchKernelGGL((trace_fast_kernel<uint8_t, NoPlane>), dim3(blocks), dim3(64), fast_lds, stream, p); break;
@@ -998,7 +1137,8 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
     TAIL_TRY(hipStreamSynchronize(stream));
     n_overflow = h_ctl[1];
-    if (getenv("FEM_TAIL_DEBUG")) fprintf(stderr, "[tail] records %u, queued for ordering %u, overflow pass %u, lanes %u/%u\n", nr, h_ctl[0], n_overflow, fast_lanes, lanes);
+    if (getenv("FEM_TAIL_DEBUG"))
+      fprintf(stderr, "[tail] records %u, queued for ordering %u, walked %u, overflow pass %u, lanes %u/%u\n", nr, h_ctl[0], h_ctl[3], n_overflow, fast_lanes, lanes);
     if (n_overflow) {  // records whose CIGAR or MD outgrew the first staging: once more, with room for any walk
       TAIL_TRY(m.o_ops.need((size_t)n_overflow * o_ops_cap * 4));
       TAIL_TRY(m.o_md.need((size_t)n_overflow * o_md_cap));
