@@ -277,14 +277,15 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         wave_sync_lds();
         // ---- flag: own slot hit twice, or a neighbouring slot present; compact the flagged values ----
         uint32_t w0[R], w1[R], xw0 = 0, xw1 = 0;
+        uint32_t *wp[R], *xwp = bitmap;  // the windows' words: read here, cleared below
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          const uint32_t *w = window_word(val[t]);  // (sentinel lanes read some word too: masked below)
-          w0[t] = w[0], w1[t] = w[1];
+          wp[t] = window_word(val[t]);  // (sentinel lanes read some word too: masked below)
+          w0[t] = wp[t][0], w1[t] = wp[t][1];
         }
         if (n_ovf) {
-          const uint32_t *w = window_word(xval);
-          xw0 = w[0], xw1 = w[1];
+          xwp = window_word(xval);
+          xw0 = xwp[0], xw1 = xwp[1];
         }
         auto flag_chunk = [&](uint32_t v, uint32_t a0, uint32_t a1, uint64_t real) {
           const uint32_t x = __builtin_amdgcn_alignbit(a1, a0, (v >> 2) & 30u);  // bits 0..4: present/twice of slot-1, slot, slot+1
@@ -303,15 +304,9 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         //      them), then the padding pairs get their permanent bits back ----
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          if (val[t] < kDenseVLimit) {
-            uint32_t *w = window_word(val[t]);
-            w[0] = 0u, w[1] = 0u;
-          }
+          if (val[t] < kDenseVLimit) wp[t][0] = 0u, wp[t][1] = 0u;
         }
-        if (n_ovf && xval < kDenseVLimit) {
-          uint32_t *w = window_word(xval);
-          w[0] = 0u, w[1] = 0u;
-        }
+        if (n_ovf && xval < kDenseVLimit) xwp[0] = 0u, xwp[1] = 0u;
         wave_sync_lds();
         if (ln == 0) bitmap[0] = 1u, bitmap[(kSlots + 1u) >> 4] = 1u << (((kSlots + 1u) << 1) & 31u);
         wave_sync_lds();
