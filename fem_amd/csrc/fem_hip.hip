@@ -51,6 +51,7 @@ struct Slot {
   size_t h_bases_cap = 0;
   uint64_t *h_off = nullptr;
   size_t h_off_cap = 0;
+  uint64_t acq_reads = 0, acq_bases = 0;  // what the last fem_dev_acquire_stage asked for
   // outputs on the device
   uint64_t *d_cand = nullptr;
   uint32_t *d_meta = nullptr;
@@ -915,6 +916,7 @@ int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n
   if ((rc = pinned_realloc(h, &s.h_bases, &s.h_bases_cap, (size_t)n_bases_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_off, &s.h_off_cap, (size_t)n_reads_cap + 1))) return rc;
   s.staged = false, s.mapped = false, s.synced = false;
+  s.acq_reads = n_reads_cap, s.acq_bases = n_bases_cap;
   *bases = s.h_bases, *offsets = s.h_off;
   return FEM_OK;
 }
@@ -924,11 +926,11 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
   if (rc) return rc;
   Slot &s = h->slot[slot];
   if (!s.h_bases || !s.h_off) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
-  if (n_reads + 1 > s.h_off_cap) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
+  if (n_reads > s.acq_reads) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
   if (max_len > kMaxReadLen)
     return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
   const uint64_t n_bases = n_reads ? s.h_off[n_reads] : 0;
-  if (n_reads && (s.h_off[0] != 0 || n_bases + 64 > s.h_bases_cap)) return fail(h, FEM_ERR_INVALID, "staged offsets must start at 0 and end inside the buffer");
+  if (n_reads && (s.h_off[0] != 0 || n_bases > s.acq_bases)) return fail(h, FEM_ERR_INVALID, "staged offsets must start at 0 and end inside the buffer");
   HIP_TRY(h, hipSetDevice(h->device));
   if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;

@@ -1,0 +1,104 @@
+"""The zero-copy read stream of the C ABI (fem_dev_acquire_stage / fem_dev_commit_stage, include/fem_hip.h) against the
+copying form (fem_dev_stage_reads) and the oracle, and the device pipeline bench.py times (several slots in flight).
+Reference shape: the reusable SequenceBatch ring of src/input_queue.c:34-79.  Needs a GPU: -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from fem_amd import Device
+    rng = np.random.default_rng(90)
+    seqs = [util.rand_seq(rng, 250_000), util.rand_seq(rng, 40_000)]
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    dev = Device(0)
+    dev.upload_reference(seqs)
+    dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    yield rng, seqs, ref, idx, dev
+    dev.close()
+
+
+def _fill(dev, slot, reads, extra_reads=0, extra_bases=0):
+    n, nb = len(reads), sum(len(r) for r in reads)
+    hb, ho = dev.acquire_stage(n + extra_reads, nb + extra_bases, slot=slot)
+    assert len(hb) >= nb + 64 and len(ho) >= n + 1
+    at = 0
+    for i, r in enumerate(reads):
+        ho[i] = at
+        hb[at:at + len(r)] = np.frombuffer(r, np.uint8)
+        at += len(r)
+    ho[n] = at
+    return n, max((len(r) for r in reads), default=0)
+
+
+def test_staged_batches_equal_copied_batches_and_the_oracle(setup):
+    rng, seqs, ref, idx, dev = setup
+    batches = [util.make_reads(rng, seqs, n, L, 3) for n, L in ((700, 100), (33, 150), (1200, 64), (5, 100))]
+    wants = [fo.map_reads(ref, idx, fo.ReadBatch(b), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY) for b in batches]
+    # all four slots filled, committed and mapped before any is fetched: H2D, kernels and D2H of different slots overlap
+    for slot, b in enumerate(batches):
+        n, mx = _fill(dev, slot, b, extra_reads=slot * 7, extra_bases=slot * 1000)
+        dev.commit_stage(n, mx, slot=slot)
+        dev.map_staged(e=3, slot=slot)
+    for slot in (2, 0, 3, 1):  # fetched out of order
+        got = dev.fetch(slot=slot)
+        want = wants[slot]
+        off, cand, ed, end = got.per_strand()
+        assert np.array_equal(got.stats, want.stats)
+        assert np.array_equal(off, want.cand_off) and np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed)
+        assert np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF])
+    # the same batches through the copying entry point, slots reused
+    for slot, b in enumerate(batches):
+        rb = fo.ReadBatch(b)
+        got = dev.map_batch(rb.bases, rb.off, e=3, slot=(slot + 1) % 4)
+        assert np.array_equal(got.stats, wants[slot].stats)
+        assert np.array_equal(got.per_strand()[1], wants[slot].cands)
+    # a slot's staging survives its batch: committing it again maps the same reads again (what bench.py's steps do)
+    n, mx = _fill(dev, 1, batches[0])
+    for _ in range(3):
+        dev.commit_stage(n, mx, slot=1)
+        dev.map_staged(e=3, slot=1)
+        assert np.array_equal(dev.fetch_stats(slot=1), wants[0].stats)
+    rec = dev.fetch_records(slot=1)  # the device tail reads the staged characters too
+    assert rec.n_records == int(wants[0].stats[4])
+
+
+def test_staging_errors_are_reported_not_fatal(setup):
+    from fem_amd import FemError
+    rng, seqs, ref, idx, dev = setup
+    reads = util.make_reads(rng, seqs, 10, 100, 3)
+    with pytest.raises(FemError):
+        dev.acquire_stage(10, 1000, slot=9)  # no such slot
+    n, mx = _fill(dev, 0, reads)
+    with pytest.raises(FemError):
+        dev.commit_stage(n + 5, mx, slot=0)  # more reads than the buffers were acquired for
+    with pytest.raises(FemError):
+        dev.commit_stage(n, 5000, slot=0)  # a read longer than the device path takes
+    hb, ho = dev.acquire_stage(4, 400, slot=3)
+    ho[0] = 8  # offsets must start at 0
+    ho[1:5] = [108, 208, 308, 408]
+    with pytest.raises(FemError):
+        dev.commit_stage(4, 100, slot=3)
+    # an empty batch is fine
+    dev.acquire_stage(0, 0, slot=2)
+    dev.commit_stage(0, 0, slot=2)
+    dev.map_staged(e=3, slot=2)
+    assert dev.fetch_stats(slot=2).tolist() == [0, 0, 0, 0, 0]
+    # stage_reads still checks what a caller hands it
+    bases = np.zeros(3000, np.uint8) + 65
+    with pytest.raises(FemError):
+        dev.stage_reads(bases, np.array([0, 100, 50], np.uint64))  # offsets go backwards
+    with pytest.raises(FemError):
+        dev.stage_reads(bases, np.array([0, 2000], np.uint64))  # longer than the limit
+    # and the handle still works afterwards
+    n, mx = _fill(dev, 0, reads)
+    dev.commit_stage(n, mx, slot=0)
+    dev.map_staged(e=3, slot=0)
+    want = fo.map_reads(ref, idx, fo.ReadBatch(reads), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    assert np.array_equal(dev.fetch_stats(slot=0), want.stats)
