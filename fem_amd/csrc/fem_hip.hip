@@ -289,7 +289,7 @@ femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
   l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 4u));
   l.dp_bits = take(n_groups * R * 8u);
   l.X = take(64u * 4u);
-  l.A = take(3u * 65u * 4u);
+  l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
   l.rb = take((femk::kReadBlock + 2u) * 8u);  // the block's read offsets
   l.picked = take(64u * 8u);                   // (goff, length) of up to 64 sequences

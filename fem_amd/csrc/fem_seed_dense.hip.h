@@ -47,10 +47,16 @@ constexpr uint32_t kDenseMaxList = 128u;       // entries of one seed's list thi
 #define FEM_DENSE_SLOTS_LO 16384u
 #endif
 #ifndef FEM_DENSE_SLOTS_HI
-#define FEM_DENSE_SLOTS_HI 32768u
+#define FEM_DENSE_SLOTS_HI 16384u
 #endif
 constexpr uint32_t dense_slots(int R) { return R >= 7 ? FEM_DENSE_SLOTS_HI : FEM_DENSE_SLOTS_LO; }
 constexpr uint32_t dense_bitmap_words(int R) { return dense_slots(R) / 16u + 2u; }
+// Flagged values one (strand, group) unit may have before the read goes to the generic kernel: chance flags grow like
+// 3 n^2 / slots, and at R >= 7 (n ~ 470) a 16 Ki-slot bitmap gives ~40 of them: two per lane there, one otherwise.
+#ifndef FEM_DENSE_FLAGS_HI
+#define FEM_DENSE_FLAGS_HI 128u
+#endif
+constexpr uint32_t dense_flag_cap(int R) { return R >= 7 ? FEM_DENSE_FLAGS_HI : 64u; }
 
 // ---- derived tables (built once per index upload) ----
 // occ (uint64 seq << 32 | pos) -> global 32-bit coordinates; *bad is set if an entry names a sequence >= n_seq
@@ -126,12 +132,13 @@ __device__ __forceinline__ uint32_t lds_or_rtn(uint32_t *w, uint32_t bits) {
 // ---------------------------------------------------------------------------------------------------------
 template <int R>
 __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
-                           uint32_t *flg /* LDS [3][65] */, uint32_t *scatter /* LDS [64] */, uint32_t *cand_lds,
+                           uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */, uint32_t *cand_lds,
                            uint32_t &kept0, uint32_t &kept1) {
   const uint32_t ln = lane_id();
   constexpr uint32_t kSlots = dense_slots(R);
   constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : kSlots == 32768u ? 15u : kSlots == 16384u ? 14u : 13u;
-  constexpr uint32_t kFlgStride = (uint32_t)kWave + 1u;  // entry 64 of a group's array takes the overflow writes
+  constexpr uint32_t kFlagCap = dense_flag_cap(R);  // flagged values one unit may have (one or two per lane)
+  constexpr uint32_t kFlgStride = kFlagCap + 1u;    // the entry behind a group's array takes the overflow writes
   constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;
   const uint32_t *occ32 = p.occ32;
@@ -157,6 +164,7 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
   uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
   uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
   uint32_t nf0 = 0, nf1 = 0, nf2 = 0;
+  bool any_hi = false;  // a survivor sits in the second flagged value of some lane
 #pragma unroll 1
   for (uint32_t u = 0; u < kUnits; ++u) {
     const uint32_t g = u >= (uint32_t)kStep ? u - (uint32_t)kStep : u;
@@ -292,7 +300,7 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
           const bool near = (x & 0x19u) != 0u;
           const uint64_t m = __builtin_amdgcn_ballot_w64(near) & real;
           uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_flag));
-          pos = pos < (uint32_t)kWave ? pos : (uint32_t)kWave;
+          pos = pos < kFlagCap ? pos : kFlagCap;
           if (near && v < kDenseVLimit) flg_g[pos] = v;
           n_flag += (uint32_t)__popcll(m);
         };
@@ -310,20 +318,45 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         wave_sync_lds();
         if (ln == 0) bitmap[0] = 1u, bitmap[(kSlots + 1u) >> 4] = 1u << (((kSlots + 1u) << 1) & 31u);
         wave_sync_lds();
-        if (n_flag > (uint32_t)kWave) return false;
+        if (n_flag > kFlagCap) return false;
       }
     }
     if (n_flag > (uint32_t)p.a) {
       // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
       const bool have = ln < n_flag;
       const uint32_t fv = have ? flg_g[ln] : 0u;
+      const uint32_t n_lo = n_flag < (uint32_t)kWave ? n_flag : (uint32_t)kWave;
       uint32_t cnt = 0;
-      for (uint32_t j = 0; j < n_flag; ++j) {
-        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
-        cnt += (uint32_t)(x - fv <= e);
+      bool pass_hi = false;
+      uint32_t fv_hi = 0;
+      if (kFlagCap > (uint32_t)kWave && n_flag > (uint32_t)kWave) {
+        // more than one flagged value per lane (long lists, small bitmap): the second goes through the same counts
+        const bool have_hi = ln + (uint32_t)kWave < n_flag;
+        fv_hi = have_hi ? flg_g[ln + (uint32_t)kWave] : 0u;
+        uint32_t cnt_hi = 0;
+        for (uint32_t j = 0; j < n_lo; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+        }
+        for (uint32_t j = (uint32_t)kWave; j < n_flag; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv_hi, (int)(j - (uint32_t)kWave));
+          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+        }
+        pass_hi = have_hi && cnt_hi > (uint32_t)p.a;
+      } else {
+        for (uint32_t j = 0; j < n_lo; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+          cnt += (uint32_t)(x - fv <= e);
+        }
       }
       const bool pass = have && cnt > (uint32_t)p.a;
       const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+      if (__builtin_amdgcn_ballot_w64(pass_hi)) {
+        // survivors among the second values: they only take part in the one-candidate shortcut below
+        any_hi = true;
+        cmin = pass_hi && fv_hi < cmin ? fv_hi : cmin;
+        cmax = pass_hi && fv_hi > cmax ? fv_hi : cmax;
+      }
       if (pm != 0) {
         if (g == 0) pm0 = pm, nf0 = n_flag;
         else if (g == 1) pm1 = pm, nf1 = n_flag;
@@ -335,11 +368,13 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
     if (g != (uint32_t)kStep - 1u) continue;
     // ---- the strand's three groups are done: its candidates ----
     uint32_t kept = 0, cv = 0;
-    if ((pm0 | pm1 | pm2) != 0) {
+    if ((pm0 | pm1 | pm2) != 0 || any_hi) {
       const uint32_t lo_all = wave_min_u32(cmin), hi_all = wave_max_u32(cmax);
       if (hi_all - lo_all <= e) {  // every survivor within e of the smallest: the greedy merges keep exactly that one
         cv = ln == 0 ? lo_all : 0u;
         kept = 1;
+      } else if (any_hi) {
+        return false;  // (the general path below takes one survivor per lane)
       } else {
         // general case: per group, survivors sorted into lanes and merged greedily (src/filter.c:45-78)
 #pragma unroll 1
@@ -368,7 +403,7 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
     }
     cand_lds[(u >= (uint32_t)kStep ? (uint32_t)kWave : 0u) + ln] = cv;
     if (u >= (uint32_t)kStep) kept1 = kept; else kept0 = kept;
-    cmin = 0xFFFFFFFFu, cmax = 0u;
+    cmin = 0xFFFFFFFFu, cmax = 0u, any_hi = false;
     pm0 = pm1 = pm2 = 0, nf0 = nf1 = nf2 = 0;
   }
   return true;
