@@ -114,7 +114,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
 
     def submit(i):
         s = i % N_SLOTS
-        dev.commit_stage(batch, L, slot=s)       # asynchronous H2D of the slot's batch
+        dev.commit_stage(batch, L, slot=s, uniform=True)  # asynchronous H2D of the slot's batch (reads of one length: no offsets)
         dev.map_staged(e=e, a=a, k=k, step=step, slot=s)
 
     def retire(i):
@@ -200,7 +200,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "workload": w["name"], "value": round(value, 3), "ms_per_step": round(elapsed * 1e3 / steps, 3), "steps": steps,
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
-        "h2d_bytes_per_step": batch * L + 8 * (batch + 1), "d2h_bytes_per_step": d2h_bytes[0],
+        "h2d_bytes_per_step": batch * L, "d2h_bytes_per_step": d2h_bytes[0],
         "counters": {"reads": int(job[0]), "mapped_reads": int(job[1]), "pre_filter": int(job[2]),
                      "candidates": int(job[3]), "mappings": int(job[4])},
         "counters_last_step_per_gpu": [int(x) for x in last_stats],

@@ -941,6 +941,27 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
   return FEM_OK;
 }
 
+int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!s.h_bases) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
+  if (read_len > kMaxReadLen)
+    return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
+  const uint64_t n_bases = n_reads * (uint64_t)read_len;
+  if (n_reads > s.acq_reads || n_bases > s.acq_bases) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), s.h_bases, n_bases, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n_reads + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
+                     s.stream, s.d_off, n_reads, read_len);
+  HIP_TRY(h, hipGetLastError());
+  s.n_reads = n_reads, s.n_bases = n_bases, s.max_len = read_len;
+  s.staged = true, s.mapped = false, s.synced = false;
+  return FEM_OK;
+}
+
 int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   int rc = check_slot(h, slot);
   if (rc) return rc;

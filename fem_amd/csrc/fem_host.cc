@@ -420,7 +420,7 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
 namespace {
 struct RangeCount {
   uint64_t n = 0, bases = 0, names = 0;
-  uint32_t max_len = 0;
+  uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
   bool ok = true;
 };
 // One strict 4-line FASTQ record at p (blank lines in front skipped).  false: not that shape (or end of range).
@@ -544,17 +544,21 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
           if (r.len == 0) continue;  // zero-length records are skipped (src/sequence_batch.c:50-52)
           ++c.n, c.bases += r.len, c.names += r.name_len;
           c.max_len = std::max<uint32_t>(c.max_len, (uint32_t)std::min<size_t>(r.len, 0xFFFFFFFFu));
+          c.min_len = std::min<uint32_t>(c.min_len, (uint32_t)std::min<size_t>(r.len, 0xFFFFFFFFu));
         }
         c.ok = !bad;
         pl->count[(size_t)t] = c;
       }
       bool ok = true;
+      uint32_t min_len = 0xFFFFFFFFu;
       for (const RangeCount &c : pl->count) ok = ok && c.ok;
       if (ok) {
         for (const RangeCount &c : pl->count) {
           shape->n_reads += c.n, shape->n_bases += c.bases, shape->n_name_bytes += c.names;
           shape->max_len = std::max(shape->max_len, c.max_len);
+          min_len = std::min(min_len, c.min_len);
         }
+        shape->min_len = shape->n_reads ? min_len : 0;
         shape->has_qual = 1;
         pl->fast = true, pl->m = m, pl->end = hi;
         f->in->seek_mem(hi);
@@ -574,8 +578,11 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
   shape->n_reads = pl->held.n;
   shape->n_bases = pl->held.n ? pl->held.off[pl->held.n] : 0;
   shape->n_name_bytes = pl->held.n ? pl->held.name_off[pl->held.n] : 0;
-  for (uint64_t i = 0; i < pl->held.n; ++i)
-    shape->max_len = std::max<uint32_t>(shape->max_len, (uint32_t)std::min<uint64_t>(pl->held.off[i + 1] - pl->held.off[i], 0xFFFFFFFFu));
+  shape->min_len = pl->held.n ? 0xFFFFFFFFu : 0u;
+  for (uint64_t i = 0; i < pl->held.n; ++i) {
+    const uint32_t l = (uint32_t)std::min<uint64_t>(pl->held.off[i + 1] - pl->held.off[i], 0xFFFFFFFFu);
+    shape->max_len = std::max(shape->max_len, l), shape->min_len = std::min(shape->min_len, l);
+  }
   shape->has_qual = pl->held.quals != nullptr || pl->held.n == 0;
   *plan_out = pl;
   return pl->rc;  // -2 / -3: "Didn't reach the end of sequence file"; the records read so far are still in the plan

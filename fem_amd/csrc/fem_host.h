@@ -56,6 +56,7 @@ typedef struct {
   uint64_t n_reads, n_bases, n_name_bytes;
   uint32_t max_len;
   int32_t has_qual; /* every record carried qualities */
+  uint32_t min_len; /* == max_len: reads of one length (fem_dev_commit_stage_uniform) */
 } fem_batch_shape;
 int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_batch_plan **plan, fem_batch_shape *shape);
 int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *plan, int n_threads, char *bases, uint64_t *off, char *quals,

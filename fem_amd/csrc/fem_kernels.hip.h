@@ -90,6 +90,12 @@ struct SeedParams {
   SeedLayout lay;
 };
 
+// read offsets of a batch of equal-length reads (fem_dev_commit_stage_uniform): off[i] = i * len, i <= n
+__global__ void uniform_offsets_kernel(uint64_t *off, uint64_t n, uint32_t len) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) off[i] = i * (uint64_t)len;
+}
+
 struct Picked {
   uint32_t start, lo, freq, pad;
 };

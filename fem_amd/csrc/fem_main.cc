@@ -457,7 +457,8 @@ int map_main(int argc, char **argv) {
         b->gpu = g, b->slot = s;
         // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are
         // unusual (the reader asks for larger buffers when a batch needs them)
-        if (acquire(b, batch_bytes / 32 + 16, batch_bytes / 2 + 4096)) free_q.push(b);
+        if (!acquire(b, batch_bytes / 32 + 16, batch_bytes / 2 + 4096)) b->bases = nullptr;
+        free_q.push(b);  // (without buffers when the acquisition failed: the reader stops on it instead of waiting for ever)
       }
       std::deque<BatchBuf *> flight;
       auto retire = [&] {
@@ -485,7 +486,8 @@ int map_main(int argc, char **argv) {
         }
         if (m.kind == kStop) break;
         if (m.kind == kRecycle) {
-          if (acquire(m.b, m.b->reads_cap, m.b->bases_cap)) free_q.push(m.b);
+          if (!acquire(m.b, m.b->reads_cap, m.b->bases_cap)) m.b->bases = nullptr;
+          free_q.push(m.b);
           continue;
         }
         if (m.kind == kRegrow) {
@@ -495,7 +497,10 @@ int map_main(int argc, char **argv) {
         }
         BatchBuf *b = m.b;  // kFilled
         b->t_submit = real_time();
-        int rc = exit_code ? FEM_ERR_STATE : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
+        int rc = exit_code ? FEM_ERR_STATE
+                 : b->shape.min_len == b->shape.max_len  // reads of one length: the offsets need not cross the link
+                     ? fem_dev_commit_stage_uniform(h, b->slot, b->shape.n_reads, b->shape.max_len)
+                     : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
         if (!rc) rc = fem_dev_map_staged(h, b->slot, &params);
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "batch submit", rc);
@@ -517,6 +522,7 @@ int map_main(int argc, char **argv) {
     }
     while (f && !exit_code) {
       BatchBuf *b = free_q.pop();
+      if (!b->bases) break;  // its GPU could not provide staging buffers (reported by the worker)
       double t0 = real_time();
       if (t_first_slot == 0) t_first_slot = t0;
       fem_batch_plan *plan = nullptr;

@@ -12,7 +12,7 @@ ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
-    "fem_dev_stage_reads", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_stage_reads", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
@@ -77,6 +77,7 @@ def load_hip():
     L.fem_dev_stage_reads.argtypes = [vp, C.c_int, C.POINTER(_ReadBatch)]
     L.fem_dev_acquire_stage.argtypes = [vp, C.c_int, u64, u64, C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_stage.argtypes = [vp, C.c_int, u64, C.c_uint32]
+    L.fem_dev_commit_stage_uniform.argtypes = [vp, C.c_int, u64, C.c_uint32]
     L.fem_dev_map_staged.argtypes = [vp, C.c_int, C.POINTER(Params)]
     L.fem_dev_sync.argtypes = [vp, C.c_int]
     L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
@@ -228,8 +229,12 @@ class Device:
         offs = np.frombuffer((C.c_char * (8 * (int(n_reads_cap) + 1))).from_address(po.value), dtype=np.uint64)
         return bases, offs
 
-    def commit_stage(self, n_reads, max_len, slot=0):
-        self._check(self._L.fem_dev_commit_stage(self._h, slot, n_reads, max_len))
+    def commit_stage(self, n_reads, max_len, slot=0, uniform=False):
+        """uniform=True: every read has exactly max_len characters; the offsets are generated on the device."""
+        if uniform:
+            self._check(self._L.fem_dev_commit_stage_uniform(self._h, slot, n_reads, max_len))
+        else:
+            self._check(self._L.fem_dev_commit_stage(self._h, slot, n_reads, max_len))
 
     def map_staged(self, e=3, a=1, k=12, step=3, slot=0):
         p = Params(k, step, e, a)

@@ -31,7 +31,7 @@ class Records(C.Structure):
 
 class BatchShape(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_name_bytes", C.c_uint64), ("max_len", C.c_uint32),
-                ("has_qual", C.c_int32)]
+                ("has_qual", C.c_int32), ("min_len", C.c_uint32)]
 
 
 class RecordView(C.Structure):
@@ -212,7 +212,7 @@ class PlannedBatch:
 
     def __init__(self, shape, bases, off, quals, names, name_off):
         self.n = int(shape.n_reads)
-        self.max_len = int(shape.max_len)
+        self.max_len, self.min_len = int(shape.max_len), int(shape.min_len)
         self.bases, self.off, self.quals, self.names_raw, self.name_off = bases, off, quals, names, name_off
 
     def seq(self, i):

@@ -65,6 +65,14 @@ def test_staged_batches_equal_copied_batches_and_the_oracle(setup):
         dev.commit_stage(n, mx, slot=1)
         dev.map_staged(e=3, slot=1)
         assert np.array_equal(dev.fetch_stats(slot=1), wants[0].stats)
+    # reads of one length: the offsets are generated on the device (they are not even looked at in the staging buffer)
+    hb, ho = dev.acquire_stage(n, sum(len(r) for r in batches[0]), slot=2)
+    hb[:n * 100] = np.frombuffer(b"".join(batches[0]), np.uint8)
+    ho[:] = 0xDEAD
+    dev.commit_stage(n, 100, slot=2, uniform=True)
+    dev.map_staged(e=3, slot=2)
+    got = dev.fetch(slot=2)
+    assert np.array_equal(got.stats, wants[0].stats) and np.array_equal(got.per_strand()[1], wants[0].cands)
     rec = dev.fetch_records(slot=1)  # the device tail reads the staged characters too
     assert rec.n_records == int(wants[0].stats[4])
 
