@@ -145,14 +145,15 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
   kept0 = 0, kept1 = 0;
   if (__builtin_amdgcn_ballot_w64(s_freq > kDenseMaxList)) return false;  // a list beyond two chunks: generic kernel
   const uint32_t s_sf = s_start | (s_freq << 16);  // start < 1024, frequency <= 128: one readlane fetches both
-  uint32_t nxt[R];  // first chunk of every run of the next unit (raw table entries)
+  uint32_t nxt[R];     // first chunk of every run of the next unit (raw table entries)
+  uint32_t nxt_sf[R];  // ... and its runs' (start | frequency << 16), wave-uniform: read once, used by the loads and the unit
   auto prefetch = [&](uint32_t u) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t)) >> 16;
+      nxt_sf[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t));
       const uint32_t *bp = occ32 + (uint32_t)__builtin_amdgcn_readlane((int)s_lo, (int)(u * R + t));
       nxt[t] = kDenseSent;
-      if (ln < fq) nxt[t] = bp[ln];
+      if (ln < (nxt_sf[t] >> 16)) nxt[t] = bp[ln];
     }
   };
   // own pair of a value: LDS word and bit of its "present" flag ("twice" is the next bit)
@@ -173,7 +174,7 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
     uint32_t n_g = 0, n_ovf = 0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      const uint32_t sf = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t));
+      const uint32_t sf = nxt_sf[t];
       f[t] = sf >> 16, st[t] = sf & 0xFFFFu;
       n_g += f[t];
       n_ovf += f[t] > (uint32_t)kWave ? f[t] - (uint32_t)kWave : 0u;
@@ -206,11 +207,14 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         if (ln < n_ovf) xval = occ32[idx];
       }
       uint64_t remap = 0;
+      {
+        uint32_t raw_max = val[0];  // the sentinel is below kDenseRemap: one compare for all the unit's first chunks
 #pragma unroll
-      for (int t = 0; t < R; ++t) {
-        remap |= __builtin_amdgcn_ballot_w64(val[t] >= kDenseRemap);
-        val[t] -= st[t];  // (the sentinel stays above kDenseVLimit: start < 1024)
+        for (int t = 1; t < R; ++t) raw_max = val[t] > raw_max ? val[t] : raw_max;
+        remap = __builtin_amdgcn_ballot_w64(raw_max >= kDenseRemap);
       }
+#pragma unroll
+      for (int t = 0; t < R; ++t) val[t] -= st[t];  // (the sentinel stays above kDenseVLimit: start < 1024)
       if (n_ovf) {
         remap |= __builtin_amdgcn_ballot_w64(xval >= kDenseRemap);
         xval -= xst;
@@ -272,11 +276,10 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
             xhit = lds_or_rtn(pair_word(xval), bit) & bit;
           }
         }
-        uint64_t coll = 0;
+        uint32_t any_hit = xhit;
 #pragma unroll
-        for (int t = 0; t < R; ++t) coll |= __builtin_amdgcn_ballot_w64(hit[t] != 0u);
-        if (n_ovf) coll |= __builtin_amdgcn_ballot_w64(xhit != 0u);
-        if (coll) {  // some slot took a second value (every true hit does): mark "twice"
+        for (int t = 0; t < R; ++t) any_hit |= hit[t];
+        if (__builtin_amdgcn_ballot_w64(any_hit != 0u)) {  // some slot took a second value (every true hit does): mark "twice"
 #pragma unroll
           for (int t = 0; t < R; ++t)
             if (hit[t]) (void)lds_or_rtn(pair_word(val[t]), hit[t] << 1);
