@@ -138,6 +138,14 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
   constexpr uint32_t kSlots = dense_slots(R);
   constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : kSlots == 32768u ? 15u : kSlots == 16384u ? 14u : 13u;
   constexpr uint32_t kFlagCap = dense_flag_cap(R);  // flagged values one unit may have (one or two per lane)
+#ifndef FEM_DENSE_PROBE_R
+#define FEM_DENSE_PROBE_R 1
+#endif
+#ifndef FEM_DENSE_PROBE_MIN
+#define FEM_DENSE_PROBE_MIN 8u
+#endif
+  constexpr bool kSecondProbe = R >= FEM_DENSE_PROBE_R;  // weed the chance flags out before the exact filter
+  constexpr uint32_t kProbeMin = FEM_DENSE_PROBE_MIN;    // ... when there are more flagged values than this
   constexpr uint32_t kFlgStride = kFlagCap + 1u;    // the entry behind a group's array takes the overflow writes
   constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;
@@ -323,6 +331,54 @@ __device__ bool dense_join(const SeedParams &p, uint32_t s_start, uint32_t s_lo,
         wave_sync_lds();
         if (n_flag > kFlagCap) return false;
       }
+    }
+    if (kSecondProbe && n_flag > kProbeMin) {
+      // ---- second probe: most of the flagged values are chance flags — values whose slot or a
+      //      neighbouring one was also hit by a value 2^17 k positions away.  The flagged values alone go through
+      //      the (clean again) bitmap once more, with the slot shifted by a multiple of the value's bits above 17:
+      //      a true pair (within e) lands in the same / adjacent slots again, chance partners scatter.  Values within
+      //      e of a 2^17 boundary are kept unseen (their partner may sit under another shift).  What survives is a
+      //      superset of every within-e pair, so the exact filter below gives the same result on far fewer values. ----
+      const bool have0 = ln < n_flag, have1 = ln + (uint32_t)kWave < n_flag;
+      const uint32_t v0 = have0 ? flg_g[ln] : kDenseSent, v1 = have1 ? flg_g[ln + (uint32_t)kWave] : kDenseSent;
+      auto key2 = [&](uint32_t v) -> uint32_t {
+        const uint32_t slot2 = (__builtin_amdgcn_ubfe(v, 3u, kSlotBits) + (v >> 17) * 0x9E5u) & (kSlots - 1u);
+        return (slot2 << 3) | (v & 7u);
+      };
+      auto edge = [&](uint32_t v) -> bool {
+        const uint32_t lo17 = v & 0x1FFFFu;
+        return lo17 < e || lo17 + e >= 0x20000u;
+      };
+      const uint32_t k0 = key2(v0), k1 = key2(v1);
+      uint32_t h0 = 0, h1 = 0;
+      if (have0) {
+        const uint32_t bit = pair_bit(k0);
+        h0 = lds_or_rtn(pair_word(k0), bit) & bit;
+      }
+      if (have1) {
+        const uint32_t bit = pair_bit(k1);
+        h1 = lds_or_rtn(pair_word(k1), bit) & bit;
+      }
+      if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u)) {
+        if (h0) (void)lds_or_rtn(pair_word(k0), h0 << 1);
+        if (h1) (void)lds_or_rtn(pair_word(k1), h1 << 1);
+      }
+      wave_sync_lds();
+      uint32_t *wq0 = window_word(k0), *wq1 = window_word(k1);
+      const uint32_t a0 = wq0[0], a1 = wq0[1], b0 = wq1[0], b1 = wq1[1];
+      const bool keep0 = have0 && (edge(v0) || (__builtin_amdgcn_alignbit(a1, a0, (k0 >> 2) & 30u) & 0x19u) != 0u);
+      const bool keep1 = have1 && (edge(v1) || (__builtin_amdgcn_alignbit(b1, b0, (k1 >> 2) & 30u) & 0x19u) != 0u);
+      wave_sync_lds();
+      if (have0) wq0[0] = 0u, wq0[1] = 0u;
+      if (have1) wq1[0] = 0u, wq1[1] = 0u;
+      wave_sync_lds();
+      if (ln == 0) bitmap[0] = 1u, bitmap[(kSlots + 1u) >> 4] = 1u << (((kSlots + 1u) << 1) & 31u);
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(keep0), m1 = __builtin_amdgcn_ballot_w64(keep1);
+      const uint32_t c0 = (uint32_t)__popcll(m0);
+      if (keep0) flg_g[__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = v0;
+      if (keep1) flg_g[__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c0))] = v1;
+      n_flag = c0 + (uint32_t)__popcll(m1);
+      wave_sync_lds();
     }
     if (n_flag > (uint32_t)p.a) {
       // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
