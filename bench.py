@@ -286,7 +286,7 @@ def main():
                                                     "(auto = c3,c5 next to c2; none)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
-    ap.add_argument("--e2e-reads", type=int, default=8_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
