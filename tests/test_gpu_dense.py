@@ -94,3 +94,34 @@ def test_dense_form_as_selected(dense, e, L, n):
 
 def test_dense_form_a2(dense):
     _compare(dense, 729, 1500, 100, 3, a=2)
+
+
+def test_dense_form_declines_what_its_32_bit_coordinates_cannot_hold():
+    # more than 2^18 sequences: the remapped near-start entries (seq << 10 | pos) do not fit; the library must fall back to
+    # the 64-bit hash-join form even when asked for the dense one, with identical results
+    from fem_amd import Device
+    from tests import util
+    rng = np.random.default_rng(262)
+    n_seq = (1 << 18) + 5
+    flat = util.rand_seq(rng, n_seq * 130)
+    seqs = [flat[i * 130:(i + 1) * 130] for i in range(n_seq)]
+    reads = [seqs[int(i)][int(o):int(o) + 100] for i, o in zip(rng.integers(0, n_seq, 300), rng.integers(0, 27, 300))]
+    reads = [util.mutate(rng, r + b"ACG", int(rng.integers(0, 3)))[:100] for r in reads]
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    want = fo.map_reads(ref, idx, fo.ReadBatch(reads), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    os.environ["FEM_FORCE_DENSE"] = "1"
+    try:
+        dev = Device(0)
+    finally:
+        os.environ.pop("FEM_FORCE_DENSE")
+    try:
+        dev.upload_reference(seqs)
+        dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+        assert dev.seed_kernel(e=3) != "seed_dense_kernel"
+        b = fo.ReadBatch(reads)
+        got = dev.map_batch(b.bases, b.off, e=3)
+        assert np.array_equal(got.stats, want.stats) and np.array_equal(got.per_strand()[1], want.cands)
+        assert want.stats[1] > 150
+    finally:
+        dev.close()

@@ -191,3 +191,17 @@ def test_batch_sizes_around_the_block_and_pull_sizes(dev, n_reads):
     reads = util.make_reads(rng, seqs, n_reads, 100, 3)
     want, got = run_both(dev, seqs, reads, e=3)
     assert_same(want, got)
+
+
+def test_many_short_sequences(dev):
+    # 150 sequences: more than the 64 whose coordinates the dense kernel keeps in LDS (its clip then goes through the
+    # block table in HBM), reads starting at the first and ending at the last base of many of them, and occurrence
+    # entries within 1 024 bases of a sequence start (the remapped entries of the 32-bit table) everywhere
+    rng = np.random.default_rng(150)
+    seqs = [util.rand_seq(rng, int(rng.integers(400, 4000))) for _ in range(150)]
+    reads = util.make_reads(rng, seqs, 600, 100, 3)
+    for s in seqs[::7]:
+        reads += [s[:100], s[-100:], util.revcomp(s[1:101]), s[5:105], s[-105:-5]]
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert want.stats[1] > 500
+    assert_same(want, got)
