@@ -355,6 +355,10 @@ int map_main(int argc, char **argv) {
   }
 
   double t_start = real_time();
+  // -t threads are shared by the two host stages that run side by side (FEM_SPLIT_THREADS=0: each gets all of them)
+  const char *sp_env = getenv("FEM_SPLIT_THREADS");
+  const bool split = !(sp_env && sp_env[0] == '0') && n_threads >= 4;
+  const int rd_threads = split ? (n_threads + 1) / 2 : n_threads, fmt_threads = split ? n_threads / 2 : n_threads;
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
   int32_t n_slots = 4;
   (void)fem_dev_limits(devs[0], nullptr, &n_slots);
@@ -410,7 +414,7 @@ int map_main(int argc, char **argv) {
         fem_tail_input in{b->res.n_reads, b->res.cand_begin, b->res.cand_count, b->res.cand, b->res.ed, b->res.end};
         char *text = nullptr;
         uint64_t len = 0;
-        fmt = fem_tail_sam(params.e, &ref.view, &reads, &in, n_threads, &text, &len);
+        fmt = fem_tail_sam(params.e, &ref.view, &reads, &in, fmt_threads, &text, &len);
         if (!fmt) {
           free(t->buf);
           t->buf = text, t->cap = len, t->owned_elsewhere = true;
@@ -420,9 +424,9 @@ int map_main(int argc, char **argv) {
         const fem_batch_records &rec = b->rec;
         fem_record_view rv{rec.n_reads, rec.n_records, rec.rec_begin, rec.flag, rec.tid, rec.pos0, rec.nm,
                            rec.cigar_off, rec.cigar, rec.md_off, rec.md};
-        t->parts.assign((size_t)n_threads, fem_text_part{0, 0});
+        t->parts.assign((size_t)fmt_threads, fem_text_part{0, 0});
         uint64_t na = 0;
-        fmt = fem_records_sam_parts(&ref.view, &reads, &rv, n_threads, &t->buf, &t->cap, t->parts.data(), &na);
+        fmt = fem_records_sam_parts(&ref.view, &reads, &rv, fmt_threads, &t->buf, &t->cap, t->parts.data(), &na);
         n_asserted += na;
       }
       busy_text += real_time() - t0;
@@ -526,7 +530,7 @@ int map_main(int argc, char **argv) {
       double t0 = real_time();
       if (t_first_slot == 0) t_first_slot = t0;
       fem_batch_plan *plan = nullptr;
-      int rc = fem_seqfile_plan(f, batch_bytes, n_threads, &plan, &b->shape);
+      int rc = fem_seqfile_plan(f, batch_bytes, rd_threads, &plan, &b->shape);
       bool ok = plan != nullptr;
       if (rc != 0) {  // the reference exits on a truncated file (src/sequence_batch.c:63-66): nothing of this batch is mapped
         fprintf(stderr, "Didn't reach the end of sequence file, which might be corrupted!");
@@ -557,7 +561,7 @@ int map_main(int argc, char **argv) {
         busy_read += real_time() - t0;
         break;  // end of input (or failure)
       }
-      rc = fem_seqfile_fill(f, plan, n_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
+      rc = fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
       busy_read += real_time() - t0;
       if (rc) {
         fprintf(stderr, "[FEM] reading failed\n");
