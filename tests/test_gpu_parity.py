@@ -205,3 +205,29 @@ def test_many_short_sequences(dev):
     want, got = run_both(dev, seqs, reads, e=3)
     assert want.stats[1] > 500
     assert_same(want, got)
+
+
+def test_long_lists_without_repeats(dev):
+    # occurrence lists of 65..128 entries whose positions are unrelated (every 12-mer of twenty loci planted ~100 times at
+    # random indexed positions elsewhere): the dense kernel's packed overflow chunk, its wave-reduced maximum of U and
+    # the second bitmap probe, with survivors at the true locus only — a 3 Gbp reference in miniature
+    rng = np.random.default_rng(128)
+    ref = bytearray(util.rand_seq(rng, 20_000_000))
+    starts = 1000 + 3000 * np.arange(20)
+    lo_plant = (int(starts[-1]) + 5000) // 3  # the loci themselves stay untouched
+    for s in starts:
+        read = bytes(ref[int(s):int(s) + 100])
+        for off in range(89):
+            kmer = read[off:off + 12]
+            for pos in rng.integers(lo_plant, (len(ref) - 20) // 3, size=int(rng.integers(80, 150))) * 3:
+                ref[int(pos):int(pos) + 12] = kmer
+    seqs = [bytes(ref)]
+    reads = []
+    for s in starts:
+        for n_err in (0, 1, 3):
+            r = util.mutate(rng, seqs[0][int(s):int(s) + 103], n_err)[:100]
+            reads.append(r if rng.random() < 0.5 else util.revcomp(r))
+    reads += util.make_reads(rng, seqs, 60, 100, 3)
+    want, got = run_both(dev, seqs, reads, e=3)
+    assert want.pre.max() > 1000 and np.sort(want.pre)[-40] > 400, "lists must be long"
+    assert_same(want, got)
