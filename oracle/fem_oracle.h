@@ -63,6 +63,9 @@ typedef struct {
 uint64_t fo_index_count(const fo_ref *ref, int k, int step);
 /* Fills lookup[4^k+1] and occ[fo_index_count()]. Returns 0 on success. */
 int fo_index_build(const fo_ref *ref, int k, int step, uint32_t *lookup, uint64_t *occ);
+/* The same arrays, built by n_threads threads (each owns a range of buckets): only to make the checker usable on
+ * BASELINE-sized references; verified against fo_index_build. */
+int fo_index_build_mt(const fo_ref *ref, int k, int step, uint32_t *lookup, uint64_t *occ, int n_threads);
 /* File format of save_index/load_index (src/index.c:100-168). */
 int fo_index_save(const char *path, int k, int step, const uint32_t *lookup, uint64_t n_occ, const uint64_t *occ);
 /* Reads header + sizes; call twice (first with lookup/occ NULL to get n_occ). */

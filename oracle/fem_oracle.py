@@ -47,6 +47,7 @@ def lib():
         L.fo_index_count.restype = C.c_uint64
         L.fo_index_count.argtypes = [C.POINTER(Ref), C.c_int, C.c_int]
         L.fo_index_build.argtypes = [C.POINTER(Ref), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fo_index_build_mt.argtypes = [C.POINTER(Ref), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.fo_index_save.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         L.fo_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p,
                                     C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64]
@@ -134,14 +135,17 @@ class ReadBatch:
 
 
 class OracleIndex:
-    def __init__(self, ref, k=12, step=3):
+    def __init__(self, ref, k=12, step=3, threads=1):
         L = lib()
         self.k, self.step = k, step
         n = L.fo_index_count(C.byref(ref.c), k, step)
         self.lookup = np.zeros((1 << (2 * k)) + 1, dtype=np.uint32)
         self.occ = np.zeros(max(int(n), 1), dtype=np.uint64)
         self.n_occ = int(n)
-        rc = L.fo_index_build(C.byref(ref.c), k, step, _ptr(self.lookup), _ptr(self.occ))
+        if threads > 1:  # same arrays, several threads (BASELINE-sized references)
+            rc = L.fo_index_build_mt(C.byref(ref.c), k, step, _ptr(self.lookup), _ptr(self.occ), threads)
+        else:
+            rc = L.fo_index_build(C.byref(ref.c), k, step, _ptr(self.lookup), _ptr(self.occ))
         assert rc == 0
         self.c = Index(k, step, _ptr(self.lookup), self.n_occ, _ptr(self.occ))
 

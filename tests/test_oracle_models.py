@@ -333,3 +333,16 @@ def test_batch_driver_threads_and_stats():
     assert r1.stats[1] == np.count_nonzero(np.diff(r1.map_off.astype(np.int64)))
     assert r1.stats[1] > 200  # most synthetic reads map
     assert not np.any(r1.r_flag & 0x8000)
+
+
+def test_threaded_index_build_equals_the_sequential_restatement():
+    # fo_index_build_mt only exists to make the checker usable on BASELINE-sized references (tests/test_gpu_full_scale.py);
+    # it must give byte for byte what the restatement of construct_index (src/index.c:57-98) gives
+    from tests import util
+    rng = np.random.default_rng(31)
+    seqs = [util.rand_seq(rng, 700_000), b"ACGT" * 5000, util.rand_seq(rng, 11), b"N" * 50 + util.rand_seq(rng, 90_000), b"A" * 3000]
+    ref = fo.Reference(seqs)
+    a = fo.OracleIndex(ref)
+    for threads in (2, 5, 16):
+        b = fo.OracleIndex(ref, threads=threads)
+        assert a.n_occ == b.n_occ and np.array_equal(a.lookup, b.lookup) and np.array_equal(a.occ, b.occ)
