@@ -46,3 +46,21 @@ def test_c3_c5_candidates_and_verification_equal_the_oracle(full, e, a, L, n, se
     assert np.array_equal(o, want.cand_off) and np.array_equal(cand, want.cands)
     assert np.array_equal(ed, want.v_ed) and np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF])
     assert want.stats[1] > 0.93 * n
+
+
+def test_c3_records_equal_the_oracle(full):
+    # ... and the mapping tail on the device (ordering, traceback, CIGAR, MD) for reads mapped against the 3 Gbp reference
+    text, off, lens, ref, idx, dev = full
+    if dev.seed_kernel(e=3) != "seed_dense_kernel":
+        dev.build_index(12, 3, fetch=False)
+    n = 40_000
+    bases, offs = host.synth_reads(33, text, off, lens, n, 100, 3, threads=16)
+    want = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offs), e=3, threads=16)
+    got = dev.map_batch(bases, offs, e=3)
+    assert np.array_equal(got.stats, want.stats)
+    rec = dev.fetch_records()
+    assert np.array_equal(rec.rec_begin, want.rec_off) and np.array_equal(rec.flag, want.r_flag)
+    assert np.array_equal(rec.tid, want.r_tid) and np.array_equal(rec.pos0, want.r_pos) and np.array_equal(rec.nm, want.r_nm)
+    assert np.array_equal(rec.cigar_off, want.cig_off) and np.array_equal(rec.cigar, want.cig)
+    assert np.array_equal(rec.md_off, want.md_off) and np.array_equal(rec.md, want.md)
+    assert np.any((want.cig & 0xF) == 1) and np.any((want.cig & 0xF) == 2)
