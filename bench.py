@@ -211,7 +211,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     }
 
 
-def cpu_baseline(w, data, n_sample, dev, threads):
+def cpu_baseline(w, data, n_sample, dev, threads, label="C2"):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of the
     same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
     import numpy as np
@@ -222,7 +222,7 @@ def cpu_baseline(w, data, n_sample, dev, threads):
     bases, offsets = host.synth_reads(w["seed"], text, off, lens, n_sample, L, e, first_read=0, threads=threads)
     ref = fo.Reference([text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)])
     t0 = time.time()
-    idx = fo.OracleIndex(ref)
+    idx = fo.OracleIndex(ref, threads=threads if len(text) > 500_000_000 else 1)  # (threaded build: same arrays, BASELINE-sized references)
     t_index = time.time() - t0
     sample = fo.ReadBatch.from_arrays(bases, offsets)
     t0 = time.perf_counter()
@@ -233,7 +233,7 @@ def cpu_baseline(w, data, n_sample, dev, threads):
     fo.free_result(h)
     got = dev.map_batch(bases, offsets, e=e, a=1, slot=1).stats  # the same sample through the device path
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "port",
-            "sample": "%d reads of the C2 workload, seeding+filter+verification, %d threads (every core this process may use)" % (n_sample, threads),
+            "sample": "%d reads of the %s workload, seeding+filter+verification, %d threads (every core this process may use)" % (n_sample, label, threads),
             "seconds": round(dt, 3), "index_build_seconds": round(t_index, 2),
             "counters_match_device": bool(np.array_equal(got, st))}
 
@@ -286,6 +286,8 @@ def main():
                                                     "(auto = c3,c5 next to c2; none)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
+    ap.add_argument("--cpu-sample-c3", type=int, default=400_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
+                                                                       "the oracle's 3 Gbp index takes ~30 s to build)")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -381,6 +383,11 @@ def main():
                                                            "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "d2h_bytes_per_step")}
                                  for k_, v_ in results.items()},
     }
+    if not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0:
+        # the bandwidth-relevant configuration on the host cores too (the device still holds the 3 Gbp reference)
+        w3 = WORKLOADS["c3"]
+        out["cpu_baseline_c3"] = cpu_baseline(w3, data_cache[(3, tuple(w3["seq_lens"]))][:3], args.cpu_sample_c3, dev, threads, label="C3")
+        out["cpu_baseline_c3"].update(device_pipeline_over_cpu=round(results["c3"]["value"] / max(out["cpu_baseline_c3"]["value"], 1e-9), 1))
     c2_data = None
     if (not args.no_cpu or not args.no_e2e) and rk.world == 1:
         w2 = WORKLOADS["c2"]
