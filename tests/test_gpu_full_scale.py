@@ -64,3 +64,40 @@ def test_c3_records_equal_the_oracle(full):
     assert np.array_equal(rec.cigar_off, want.cig_off) and np.array_equal(rec.cigar, want.cig)
     assert np.array_equal(rec.md_off, want.md_off) and np.array_equal(rec.md, want.md)
     assert np.any((want.cig & 0xF) == 1) and np.any((want.cig & 0xF) == 2)
+
+
+def test_diagonals_around_the_second_probe_boundaries(full):
+    # The join's second bitmap probe shifts a value's slot by its bits above 17 and keeps values within e of a 2^17
+    # boundary unseen (fem_seed_dense.hip.h).  Reads with a 2-base deletion / insertion in the middle have their seeds
+    # on two diagonals two apart; here those diagonals sit at every offset -9..9 around multiples of 2^17 of the global
+    # coordinate, in three sequences, on both strands, among ordinary reads (so that the lists are long and the probe runs).
+    from tests import util
+    text, off, lens, ref, idx, dev = full
+    if dev.seed_kernel(e=3) != "seed_dense_kernel":
+        dev.build_index(12, 3, fetch=False)
+    gap = 2048  # femk::kDenseGap: goff[s] = gap + s * (len + gap)
+    special = []
+    for s in (0, 5, 23):
+        goff = gap + s * (125_000_000 + gap)
+        seq = text[int(off[s]):int(off[s]) + int(lens[s])]
+        for i in range(5):
+            g0 = ((goff + 7_000_000 + 11_111_111 * i) // 131072 + 1) * 131072
+            for delta in range(-9, 10):
+                pos = g0 + delta - goff
+                for shift in (0, 30):  # the seed's offset in the read moves the diagonal: v = G - start
+                    p0 = pos - shift
+                    dele = seq[p0:p0 + 48].tobytes() + seq[p0 + 50:p0 + 102].tobytes()
+                    ins = seq[p0:p0 + 48].tobytes() + b"GT" + seq[p0 + 48:p0 + 98].tobytes()
+                    special += [dele, util.revcomp(dele), ins, util.revcomp(ins)]
+    n = 20_000
+    bases, offs = host.synth_reads(77, text, off, lens, n, 100, 3, threads=16)
+    reads = [bases[i * 100:(i + 1) * 100].tobytes() for i in range(n)] + special
+    batch = fo.ReadBatch(reads)
+    want = fo.map_reads(ref, idx, batch, e=3, threads=16, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    got = dev.map_batch(batch.bases, batch.off, e=3)
+    o, cand, ed, end = got.per_strand()
+    assert np.array_equal(got.stats, want.stats), (got.stats, want.stats)
+    assert np.array_equal(o, want.cand_off) and np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed)
+    # nearly all of the special reads map (2 edits <= e)
+    per_read = np.add.reduceat(np.diff(want.cand_off.astype(np.int64)), np.arange(0, 2 * len(reads), 2))
+    assert (per_read[n:] > 0).mean() > 0.95
