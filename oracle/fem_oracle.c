@@ -466,7 +466,7 @@ uint32_t fo_seed_candidates(const fo_params *p, const char *seq, uint32_t len, c
   uint32_t rc = n;
   if (n > cap)
     rc = UINT32_MAX;
-  else
+  else if (n)
     memcpy(cands, s.cands.a, (size_t)n * sizeof(uint64_t));
   free(s.buf1.a);
   free(s.buf2.a);
