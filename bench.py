@@ -305,6 +305,10 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # host placement: this rank's threads and pinned buffers next to its GPU, before any thread pool exists (after torch
+    # has loaded its HIP runtime: the other order leaves torch without a device)
+    from fem_amd import device as _fem_device
+    numa_bound = _fem_device.bind_near_device(0 if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else rk.local_rank)
     # Rehearsal hooks for a one-GPU box (never set by the driver): FEM_BENCH_ONE_GPU=1 puts every rank on GPU 0,
     # FEM_BENCH_BACKEND=gloo reduces the counters over gloo instead of RCCL (RCCL refuses two ranks on one GPU).
     backend = os.environ.get("FEM_BENCH_BACKEND", "nccl")
@@ -324,7 +328,8 @@ def main():
         cores = max(1, int(os.environ["FEM_BENCH_THREADS"]))
     threads = max(1, cores // (rk.world if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else 1))
     gen_threads = max(1, min(threads, 32))
-    log("rank %d: %d host threads (affinity mask %d CPUs, cgroup quota %s)" % (rk.rank, threads, n_aff, quota))
+    log("rank %d: %d host threads (affinity mask %d CPUs%s, cgroup quota %s)" %
+        (rk.rank, threads, n_aff, ", bound to the GPU's NUMA node" if numa_bound else "", quota))
 
     extras = []
     if rk.world == 1 and args.extra != "none":

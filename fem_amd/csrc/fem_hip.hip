@@ -5,8 +5,10 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1267,6 +1269,65 @@ int fem_dbg_stamps(uint64_t *out, int n) {
   return 0;
 }
 #endif
+
+// ---- host placement ----
+// The pinned staging buffers are what the GPU's copy engines read: they should sit in the memory of the socket the GPU
+// hangs off, and so should the threads that fill them (measured on a two-socket MI355X host, FASTQ -> SAM on 16 M reads:
+// 0.30 s with the process on the GPU's node, 0.35-0.45 s unbound, 0.39-0.42 s on the other node).
+int fem_device_numa(int device, int32_t *node, char *cpulist, uint64_t cap) {
+  if (node) *node = -1;
+  if (cpulist && cap) cpulist[0] = 0;
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return FEM_ERR_HIP;
+  for (char *c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);  // sysfs spells the address in lower case
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f) return FEM_OK;  // (no sysfs: unknown, not an error)
+  int n = -1;
+  if (fscanf(f, "%d", &n) != 1) n = -1;
+  fclose(f);
+  if (node) *node = n;
+  if (n >= 0 && cpulist && cap) {
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
+    if ((f = fopen(path, "r"))) {
+      if (!fgets(cpulist, (int)std::min<uint64_t>(cap, 1u << 20), f)) cpulist[0] = 0;
+      fclose(f);
+      for (char *c = cpulist; *c; ++c)
+        if (*c == '\n') *c = 0;
+    }
+  }
+  return FEM_OK;
+}
+
+int fem_bind_thread_near_device(int device) {
+  const char *env = getenv("FEM_NUMA_BIND");
+  if (env && env[0] == '0') return 1;
+  int32_t node = -1;
+  std::vector<char> list(4096, 0);
+  if (fem_device_numa(device, &node, list.data(), list.size()) != FEM_OK || node < 0 || !list[0]) return 1;
+  cpu_set_t now, want;
+  CPU_ZERO(&now);
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof now, &now) != 0) return 1;
+  int n_set = 0;
+  for (const char *c = list.data(); *c;) {  // "a-b,c,d-e"
+    char *end = nullptr;
+    const long lo = strtol(c, &end, 10);
+    if (end == c) break;
+    long hi = lo;
+    if (*end == '-') hi = strtol(end + 1, &end, 10);
+    for (long i = lo; i <= hi && i < CPU_SETSIZE; ++i)
+      if (i >= 0 && CPU_ISSET((int)i, &now)) {
+        CPU_SET((int)i, &want);
+        ++n_set;
+      }
+    if (*end != ',') break;
+    c = end + 1;
+  }
+  if (n_set == 0) return 1;  // the node's CPUs are not ours to run on: leave the thread where it is
+  return sched_setaffinity(0, sizeof want, &want) == 0 ? 0 : 1;
+}
 
 int fem_dev_allreduce_stats(fem_dev *const *hs, int n, uint64_t *stats) {
   if (!hs || n <= 0 || !stats) return FEM_ERR_INVALID;

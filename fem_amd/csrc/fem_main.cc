@@ -127,6 +127,7 @@ int index_main(int argc, char **argv) {
     usage_index();
     exit(EXIT_FAILURE);
   }
+  (void)fem_bind_thread_near_device(0);  // host threads and buffers next to the GPU (FEM_NUMA_BIND=0: leave them alone)
   Reference ref;
   if (!ref.load(ref_path)) exit(EXIT_FAILURE);
   fem_dev *h = nullptr;
@@ -289,6 +290,11 @@ int map_main(int argc, char **argv) {
     exit(EXIT_FAILURE);
   }
 
+  // Host placement: with one GPU the whole process (parser, formatter, staging buffers) moves next to it, before any
+  // thread pool exists; with several, each GPU's worker thread does so for itself and the buffers it acquires.
+  const char *sg = getenv("FEM_TEST_SHARE_GPU");
+  const bool share_gpu = sg && sg[0] == '1';
+  if (n_gpus == 1 || share_gpu) (void)fem_bind_thread_near_device(0);
   Reference ref;
   if (!ref.load(ref_path)) exit(EXIT_FAILURE);
   double t_idx = real_time();
@@ -308,13 +314,12 @@ int map_main(int argc, char **argv) {
   std::vector<fem_dev *> devs((size_t)n_gpus, nullptr);
   // FEM_TEST_SHARE_GPU=1 (test hook for one-GPU boxes): all `--gpus N` workers open GPU 0, each with its own handle, and
   // the counters are summed on the host (RCCL refuses two ranks on one device)
-  const char *sg = getenv("FEM_TEST_SHARE_GPU");
-  const bool share_gpu = sg && sg[0] == '1';
   {  // one thread per GPU uploads the replicated reference + index (src/FEM_map.c:135-143)
     std::vector<int> up_rc((size_t)n_gpus, 0);
     std::vector<std::thread> up;
     for (int g = 0; g < n_gpus; ++g)
       up.emplace_back([&, g] {
+        if (n_gpus > 1 && !share_gpu) (void)fem_bind_thread_near_device(g);  // the handle's pinned result buffers
         int rc = fem_dev_open(share_gpu ? 0 : g, &devs[(size_t)g]);
         if (!rc) rc = ref.upload(devs[(size_t)g]);
         if (!rc) rc = fem_dev_upload_index(devs[(size_t)g], ik, istep, lookup, ((uint64_t)1 << (2 * ik)) + 1, occ, n_occ);
@@ -445,6 +450,7 @@ int map_main(int argc, char **argv) {
   for (int g = 0; g < n_gpus; ++g)
     workers.emplace_back([&, g] {
       fem_dev *h = devs[(size_t)g];
+      if (n_gpus > 1 && !share_gpu) (void)fem_bind_thread_near_device(g);
       auto acquire = [&](BatchBuf *b, uint64_t reads_cap, uint64_t bases_cap) -> bool {
         char *pb = nullptr;
         uint64_t *po = nullptr;

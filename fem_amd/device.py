@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
+    "fem_device_numa", "fem_bind_thread_near_device",
     "fem_dev_allreduce_stats",
 ]
 
@@ -91,8 +92,25 @@ def load_hip():
     L.fem_dev_copy_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_h2d_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_allreduce_stats.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.fem_device_numa.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_char_p, u64]
+    L.fem_bind_thread_near_device.argtypes = [C.c_int]
     _HIP = L
     return L
+
+
+def device_numa(device=0):
+    """(NUMA node of the host memory next to GPU `device` or -1, that node's CPUs as a cpulist string)."""
+    node = C.c_int32(-1)
+    buf = C.create_string_buffer(4096)
+    rc = load_hip().fem_device_numa(int(device), C.byref(node), buf, 4096)
+    if rc != 0:
+        raise FemError("fem_device_numa: %d" % rc)
+    return node.value, buf.value.decode()
+
+
+def bind_near_device(device=0):
+    """Restricts the calling thread (and the threads it starts later) to the CPUs next to GPU `device`; True if bound."""
+    return load_hip().fem_bind_thread_near_device(int(device)) == 0
 
 
 def _copy(ptr, n, dtype, copy=True):

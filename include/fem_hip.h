@@ -184,6 +184,15 @@ int fem_dev_copy_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per
 /* Achieved pinned-host-to-device bandwidth in GB/s (what bounds the read stream). */
 int fem_dev_h2d_bandwidth(fem_dev *h, uint64_t bytes, int iters, double *gb_per_s);
 
+/* ---- host placement (new; the reference leaves its threads to the scheduler, src/FEM_map.c:172-198) ---- */
+/* NUMA node of the host memory GPU `device` is attached to (-1 if the system does not say) and that node's CPUs
+ * as a Linux cpulist ("64-127,192-255").  Needs no handle. */
+int fem_device_numa(int device, int32_t *node, char *cpulist, uint64_t cap);
+/* Restricts the CALLING thread (and the threads it creates afterwards) to those CPUs, so that the pinned staging
+ * buffers and the threads that fill them sit next to the GPU.  0 = bound; 1 = nothing done (unknown topology, none of
+ * the node's CPUs allowed to this process, or FEM_NUMA_BIND=0).  Call it before the first fem_dev_open on a thread. */
+int fem_bind_thread_near_device(int device);
+
 /* ---- multi-GPU (replaces the thread reduction src/FEM_map.c:200-212) ---- */
 /* Sums the five MappingStats counters of n handles (one per GPU of this
  * process) with one RCCL all-reduce; stats is n x 5, reduced in place.  The

@@ -1,6 +1,8 @@
 """The zero-copy read stream of the C ABI (fem_dev_acquire_stage / fem_dev_commit_stage, include/fem_hip.h) against the
 copying form (fem_dev_stage_reads) and the oracle, and the device pipeline bench.py times (several slots in flight).
 Reference shape: the reusable SequenceBatch ring of src/input_queue.c:34-79.  Needs a GPU: -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,3 +112,37 @@ def test_staging_errors_are_reported_not_fatal(setup):
     dev.map_staged(e=3, slot=0)
     want = fo.map_reads(ref, idx, fo.ReadBatch(reads), e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
     assert np.array_equal(dev.fetch_stats(slot=0), want.stats)
+
+
+def test_host_placement_next_to_the_gpu():
+    # fem_device_numa / fem_bind_thread_near_device: the calling thread ends up on a subset of its CPUs, all of them on
+    # the GPU's node; FEM_NUMA_BIND=0 turns it off.  (In a child process: the binding is inherited by later threads.)
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+from fem_amd import device
+before = os.sched_getaffinity(0)
+node, cpus = device.device_numa(0)
+os.environ["FEM_NUMA_BIND"] = "0"
+assert device.bind_near_device(0) is False and os.sched_getaffinity(0) == before
+del os.environ["FEM_NUMA_BIND"]
+bound = device.bind_near_device(0)
+after = os.sched_getaffinity(0)
+assert after <= before
+if node >= 0 and cpus:
+    want = set()
+    for part in cpus.split(","):
+        lo, _, hi = part.partition("-")
+        want |= set(range(int(lo), int(hi or lo) + 1))
+    if want & before:
+        assert bound and after == want & before, (node, cpus, sorted(after)[:4])
+    else:
+        assert not bound and after == before
+else:
+    assert not bound and after == before
+print("ok", node, cpus, len(before), len(after))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith(b"ok"), r.stderr.decode()
