@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr int kSlots = 4;
+#ifndef FEM_SLOTS
+#define FEM_SLOTS 4
+#endif
+constexpr int kSlots = FEM_SLOTS;
 constexpr uint32_t kMaxReadLen = 1024;
 constexpr size_t kFrontPad = 16;  // kernels fetch a reverse-strand chunk from up to 15 bytes in front of a read
 constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;

@@ -13,6 +13,7 @@
 #include <sys/resource.h>
 #include <sys/time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -363,7 +364,10 @@ int map_main(int argc, char **argv) {
   // -t threads are shared by the two host stages that run side by side (FEM_SPLIT_THREADS=0: each gets all of them)
   const char *sp_env = getenv("FEM_SPLIT_THREADS");
   const bool split = !(sp_env && sp_env[0] == '0') && n_threads >= 4;
-  const int rd_threads = split ? (n_threads + 1) / 2 : n_threads, fmt_threads = split ? n_threads / 2 : n_threads;
+  int rd_share = 50;  // per cent of the threads that parse (FEM_READER_SHARE)
+  if (const char *rs = getenv("FEM_READER_SHARE")) rd_share = std::min(90, std::max(10, atoi(rs)));
+  const int rd_threads = split ? std::max(1, std::min(n_threads - 1, (n_threads * rd_share + 50) / 100)) : n_threads;
+  const int fmt_threads = split ? n_threads - rd_threads : n_threads;
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
   int32_t n_slots = 4;
   (void)fem_dev_limits(devs[0], nullptr, &n_slots);
@@ -373,6 +377,8 @@ int map_main(int argc, char **argv) {
   const char *ht = getenv("FEM_HOST_TAIL");
   const bool host_tail = ht && ht[0] == '1';
   double busy_read = 0, busy_text = 0, busy_write = 0;
+  double wait_slot = 0, wait_records = 0, wait_text_buf = 0;  // reader waiting for a free slot, formatter for records / a text buffer
+  std::vector<double> busy_submit((size_t)n_gpus, 0.0), busy_recycle((size_t)n_gpus, 0.0);
   double t_first_slot = 0, t_first_filled = 0, t_reader_done = 0, t_workers_done = 0;
   std::vector<double> busy_wait((size_t)n_gpus, 0.0);
   std::atomic<uint64_t> n_asserted{0};
@@ -407,10 +413,14 @@ int map_main(int argc, char **argv) {
   // ---- formatter: records -> SAM text (src/align.c:546-632, src/output_queue.c:93-116) ----
   std::thread formatter([&] {
     for (;;) {
+      const double t_pop = real_time();
       BatchBuf *b = text_q.pop();
       if (!b) break;
-      double t0 = real_time();
+      const double t_got = real_time();
+      wait_records += t_got - t_pop;
       TextOut *t = text_free_q.pop();
+      double t0 = real_time();
+      wait_text_buf += t0 - t_got;
       fem_seqset reads{};
       reads.n = b->shape.n_reads, reads.bases = b->bases, reads.off = b->off, reads.quals = b->quals.p, reads.names = b->names.p;
       reads.name_off = (uint64_t *)b->name_off.p;
@@ -441,7 +451,7 @@ int map_main(int argc, char **argv) {
       }
       write_q.push(t);
       fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - b->t_submit);
-      work_q[(size_t)b->gpu].push(Msg{kRecycle, b});  // the slot is free again once its GPU's thread has re-acquired it
+      free_q.push(b);  // fetched and rendered: the staging buffers may be refilled (they stay acquired, include/fem_hip.h)
     }
   });
 
@@ -496,7 +506,9 @@ int map_main(int argc, char **argv) {
         }
         if (m.kind == kStop) break;
         if (m.kind == kRecycle) {
+          const double t0 = real_time();
           if (!acquire(m.b, m.b->reads_cap, m.b->bases_cap)) m.b->bases = nullptr;
+          busy_recycle[(size_t)g] += real_time() - t0;
           free_q.push(m.b);
           continue;
         }
@@ -517,6 +529,7 @@ int map_main(int argc, char **argv) {
           work_q[(size_t)g].push(Msg{kRecycle, b});
           continue;
         }
+        busy_submit[(size_t)g] += real_time() - b->t_submit;
         flight.push_back(b);
         while (flight.size() > 2) retire();  // two batches in flight per GPU
       }
@@ -524,16 +537,19 @@ int map_main(int argc, char **argv) {
     });
 
   // ---- reader (src/input_queue.c:53-79): this thread ----
+  fem_seqfile *read_file = nullptr;
   {
-    fem_seqfile *f = fem_seqfile_open(read_path);
+    fem_seqfile *f = read_file = fem_seqfile_open(read_path);
     if (!f) {
       fprintf(stderr, "Cannot find sequence file!");  // the reference exits here (src/sequence_batch.c:33-35)
       exit_code = EXIT_FAILURE;
     }
     while (f && !exit_code) {
+      const double t_pop = real_time();
       BatchBuf *b = free_q.pop();
       if (!b->bases) break;  // its GPU could not provide staging buffers (reported by the worker)
       double t0 = real_time();
+      wait_slot += t0 - t_pop;
       if (t_first_slot == 0) t_first_slot = t0;
       fem_batch_plan *plan = nullptr;
       int rc = fem_seqfile_plan(f, batch_bytes, rd_threads, &plan, &b->shape);
@@ -577,7 +593,8 @@ int map_main(int argc, char **argv) {
       if (t_first_filled == 0) t_first_filled = real_time();
       work_q[(size_t)b->gpu].push(Msg{kFilled, b});
     }
-    if (f) fem_seqfile_close(f);
+    // (the file stays open until the mapping phase is over: unmapping 4 GB of faulted-in pages takes 0.08 s, which the GPUs
+    // would otherwise spend waiting for their stop message)
     t_reader_done = real_time();
   }
   for (int g = 0; g < n_gpus; ++g) work_q[(size_t)g].push(Msg{kStop, nullptr});
@@ -590,14 +607,18 @@ int map_main(int argc, char **argv) {
   if (stage_times) {
     double bw = 0;
     for (double x : busy_wait) bw += x;
+    double bs = 0, br = 0;
+    for (double x : busy_submit) bs += x;
+    for (double x : busy_recycle) br += x;
     fprintf(stderr, "[FEM] stage busy seconds: reader %.3f, device wait %.3f, SAM text %.3f, writer %.3f\n", busy_read, bw,
             busy_text, busy_write);
+    fprintf(stderr, "[FEM] waiting seconds: reader for a free slot %.3f, formatter for records %.3f and for a text buffer %.3f; "
+                    "GPU threads: submit %.3f, slot recycling %.3f\n", wait_slot, wait_records, wait_text_buf, bs, br);
     fprintf(stderr, "[FEM] timeline (s after the mapping phase began): first staging slot %.3f, first batch parsed %.3f, input read %.3f, "
                     "devices done %.3f, output written %.3f\n", t_first_slot - t_start, t_first_filled - t_start, t_reader_done - t_start,
             t_workers_done - t_start, real_time() - t_start);
   }
   if (close(out_fd) != 0 && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
-  for (TextOut &t : texts) free(t.buf);
   if (n_asserted)
     fprintf(stderr, "[FEM] %lu records on which the reference would have tripped an assertion (src/align.c:366-368) were "
                     "written with CIGAR *\n", (unsigned long)n_asserted.load());
@@ -613,6 +634,8 @@ int map_main(int argc, char **argv) {
   uint64_t totals[5];
   for (int i = 0; i < 5; ++i) totals[i] = per_gpu[(size_t)i];
   const double t_mapping = real_time() - t_start;  // (the reference's timer stops after the counter reduction, src/FEM_map.c:219)
+  for (TextOut &t : texts) free(t.buf);
+  if (read_file) fem_seqfile_close(read_file);
   for (fem_dev *h : devs) fem_dev_close(h);
   if (exit_code) return exit_code;
   fprintf(stderr, "The number of read: %lu\n", (unsigned long)totals[0]);

@@ -144,6 +144,8 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads);
  * batch straight into them, commit starts the asynchronous H2D copy and returns at once.
  *   acquire: waits until the slot is idle, grows the buffers to n_reads_cap + 1 offsets and n_bases_cap
  *            characters (+ 64 bytes of slack the caller may overrun), returns them; valid until the next acquire.
+ *            Once the slot's batch has been fetched (fem_dev_fetch*, fem_dev_sync) the same buffers may be
+ *            refilled and committed again without another acquire.
  *   commit:  the batch is complete: n_reads reads, offsets[0] == 0, offsets ascending, offsets[n_reads]
  *            characters, longest read max_len (the parser knows it; no per-read host work happens here).
  *            A wrong max_len / offset table is the caller's bug: the kernels trust them. */
