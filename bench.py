@@ -7,10 +7,13 @@ N > 1: bench.py starts its N ranks itself (children made before anything touches
 it is already under torch.distributed.run (RANK / WORLD_SIZE in the environment).  One rank per GPU.
 
 One step = one batch of `--batch` (2.5 M) synthetic reads through the DEVICE PIPELINE of libfemhip.so:
-    library-owned pinned host staging --H2D--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
+    the caller's batch in ordinary host memory --fem_dev_map_batch_submit: packed to 2 bits per base into pinned
+    staging by the library's host threads, H2D, expanded--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
 with three batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
-`value` is that rate.  The kernels alone, replayed on a batch already resident in HBM (what round 1 reported), are
-`config.kernel_only_mreads`; the end-to-end command line (FASTQ -> SAM) is `e2e_cli`.
+`value` is that rate; `pipeline_by_workload[*].zero_copy_ascii_mreads` is the same pipeline fed from batches that
+already sit in pinned staging as characters (the parser's zero-copy form; bound by the PCIe link at C2).  The kernels
+alone, replayed on a batch already resident in HBM (what round 1 reported), are `config.kernel_only_mreads`; the
+end-to-end command line (FASTQ -> SAM) is `e2e_cli`.
 
 Workloads (BASELINE.json `configs`):
     c2   5 Mbp reference, 100 bp reads, e=3        the configuration the metric is quoted on: `value`, all N
@@ -97,13 +100,13 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     w = WORKLOADS[key]
     L, e, a, k, step = w["L"], w["e"], 1, 12, 3
     text, off, lens = data
-    # a different batch in every slot, generated straight into the library's pinned staging buffers
+    # a different batch for every slot, in ordinary (pageable) host memory: what a caller of the C ABI owns
     t0 = time.time()
+    batches = []
     for s in range(N_SLOTS):
-        hb, ho = dev.acquire_stage(batch, batch * L + 8, slot=s)
-        host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=(rk.rank * N_SLOTS + s) * batch,
-                         threads=threads, out=hb, out_offsets=ho)
-    log("rank %d %s: %d x %d reads generated into pinned staging in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
+        b, o = host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=(rk.rank * N_SLOTS + s) * batch, threads=threads)
+        batches.append((b, o))
+    log("rank %d %s: %d x %d reads generated in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
 
     def fence():
         if rk.world > 1:
@@ -111,14 +114,21 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         torch.cuda.synchronize()
 
     d2h_bytes = [0]
+    form = ["stage_reads"]
 
     def submit(i):
         s = i % N_SLOTS
-        dev.commit_stage(batch, L, slot=s, uniform=True)  # asynchronous H2D of the slot's batch (reads of one length: no offsets)
+        if form[0] == "stage_reads":
+            # fem_dev_map_batch_submit (include/fem_hip.h): the caller's batch is packed to two bits per base into the slot's
+            # pinned staging by the library's host threads, sent, expanded on the device; everything behind it asynchronous
+            dev.stage_reads(batches[s][0], batches[s][1], slot=s)
+        else:
+            # zero-copy form: the batch already sits in the slot's pinned staging as characters (a parser wrote it there)
+            dev.commit_stage(batch, L, slot=s, uniform=True)
         dev.map_staged(e=e, a=a, k=k, step=step, slot=s)
 
     def retire(i):
-        r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits, D2H of the per-candidate outcome into pinned memory
+        r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
         d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
         return r.stats
 
@@ -136,6 +146,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         return tot, last
 
     pipeline(max(warmup, 1))
+    h2d_bytes, sent_packed = dev.stage_info(0)
     stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
     dev.set_timing(True)
     dev.reset_timing()
@@ -155,11 +166,28 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         elapsed = float(tmax.item())
     kt = {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}
 
+    # the zero-copy form, for comparison (the staging buffers held the packed batches until now)
+    form[0] = "acquire_commit"
+    for s in range(N_SLOTS):
+        hb, ho = dev.acquire_stage(batch, batch * L + 8, slot=s)
+        hb[:batch * L] = batches[s][0][:batch * L]
+        ho[:batch + 1] = batches[s][1]
+    pipeline(N_SLOTS + 2)  # (every slot's buffers exist after this)
+    fence()
+    tz = time.perf_counter()
+    n_z = max(4, min(steps, 10))
+    pipeline(n_z)
+    fence()
+    zero_copy = batch * n_z / (time.perf_counter() - tz) / 1e6
+    h2d_zero_copy = dev.stage_info(0)[0]
+
     # the kernels alone on a batch already resident in HBM (slot 0 as staged by the last pipeline step that used it)
+    n_rep = 3
+    dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
+    dev.fetch_stats(slot=0)  # (from here on nothing but the counters comes back: no result arrays behind the kernels)
     dev.reset_timing()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n_rep = 3
     for _ in range(n_rep):
         dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
         dev.fetch_stats(slot=0)
@@ -200,7 +228,8 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "workload": w["name"], "value": round(value, 3), "ms_per_step": round(elapsed * 1e3 / steps, 3), "steps": steps,
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
-        "h2d_bytes_per_step": batch * L, "d2h_bytes_per_step": d2h_bytes[0],
+        "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_bytes[0],
+        "zero_copy_ascii_mreads": round(zero_copy, 3), "zero_copy_h2d_bytes_per_step": int(h2d_zero_copy),
         "counters": {"reads": int(job[0]), "mapped_reads": int(job[1]), "pre_filter": int(job[2]),
                      "candidates": int(job[3]), "mappings": int(job[4])},
         "counters_last_step_per_gpu": [int(x) for x in last_stats],
@@ -369,7 +398,7 @@ def main():
             if not bw:
                 bw = {"device_copy_gbs": round(dev.copy_bandwidth(1 << 30, 10), 1), "pinned_h2d_gbs": round(dev.h2d_bandwidth(1 << 28, 8), 1)}
         text, off, lens, n_occ = data_cache[ref_key]
-        steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, 1)
+        steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, N_SLOTS + 1)  # (every slot warm)
         res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads)
         res["index_entries"] = n_occ
         results[key] = res
@@ -382,6 +411,7 @@ def main():
         return
 
     head = results[args.workload]
+    stage_threads = int(os.environ.get("FEM_STAGE_THREADS", "12"))
     roof_key = "c3" if "c3" in results else args.workload
     out = {
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
@@ -389,14 +419,16 @@ def main():
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic",
         "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline")},
-                       value_is="device pipeline: pinned host staging -> H2D -> kernels -> D2H of fem_batch_result, %d batches in flight, "
-                                "a different batch per slot" % DEPTH,
+                       value_is="device pipeline: caller-owned batch in host memory -> fem_dev_map_batch_submit (2-bit packing into pinned "
+                                "staging on %d host threads, H2D, expansion) -> kernels -> D2H of fem_batch_result, %d batches in "
+                                "flight, a different batch per slot" % (stage_threads, DEPTH),
                        parallelism="reads sharded x%d, index replicated" % rk.world, bandwidths=bw),
         "roofline": dict(results[roof_key]["roofline"], workload=roof_key),
         "roofline_by_workload": {k_: v_["roofline"] for k_, v_ in results.items()},
         "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
                                                            "reads_per_step_per_gpu", "kernel_ms_per_launch", "counters_last_step_per_gpu",
-                                                           "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "d2h_bytes_per_step")}
+                                                           "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step",
+                                                           "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step")}
                                  for k_, v_ in results.items()},
     }
     if not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0:

@@ -6,12 +6,17 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <sched.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -57,6 +62,14 @@ struct Slot {
   uint64_t *h_off = nullptr;
   size_t h_off_cap = 0;
   uint64_t acq_reads = 0, acq_bases = 0;  // what the last fem_dev_acquire_stage asked for
+  uint8_t *d_packed = nullptr;            // packed transfer (fem_dev_stage_reads): 2-bit codes + positions of other characters
+  size_t packed_cap = 0;
+  // fem_dev_fetch callers get the result arrays sent home behind the kernels, without the host waiting for the batch first:
+  // the per-read arrays whole, the per-candidate arrays up to what the slot's previous batch needed (the rest at fetch)
+  bool prefetch_results = false, staged_by_copy = false;
+  uint64_t prefetched_reads2 = 0, prefetched_cand = 0, last_n_cand = 0;
+  uint64_t h2d_bytes = 0;                 // what the last staging sent over the link
+  bool sent_packed = false;
   // outputs on the device
   uint64_t *d_cand = nullptr;
   uint32_t *d_meta = nullptr;
@@ -96,8 +109,83 @@ static_assert(kCtlBytes <= kCtlWorkCursor, "control block layout");
 
 }  // namespace
 
+namespace {
+// The host threads of fem_dev_stage_reads: created once per handle and parked between batches (a batch every few ms:
+// starting and joining a dozen threads per batch cost more than the packing gained, and under a cgroup CPU quota the
+// short-lived threads, scattered over the machine's CPUs, had the whole process throttled now and then).
+class StagePool {
+ public:
+  ~StagePool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  // work(t) for t in [0, n): t = 0 on the calling thread, the rest on the pool
+  void run(unsigned n, const std::function<void(unsigned)> &work) {
+    if (n <= 1) return work(0u);
+    {
+      std::lock_guard<std::mutex> l(m_);
+      while (threads_.size() + 1 < n) {
+        const unsigned id = (unsigned)threads_.size() + 1;
+        threads_.emplace_back([this, id] { loop(id); });
+      }
+      work_ = &work, n_ = n, pending_ = n - 1, ++epoch_;
+    }
+    cv_.notify_all();
+    work(0u);
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [&] { return pending_ == 0; });
+    work_ = nullptr;
+  }
+
+ private:
+  void loop(unsigned id) {
+    if (const char *e = getenv("FEM_STAGE_PIN")) {  // experiment: worker i on the i-th CPU this process may use
+      if (e[0] == '1') {
+        cpu_set_t now, one;
+        CPU_ZERO(&now);
+        CPU_ZERO(&one);
+        if (sched_getaffinity(0, sizeof now, &now) == 0) {
+          unsigned k = 0;
+          for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &now) && k++ == id) {
+              CPU_SET(c, &one);
+              (void)sched_setaffinity(0, sizeof one, &one);
+              break;
+            }
+        }
+      }
+    }
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)> *w = nullptr;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || (epoch_ != seen && id < n_); });
+        if (stop_) return;
+        seen = epoch_, w = work_;
+      }
+      (*w)(id);
+      std::lock_guard<std::mutex> l(m_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;
+  const std::function<void(unsigned)> *work_ = nullptr;
+  unsigned n_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 struct fem_dev {
   int device = 0;
+  StagePool *stage_pool = nullptr;  // host threads of fem_dev_stage_reads
   int n_cu = 256;
   std::string err;
   // index
@@ -614,6 +702,25 @@ int launch_batch(fem_dev *h, Slot &s) {
     h->have_kernels_done = true;
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
+  s.prefetched_reads2 = 0, s.prefetched_cand = 0;
+  static const bool no_prefetch = [] { const char *e = getenv("FEM_NO_PREFETCH"); return e && e[0] == '1'; }();
+  // (only behind fem_dev_stage_reads, whose caller packs the next batch in the meantime; a caller of the zero-copy form is
+  // idle until it fetches, and the extra traffic next to its four-times-larger H2D cost 5 % there)
+  if (s.prefetch_results && s.staged_by_copy && !no_prefetch) {
+    const size_t n2 = (size_t)s.n_reads * 2;
+    if (n2 && s.h_begin && n2 <= s.h_per_read_cap) {
+      HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+      HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d_count, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+      s.prefetched_reads2 = n2;
+    }
+    const size_t guess = std::min<size_t>({(size_t)(s.last_n_cand + s.last_n_cand / 32 + 1024), s.h_cand_cap, (size_t)s.cand_cap});
+    if (s.last_n_cand && s.h_cand && guess) {
+      HIP_TRY(h, hipMemcpyAsync(s.h_cand, s.d_cand, guess * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
+      HIP_TRY(h, hipMemcpyAsync(s.h_ed, s.d_ed, guess * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
+      HIP_TRY(h, hipMemcpyAsync(s.h_end, s.d_end, guess * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+      s.prefetched_cand = guess;
+    }
+  }
   s.mapped = true;
   s.synced = false;
   return FEM_OK;
@@ -709,6 +816,72 @@ int check_slot(fem_dev *h, int slot) {
   return FEM_OK;
 }
 
+
+// ---- packed read transfer: host side (the device side is unpack_reads_kernel) ----
+// Two bits per base, four bases per byte, low bits first.  Only the characters A C G T are packed; every other byte
+// (lower case, N, anything) becomes code 0 and goes to `exc` as index << 8 | byte, so that the device gets the batch back
+// byte for byte: the seed and verification kernels see codes (src/utils.h:72-73), but the traceback compares characters
+// (src/align.c:289-300, :344-366) and a lower-case read takes the reference's assertion path there.
+// `first_index` is the batch-wide index of src[0].
+inline uint32_t code2(uint8_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }  // A C G T -> 0 1 2 3
+inline bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+void pack_scalar(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index, std::vector<uint64_t> &exc) {
+  for (uint64_t i = 0; i < n; i += 4) {
+    uint32_t b = 0;
+    for (uint32_t q = 0; q < 4 && i + q < n; ++q) {
+      const uint8_t c = src[i + q];
+      if (is_acgt(c)) b |= code2(c) << (2u * q);
+      else exc.push_back(((first_index + i + q) << 8) | c);
+    }
+    dst[i >> 2] = (uint8_t)b;
+  }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void pack_avx2(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index,
+                                               std::vector<uint64_t> &exc) {
+  const __m256i three = _mm256_set1_epi8(3);
+  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+  const __m256i w1 = _mm256_set1_epi16(0x0401), w2 = _mm256_set1_epi32(0x00100001);
+  const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1,
+                                        -1, -1, -1, -1, -1, -1, -1);
+  const __m256i gather = _mm256_setr_epi32(0, 4, 1, 1, 1, 1, 1, 1);
+  uint64_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, cA), _mm256_cmpeq_epi8(v, cC)),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, cG), _mm256_cmpeq_epi8(v, cT)));
+    // (16-bit shifts: what crosses a byte border lands in bits 6-7 and is masked off)
+    __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+    code = _mm256_and_si256(code, ok);
+    const __m256i pairs = _mm256_maddubs_epi16(code, w1);  // c0 + 4 c1 per 16 bits
+    const __m256i quads = _mm256_madd_epi16(pairs, w2);    // + 16 (c2 + 4 c3) per 32 bits: the packed byte
+    const __m256i bytes = _mm256_permutevar8x32_epi32(_mm256_shuffle_epi8(quads, pick), gather);
+    _mm_storel_epi64((__m128i *)(dst + (i >> 2)), _mm256_castsi256_si128(bytes));
+    uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok);
+    while (bad) {
+      const uint64_t at = i + (uint64_t)__builtin_ctz(bad);
+      exc.push_back(((first_index + at) << 8) | src[at]);
+      bad &= bad - 1;
+    }
+  }
+  if (i < n) pack_scalar(src + i, n - i, dst + (i >> 2), first_index + i, exc);
+}
+#endif
+void pack_bases(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index, std::vector<uint64_t> &exc) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return pack_avx2(src, n, dst, first_index, exc);
+#endif
+  pack_scalar(src, n, dst, first_index, exc);
+}
+
+unsigned stage_threads(uint64_t n_reads) {
+  unsigned want = 12;  // (measured on the GPU box's 16-core share: 8 -> 12 threads still gains, 16 does not)
+  if (const char *e = getenv("FEM_STAGE_THREADS")) want = (unsigned)std::max(1, atoi(e));
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(hw ? hw : 1), (uint64_t)want, n_reads / 65536 + 1}));
+}
+
 }  // namespace
 
 extern "C" {
@@ -775,11 +948,13 @@ int fem_dev_close(fem_dev *h) {
   }
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  delete h->stage_pool;
+  h->stage_pool = nullptr;
   for (auto &s : h->slot) {
     drain_timing(h, s);
     for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
-                    (void *)s.d_arena, (void *)s.d_slow})
+                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_packed})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
                     (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off})
@@ -943,6 +1118,7 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
   if (n_reads) HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
   s.n_reads = n_reads, s.n_bases = n_bases, s.max_len = max_len;
   s.staged = true, s.mapped = false, s.synced = false;
+  s.h2d_bytes = n_bases + (n_reads ? (n_reads + 1) * sizeof(uint64_t) : 0), s.sent_packed = false, s.staged_by_copy = false;
   return FEM_OK;
 }
 
@@ -964,6 +1140,7 @@ int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_
   HIP_TRY(h, hipGetLastError());
   s.n_reads = n_reads, s.n_bases = n_bases, s.max_len = read_len;
   s.staged = true, s.mapped = false, s.synced = false;
+  s.h2d_bytes = n_bases, s.sent_packed = false, s.staged_by_copy = false;
   return FEM_OK;
 }
 
@@ -979,14 +1156,17 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   char *hb = nullptr;
   uint64_t *ho = nullptr;
   if ((rc = fem_dev_acquire_stage(h, slot, n, n_bases, &hb, &ho))) return rc;
-  // copy + check in a few host threads: relative offsets, longest read, order
-  const unsigned hw = std::thread::hardware_concurrency();
-  const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(hw ? hw : 1), 8ull, n / 65536 + 1}));
-  std::vector<uint32_t> t_max(n_thr, 0);
+  Slot &s = h->slot[slot];
+  const unsigned n_thr = stage_threads(n);
+  if (!h->stage_pool) h->stage_pool = new (std::nothrow) StagePool();
+  if (!h->stage_pool) return fail(h, FEM_ERR_NOMEM, "out of host memory");
+  auto run_threads = [&](unsigned nt, const std::function<void(unsigned)> &work) { h->stage_pool->run(nt, work); };
+  // ---- pass 1 (a few host threads): order, longest and shortest read ----
+  std::vector<uint32_t> t_max(n_thr, 0), t_min(n_thr, 0xFFFFFFFFu);
   std::atomic<int> bad{0};
-  auto work = [&](unsigned t) {
+  run_threads(n_thr, [&](unsigned t) {
     const uint64_t r_lo = n * t / n_thr, r_hi = n * (t + 1) / n_thr;
-    uint32_t mx = 0;
+    uint32_t mx = 0, mn = 0xFFFFFFFFu;
     for (uint64_t i = r_lo; i < r_hi; ++i) {
       const uint64_t o0 = reads->offsets[i], o1 = reads->offsets[i + 1];
       if (o1 < o0) {
@@ -998,27 +1178,86 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
         bad.store(2);
         return;
       }
-      mx = std::max<uint32_t>(mx, (uint32_t)len);
-      ho[i] = o0 - base0;
+      mx = std::max<uint32_t>(mx, (uint32_t)len), mn = std::min<uint32_t>(mn, (uint32_t)len);
     }
-    if (r_hi == n) ho[n] = reads->offsets[n] - base0;
-    if (r_hi > r_lo) memcpy(hb + (reads->offsets[r_lo] - base0), reads->bases + reads->offsets[r_lo], reads->offsets[r_hi] - reads->offsets[r_lo]);
-    t_max[t] = mx;
-  };
-  if (n_thr == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
-    for (auto &th : pool) th.join();
-  }
-  if (n == 0) ho[0] = 0;
+    t_max[t] = mx, t_min[t] = mn;
+  });
   if (bad.load() == 1) return fail(h, FEM_ERR_INVALID, "read offsets must be ascending");
   if (bad.load() == 2)
     return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
-  uint32_t max_len = 0;
-  for (uint32_t m : t_max) max_len = std::max(max_len, m);
-  return fem_dev_commit_stage(h, slot, n, max_len);
+  uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
+  for (unsigned t = 0; t < n_thr; ++t) max_len = std::max(max_len, t_max[t]), min_len = std::min(min_len, t_min[t]);
+  // ---- reads of one length: two bits per base cross the link instead of eight ----
+  const char *np = getenv("FEM_NO_PACK");
+  if (n && min_len == max_len && max_len > 0 && n_bases < 0xFFFFFFF0ull && !(np && np[0] == '1')) {
+    const uint32_t len = max_len, bpr = (len + 3u) / 4u;
+    const uint64_t code_bytes = (n * bpr + 7u) & ~7ull;
+    const uint64_t exc_cap = (n_bases + 64 - std::min<uint64_t>(code_bytes, n_bases + 64)) / 5u;  // what is left of the staging buffer
+    std::vector<std::vector<uint64_t>> exc(n_thr);
+    const uint8_t *src = (const uint8_t *)reads->bases + base0;
+    // (pieces of 32 Ki reads handed out as the threads ask for them: one thread held up by the host's other tenants
+    // holds up its piece, not a twelfth of the batch)
+    constexpr uint64_t kPiece = 32768;
+    std::atomic<uint64_t> next_piece{0};
+    run_threads(n_thr, [&](unsigned t) {
+      for (;;) {
+        const uint64_t r_lo = next_piece.fetch_add(1, std::memory_order_relaxed) * kPiece;
+        if (r_lo >= n) break;
+        const uint64_t r_hi = std::min(n, r_lo + kPiece);
+        if ((len & 3u) == 0u) {  // no padding: the piece's reads are one stream
+          pack_bases(src + r_lo * len, (r_hi - r_lo) * len, (uint8_t *)hb + r_lo * bpr, r_lo * len, exc[t]);
+        } else {
+          for (uint64_t i = r_lo; i < r_hi; ++i) pack_bases(src + i * len, len, (uint8_t *)hb + i * bpr, i * len, exc[t]);
+        }
+      }
+    });
+    uint64_t n_exc = 0;
+    for (const auto &v : exc) n_exc += v.size();
+    if (n_exc <= exc_cap && n_exc <= n_bases / 16u) {  // (more than that and the characters themselves are the smaller message)
+      // codes | positions (uint32 each) | the bytes that belong there
+      uint32_t *he = (uint32_t *)(hb + code_bytes);
+      uint8_t *hc = (uint8_t *)(he + n_exc);
+      for (const auto &v : exc)
+        for (uint64_t x : v) *he++ = (uint32_t)(x >> 8), *hc++ = (uint8_t)x;
+      const uint64_t total = code_bytes + n_exc * 5u;
+      if ((rc = dev_realloc(h, &s.d_packed, &s.packed_cap, (size_t)total + 64))) return rc;
+      if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+      if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
+      HIP_TRY(h, hipMemcpyAsync(s.d_packed, hb, total, hipMemcpyHostToDevice, s.stream));
+      const uint32_t grid = (uint32_t)std::min<uint64_t>((n * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
+      hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed, n, len, bpr, s.bases());
+      if (n_exc)
+        hipLaunchKernelGGL(femk::scatter_chars_kernel, dim3((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u)), dim3(256),
+                           0, s.stream, (const uint32_t *)(s.d_packed + code_bytes), (const uint8_t *)(s.d_packed + code_bytes + 4u * n_exc), n_exc,
+                           s.bases());
+      hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
+                         s.stream, s.d_off, n, len);
+      HIP_TRY(h, hipGetLastError());
+      s.n_reads = n, s.n_bases = n_bases, s.max_len = len;
+      s.staged = true, s.mapped = false, s.synced = false;
+      s.h2d_bytes = total, s.sent_packed = true, s.staged_by_copy = true;
+      return FEM_OK;
+    }
+  }
+  // ---- any other batch: the characters and the offsets as they are ----
+  run_threads(n_thr, [&](unsigned t) {
+    const uint64_t r_lo = n * t / n_thr, r_hi = n * (t + 1) / n_thr;
+    for (uint64_t i = r_lo; i < r_hi; ++i) ho[i] = reads->offsets[i] - base0;
+    if (r_hi == n) ho[n] = reads->offsets[n] - base0;
+    if (r_hi > r_lo) memcpy(hb + (reads->offsets[r_lo] - base0), reads->bases + reads->offsets[r_lo], reads->offsets[r_hi] - reads->offsets[r_lo]);
+  });
+  if (n == 0) ho[0] = 0;
+  rc = fem_dev_commit_stage(h, slot, n, max_len);
+  s.staged_by_copy = true;
+  return rc;
+}
+
+int fem_dev_stage_info(fem_dev *h, int slot, uint64_t *h2d_bytes, int32_t *packed) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  if (h2d_bytes) *h2d_bytes = h->slot[slot].h2d_bytes;
+  if (packed) *packed = h->slot[slot].sent_packed ? 1 : 0;
+  return FEM_OK;
 }
 
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p) {
@@ -1095,6 +1334,7 @@ int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]) {
   int rc = fem_dev_sync(h, slot);
   if (rc) return rc;
   if (stats) memcpy(stats, h->slot[slot].stats, sizeof(uint64_t) * 5);
+  h->slot[slot].prefetch_results = false;  // this caller takes the counters only
   return FEM_OK;
 }
 
@@ -1104,7 +1344,9 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
   if (!out) return fail(h, FEM_ERR_INVALID, "null result");
   Slot &s = h->slot[slot];
   const size_t n2 = (size_t)s.n_reads * 2, nc = s.n_cand;
+  bool regrown = false;
   if (n2 > s.h_per_read_cap || !s.h_begin) {
+    regrown = true;
     size_t c0 = 0, c1 = 0;
     if (s.h_begin) (void)hipHostFree(s.h_begin);
     if (s.h_count) (void)hipHostFree(s.h_count);
@@ -1114,6 +1356,7 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
     s.h_per_read_cap = c0;
   }
   if (nc > s.h_cand_cap || !s.h_cand) {
+    regrown = true;
     size_t c0 = 0, c1 = 0, c2 = 0;
     for (void *p : {(void *)s.h_cand, (void *)s.h_ed, (void *)s.h_end})
       if (p) (void)hipHostFree(p);
@@ -1124,16 +1367,20 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
     if ((rc = pinned_realloc(h, &s.h_end, &c2, want))) return rc;
     s.h_cand_cap = c0;
   }
-  if (n2) {
+  // what did not come home behind the kernels already (launch_batch; nothing did if a buffer was regrown just now)
+  const bool per_read_home = !regrown && s.prefetched_reads2 == n2;
+  const size_t c_from = regrown ? 0 : std::min<size_t>(s.prefetched_cand, nc);
+  if (n2 && !per_read_home) {
     HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d_count, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   }
-  if (nc) {
-    HIP_TRY(h, hipMemcpyAsync(s.h_cand, s.d_cand, nc * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_ed, s.d_ed, nc * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_end, s.d_end, nc * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+  if (nc > c_from) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_cand + c_from, s.d_cand + c_from, (nc - c_from) * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_ed + c_from, s.d_ed + c_from, (nc - c_from) * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_end + c_from, s.d_end + c_from, (nc - c_from) * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
   }
-  HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if ((n2 && !per_read_home) || nc > c_from) HIP_TRY(h, hipStreamSynchronize(s.stream));
+  s.prefetch_results = true, s.last_n_cand = nc;
   out->n_reads = s.n_reads;
   out->n_candidates = nc;
   out->cand_begin = s.h_begin, out->cand_count = s.h_count;
@@ -1147,6 +1394,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   if (rc) return rc;
   if (!out) return fail(h, FEM_ERR_INVALID, "null result");
   Slot &s = h->slot[slot];
+  s.prefetch_results = false;  // this caller takes records, not the per-candidate arrays
   if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
   if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
   femt::TailInput in{};

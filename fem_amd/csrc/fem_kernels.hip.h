@@ -96,6 +96,36 @@ __global__ void uniform_offsets_kernel(uint64_t *off, uint64_t n, uint32_t len) 
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) off[i] = i * (uint64_t)len;
 }
 
+// ---- packed read transfer (fem_dev_stage_reads on batches of equal-length reads) ----
+// The host sends two bits per base for the characters A C G T (four bases per byte, low bits first, every read padded
+// to whole bytes) and, for every other byte of the batch, its position and the byte itself; the batch is rebuilt byte
+// for byte.  One thread per packed byte.
+__global__ void unpack_reads_kernel(const uint8_t *packed, uint64_t n_reads, uint32_t len, uint32_t bytes_per_read, uint8_t *bases) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, total = n_reads * bytes_per_read;
+  const bool aligned = (len & 3u) == 0u && (((uintptr_t)bases) & 3u) == 0u;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const uint32_t b = packed[i];
+    // "ACGT" as a little-endian word: the code selects its byte
+    const uint32_t c0 = (0x54474341u >> (8u * (b & 3u))) & 0xFFu, c1 = (0x54474341u >> (8u * ((b >> 2) & 3u))) & 0xFFu;
+    const uint32_t c2 = (0x54474341u >> (8u * ((b >> 4) & 3u))) & 0xFFu, c3 = (0x54474341u >> (8u * (b >> 6))) & 0xFFu;
+    if (aligned) {  // (then bytes_per_read * 4 == len: the packed stream has no padding)
+      ((uint32_t *)bases)[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    } else {
+      const uint64_t r = i / bytes_per_read;
+      const uint32_t k = (uint32_t)(i - r * bytes_per_read) * 4u;
+      uint8_t *o = bases + r * len + k;
+      o[0] = (uint8_t)c0;
+      if (k + 1u < len) o[1] = (uint8_t)c1;
+      if (k + 2u < len) o[2] = (uint8_t)c2;
+      if (k + 3u < len) o[3] = (uint8_t)c3;
+    }
+  }
+}
+__global__ void scatter_chars_kernel(const uint32_t *at, const uint8_t *ch, uint64_t n, uint8_t *bases) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bases[at[i]] = ch[i];
+}
+
 struct Picked {
   uint32_t start, lo, freq, pad;
 };

@@ -12,7 +12,7 @@ ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
-    "fem_dev_stage_reads", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
@@ -92,6 +92,7 @@ def load_hip():
     L.fem_dev_copy_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_h2d_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_allreduce_stats.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.fem_dev_stage_info.argtypes = [vp, C.c_int, C.POINTER(u64), C.POINTER(C.c_int32)]
     L.fem_device_numa.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_char_p, u64]
     L.fem_bind_thread_near_device.argtypes = [C.c_int]
     _HIP = L
@@ -237,6 +238,12 @@ class Device:
     def stage_reads(self, bases, offsets, slot=0):
         b, keep = self._batch(bases, offsets)
         self._check(self._L.fem_dev_stage_reads(self._h, slot, C.byref(b)))
+
+    def stage_info(self, slot=0):
+        """(bytes the slot's last staging sent over the link, True if as 2-bit codes)."""
+        nb, pk = C.c_uint64(0), C.c_int32(0)
+        self._check(self._L.fem_dev_stage_info(self._h, slot, C.byref(nb), C.byref(pk)))
+        return nb.value, bool(pk.value)
 
     def acquire_stage(self, n_reads_cap, n_bases_cap, slot=0):
         """The slot's pinned staging buffers as numpy views (bases uint8[n_bases_cap + 64], offsets uint64[n_reads_cap + 1]):

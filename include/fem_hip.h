@@ -139,6 +139,12 @@ int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out);
  * (offsets ascending, reads within fem_dev_limits) and starts the asynchronous copy to HBM.  Returns without
  * waiting for the copy; the caller's buffers are free again on return. */
 int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads);
+/* A batch of equal-length reads crosses the link as two bits per base for the characters A C G T plus, for every other
+ * byte (lower case, N, anything), its position and the byte, and is rebuilt byte for byte on the device.  Batches of
+ * mixed lengths, or with more than one such byte in sixteen, go as characters + offsets.  FEM_NO_PACK=1 turns the
+ * packing off.  fem_dev_stage_info: bytes the slot's last staging (either form) sent to the device, and whether they
+ * were packed. */
+int fem_dev_stage_info(fem_dev *h, int slot, uint64_t *h2d_bytes, int32_t *packed);
 /* Zero-copy form (north_star: "reads streamed in pinned batches"; the reusable SequenceBatch ring of
  * src/input_queue.c:34-51): the library lends the slot's PINNED staging buffers, the FASTQ parser writes the
  * batch straight into them, commit starts the asynchronous H2D copy and returns at once.
