@@ -54,6 +54,13 @@ class ByteStream {
   ByteStream(const char *mem, size_t len) : mem_(mem), mem_len_(len) {}
   // bytes handed out so far (memory source: the offset of the next byte in the map)
   size_t tell() const { return mem_ ? mem_pos_ - (end_ - pos_) : consumed_ - (end_ - pos_); }
+  // gz source: `n` bytes that were read ahead (fem_seqfile's window) go back in front of the stream
+  void prepend(const char *p, size_t n) {
+    pre_.assign(p, p + n);
+    pre_pos_ = 0;
+  }
+  void set_error() { eof_ = true, last_rc_ = -3; }
+  void set_eof() { eof_ = true, last_rc_ = -1; }
   void seek_mem(size_t at) {  // memory source only
     mem_pos_ = at;
     pos_ = end_ = 0;
@@ -92,9 +99,16 @@ class ByteStream {
 
  private:
   bool refill() {
+    if (pre_pos_ < pre_.size()) {  // bytes handed back by the window reader come first
+      cur_ = pre_.data() + pre_pos_;
+      const size_t n = pre_.size() - pre_pos_;
+      pre_pos_ = pre_.size();
+      consumed_ += n;
+      pos_ = 0, end_ = n;
+      return true;
+    }
     if (eof_) {
-      last_rc_ = -1;
-      return false;
+      return false;  // (last_rc_ keeps -1 or -3)
     }
     if (mem_) {
       if (mem_pos_ >= mem_len_) {
@@ -111,7 +125,9 @@ class ByteStream {
     int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
     if (n <= 0) {
       eof_ = true;
-      last_rc_ = n < 0 ? -3 : -1;
+      int zerr = Z_OK;
+      (void)gzerror(f_, &zerr);  // a stream that stops short reads as 0 bytes + Z_BUF_ERROR, not as -1
+      last_rc_ = n < 0 || zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR ? -3 : -1;
       return false;
     }
     cur_ = buf_.data();
@@ -122,7 +138,8 @@ class ByteStream {
   gzFile f_ = nullptr;
   const char *mem_ = nullptr;
   size_t mem_len_ = 0, mem_pos_ = 0, consumed_ = 0;
-  std::vector<char> buf_;
+  std::vector<char> buf_, pre_;
+  size_t pre_pos_ = 0;
   const char *cur_ = nullptr;
   size_t pos_ = 0, end_ = 0;
   bool eof_ = false;
@@ -136,6 +153,11 @@ struct fem_seqfile {
   ByteStream *in = nullptr;
   const char *map = nullptr;  // plain (not gzip) regular files are memory-mapped
   size_t map_len = 0;
+  // gzip input: inflated a window at a time (one thread: a gzip stream has no entry points), each window parsed by
+  // all threads like a stretch of a mapped file
+  std::vector<char> win;
+  size_t win_lo = 0, win_len = 0;  // unparsed bytes of the window: [win_lo, win_len)
+  bool gz_eof = false, gz_err = false;
   bool fast_ok = true;        // 4-line FASTQ so far: the multi-threaded parser may be used
   int last_char = 0;  // header character already consumed by the previous record
   std::string name, comment, seq, qual;
@@ -344,10 +366,89 @@ bool parse_fastq_range(const char *m, size_t lo, size_t hi, ParsedChunk &c) {
   return true;
 }
 
+
+// ---- a stretch of the input in memory for the multi-threaded 4-line FASTQ parser: the file's mapping, or (gzip) a
+//      window inflated ahead of the parser ----
+struct FastView {
+  const char *m = nullptr;
+  size_t len = 0, lo = 0;
+  bool whole = true;  // m[len] is the end of the file (a window of a gzip stream usually is not)
+};
+size_t next_fastq_record(const char *m, size_t len, size_t from);
+// start of the last record that begins in m[lo, len) (it may be cut off by the end of the window); len if none is found
+size_t last_fastq_record(const char *m, size_t lo, size_t len) {
+  size_t from = len > lo + (1u << 16) ? len - (1u << 16) : lo;
+  size_t cur = next_fastq_record(m, len, from), last = cur;
+  while (cur < len) {
+    cur = next_fastq_record(m, len, cur + 1);
+    if (cur < len) last = cur;
+  }
+  return last;
+}
+bool fast_view(fem_seqfile *f, uint64_t approx_bytes, FastView *v);
+void fast_view_consumed(fem_seqfile *f, size_t upto);
+void fast_view_abandon(fem_seqfile *f, size_t pos0);
+
+bool fast_view(fem_seqfile *f, uint64_t approx_bytes, FastView *v) {
+  if (!f->fast_ok || f->last_char != 0) return false;
+  if (f->map) {
+    v->m = f->map, v->len = f->map_len, v->lo = f->in->tell(), v->whole = true;
+    return true;
+  }
+  if (!f->gz || f->gz_err) return false;
+  // gzip: drop what has been parsed, inflate until the window holds approx_bytes (+ room for the record that straddles
+  // its end), or everything when approx_bytes == 0
+  if (f->win_lo > 0) {
+    memmove(f->win.data(), f->win.data() + f->win_lo, f->win_len - f->win_lo);
+    f->win_len -= f->win_lo, f->win_lo = 0;
+  }
+  const size_t slack = 1u << 20;
+  size_t target = approx_bytes ? (size_t)approx_bytes + slack : (size_t)64 << 20;
+  while (!f->gz_eof) {
+    if (f->win.size() < target) f->win.resize(target);
+    while (f->win_len < target && !f->gz_eof) {
+      const int n = gzread(f->gz, f->win.data() + f->win_len, (unsigned)std::min<size_t>(target - f->win_len, 1u << 26));
+      int zerr = Z_OK;
+      if (n <= 0) (void)gzerror(f->gz, &zerr);  // a stream that stops short reads as 0 bytes + Z_BUF_ERROR, not as -1
+      if (n < 0 || zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) {
+        f->gz_err = true;  // truncated or damaged stream: "Didn't reach the end of sequence file"
+        f->in->set_error();
+        return false;
+      }
+      if (n == 0) f->gz_eof = true;
+      f->win_len += (size_t)n;
+    }
+    if (approx_bytes) break;
+    target *= 2;  // the whole file was asked for
+  }
+  if (f->gz_eof) f->in->set_eof();  // (the sequential reader, should it take over, has nothing behind the window)
+  v->m = f->win.data(), v->len = f->win_len, v->lo = 0, v->whole = f->gz_eof;
+  return true;
+}
+void fast_view_consumed(fem_seqfile *f, size_t upto) {
+  if (f->map) f->in->seek_mem(upto);
+  else f->win_lo = upto;
+}
+// the window is not 4-line FASTQ: the sequential reader takes over where the fast one stood
+void fast_view_abandon(fem_seqfile *f, size_t pos0) {
+  if (f->map) {
+    f->in->seek_mem(pos0);
+  } else {
+    f->in->prepend(f->win.data() + f->win_lo, f->win_len - f->win_lo);
+    f->win_lo = f->win_len = 0;
+    f->win.clear();
+    f->win.shrink_to_fit();
+  }
+}
+
 }  // namespace
 
 int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
   if (!f || !out) return -1;
+  if (f->gz && f->win_len > f->win_lo) {  // after batches read through the window: hand its rest to this reader
+    f->fast_ok = false;
+    fast_view_abandon(f, 0);
+  }
   std::vector<ParsedChunk> parts(1);
   int rc = 0;
   while (max_seqs == 0 || parts[0].len.size() < max_seqs) {
@@ -368,19 +469,21 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
   if (!f || !out) return -1;
   if (n_threads < 1) n_threads = 1;
   const size_t pos0 = f->in->tell();
-  // ---- memory-mapped plain file at a record boundary: split the window between threads ----
-  if (f->map && f->fast_ok && f->last_char == 0) {
-    const char *m = f->map;
-    const size_t len = f->map_len;
-    size_t lo = pos0;
+  // ---- mapped plain file, or inflated window of a gzip stream, at a record boundary: split it between threads ----
+  FastView fv;
+  if (fast_view(f, approx_bytes, &fv)) {
+    const char *m = fv.m;
+    const size_t len = fv.len;
+    size_t lo = fv.lo;
     while (lo < len && m[lo] != '@' && m[lo] != '>') ++lo;  // kseq skips to the first header character
-    if (lo >= len) {
+    if (lo >= len && fv.whole) {
       std::vector<ParsedChunk> none(1);
-      f->in->seek_mem(len);
+      fast_view_consumed(f, len);
       return finish_seqset(none, out);
     }
-    const size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
-    if (m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
+    size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
+    if (!fv.whole && hi >= len) hi = last_fastq_record(m, lo, len);  // the record that straddles the window's end waits
+    if (lo < len && hi > lo && (fv.whole || hi < len) && m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
       const size_t span = hi - lo;
       int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, span / (1u << 20) + 1));
       std::vector<size_t> cut((size_t)nt + 1, hi);
@@ -392,12 +495,12 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
 #pragma omp parallel for schedule(static, 1) num_threads(nt) reduction(&& : ok)
       for (int t = 0; t < nt; ++t) ok = parse_fastq_range(m, cut[(size_t)t], cut[(size_t)t + 1], parts[(size_t)t]) && ok;
       if (ok) {
-        f->in->seek_mem(hi);
+        fast_view_consumed(f, hi);
         return finish_seqset(parts, out);
       }
     }
     f->fast_ok = false;  // FASTA, multi-line FASTQ or malformed input: the exact sequential reader takes over
-    f->in->seek_mem(pos0);
+    fast_view_abandon(f, pos0);
   }
   // ---- sequential, kseq-exact ----
   std::vector<ParsedChunk> parts(1);
@@ -510,22 +613,24 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
   fem_batch_plan *pl = new (std::nothrow) fem_batch_plan();
   if (!pl) return -4;
   const size_t pos0 = f->in->tell();
-  if (f->map && f->fast_ok && f->last_char == 0) {
-    // (Reading the window out of the page cache with pread by all threads, into a reusable buffer, was tried in place of
-    // faulting the mapping in: 3 GB/s on tmpfs against 18 GB/s through the mapping.)
-    const char *m = f->map;
-    const size_t len = f->map_len;
-    size_t lo = pos0;
+  FastView fv;
+  if (fast_view(f, approx_bytes, &fv)) {
+    // (Reading a plain file's window out of the page cache with pread by all threads, into a reusable buffer, was tried in
+    // place of faulting the mapping in: 3 GB/s on tmpfs against 18 GB/s through the mapping.)
+    const char *m = fv.m;
+    const size_t len = fv.len;
+    size_t lo = fv.lo;
     while (lo < len && m[lo] != '@' && m[lo] != '>') ++lo;  // kseq skips to the first header character
-    if (lo >= len) {  // end of input: an empty batch
-      f->in->seek_mem(len);
+    if (lo >= len && fv.whole) {  // end of input: an empty batch
+      fast_view_consumed(f, len);
       pl->fast = true, pl->m = m, pl->end = len, pl->cut.assign(2, len), pl->count.assign(1, RangeCount());
       shape->has_qual = 1;
       *plan_out = pl;
       return 0;
     }
-    const size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
-    if (m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
+    size_t hi = approx_bytes == 0 || lo + approx_bytes >= len ? len : next_fastq_record(m, len, lo + (size_t)approx_bytes);
+    if (!fv.whole && hi >= len) hi = last_fastq_record(m, lo, len);  // the record that straddles the window's end waits
+    if (lo < len && hi > lo && (fv.whole || hi < len) && m[lo] == '@' && next_fastq_record(m, len, lo) == lo) {
       const size_t span = hi - lo;
       const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, span / (1u << 18) + 1));
       pl->cut.assign((size_t)nt + 1, hi);
@@ -561,13 +666,14 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
         shape->min_len = shape->n_reads ? min_len : 0;
         shape->has_qual = 1;
         pl->fast = true, pl->m = m, pl->end = hi;
-        f->in->seek_mem(hi);
+        fast_view_consumed(f, hi);
         *plan_out = pl;
         return 0;
       }
     }
     f->fast_ok = false;  // FASTA, multi-line FASTQ or malformed input: the exact sequential reader takes over
-    f->in->seek_mem(pos0);
+    fast_view_abandon(f, pos0);
+    pl->cut.clear(), pl->count.clear();
   }
   pl->rc = fem_seqfile_read_bytes(f, approx_bytes, n_threads, &pl->held);
   if (pl->rc != 0 && pl->rc != -2 && pl->rc != -3) {  // allocation failure

@@ -257,3 +257,52 @@ def test_summary_slot_arithmetic_is_exact():
     assert np.array_equal(q, x // 3)
     r = np.arange(24, dtype=np.uint32)
     assert np.array_equal((r * 11) >> 5, r // 3)
+
+
+def test_gzip_input_is_parsed_window_by_window(tmp_path):
+    # gzip streams are inflated a window at a time and each window goes through the multi-threaded 4-line parser
+    # (fem_host.cc: fast_view); records that straddle a window's end, a switch to the sequential reader in the middle of
+    # the stream (multi-line record), and a truncated stream
+    rng = np.random.default_rng(13)
+    n, L = 12_000, 100
+    recs = []
+    for i in range(n):
+        ln = L if i % 4 else int(rng.integers(1, 3 * L))
+        seq = util.rand_seq(rng, ln)
+        qual = bytes(rng.integers(33, 74, size=ln).astype(np.uint8))
+        recs.append(b"@g%d c\n" % i + seq + b"\n+\n" + qual + (b"\n\n" if i % 19 == 0 else b"\n"))
+    plain = tmp_path / "w.fq"
+    plain.write_bytes(b"".join(recs)[:-1])
+    whole = host.read_sequences(str(plain))
+    assert whole.n == n
+    gzp = tmp_path / "w.fq.gz"
+    with gzip.open(str(gzp), "wb", compresslevel=1) as f:
+        f.write(plain.read_bytes())
+
+    def same(parts, ref, n_expected):
+        assert sum(p.n for p in parts) == n_expected
+        assert b"".join(p.bases[:int(p.off[p.n])].tobytes() for p in parts) == ref.bases.tobytes()
+        assert b"".join(p.quals[:int(p.off[p.n])].tobytes() for p in parts) == ref.quals.tobytes()
+        assert b"".join(p.names_raw[:int(p.name_off[p.n])].tobytes() for p in parts) == ref.names_raw.tobytes()
+
+    for approx, threads in ((70_000, 3), (300_000, 8), (1 << 22, 4), (0, 4)):
+        parts = host.read_planned_batches(str(gzp), approx, threads=threads)
+        same(parts, whole, n)
+        if approx == 70_000:
+            assert len(parts) > 20  # many windows
+    chunks = host.read_sequences_in_chunks(str(gzp), 200_000, threads=4)
+    assert b"".join(p.bases.tobytes() for p in chunks) == whole.bases.tobytes()
+    # a multi-line record in the middle: the windows before it are parsed by the fast reader, the rest by the exact one
+    mixed = b"".join(recs[:5000]) + b"@ml x\nACGT\nACG\n+\nIIII\nIII\n" + b"".join(recs[5000:])
+    mp, mg = tmp_path / "m.fq", tmp_path / "m.fq.gz"
+    mp.write_bytes(mixed)
+    with gzip.open(str(mg), "wb", compresslevel=1) as f:
+        f.write(mixed)
+    ref = host.read_sequences(str(mp))
+    assert ref.n == n + 1
+    same(host.read_planned_batches(str(mg), 150_000, threads=4), ref, n + 1)
+    # truncated stream: the reference exits with "Didn't reach the end of sequence file" (src/sequence_batch.c:63-66)
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(gzp.read_bytes()[:gzp.stat().st_size * 2 // 3])
+    with pytest.raises(ValueError):
+        host.read_planned_batches(str(cut), 100_000, threads=2)
