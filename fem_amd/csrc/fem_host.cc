@@ -193,12 +193,12 @@ struct fem_seqfile {
     while ((c = in->get()) >= 0 && c != '\n') {
     }
     if (c == -1) return -2;
-    while (qual.size() < seq.size()) {
+    do {  // at least one line, even behind an empty sequence (src/kseq.h:222: the call sits in the loop's condition)
       int d = in->until(true, &qual, &got);
       if (d == -3) return -3;
       if (qual.size() > 1 && qual.back() == '\r') qual.pop_back();
-      if (d < 0) break;
-    }
+      if (d < 0 && !got) break;  // end of file with nothing read
+    } while (qual.size() < seq.size());
     last_char = 0;
     if (seq.size() != qual.size()) return -2;
     return (long)seq.size();
