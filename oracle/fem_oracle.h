@@ -12,7 +12,10 @@
  * therefore a line-by-line restatement of the reference algorithm, each
  * function citing the reference file:line it follows, cross-checked only by
  * independent brute-force models in tests/ (full-matrix edit distance,
- * closed-form candidate sets, CIGAR re-scoring).
+ * closed-form candidate sets, CIGAR re-scoring).  One function is pinned
+ * against reference code: fo_sort_mapping_keys equals the reference's own
+ * ksort.h instantiation, built from /root/reference behind ref_klib.c
+ * (tests/test_ref_klib.py).
  */
 #ifndef FEM_ORACLE_H_
 #define FEM_ORACLE_H_
