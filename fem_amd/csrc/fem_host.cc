@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -50,7 +51,8 @@ T *dup_vec(const std::vector<T> &v) {
 // ------------------------------------------------------------------------------------------------
 class ByteStream {
  public:
-  explicit ByteStream(gzFile f) : f_(f), buf_(1u << 20) {}
+  // compressed source: read(buf, cap) returns the bytes it produced, 0 at the end of the stream, -1 on an error
+  explicit ByteStream(std::function<int(char *, unsigned)> read) : read_(std::move(read)), buf_(1u << 20) {}
   ByteStream(const char *mem, size_t len) : mem_(mem), mem_len_(len) {}
   // bytes handed out so far (memory source: the offset of the next byte in the map)
   size_t tell() const { return mem_ ? mem_pos_ - (end_ - pos_) : consumed_ - (end_ - pos_); }
@@ -122,12 +124,10 @@ class ByteStream {
       pos_ = 0, end_ = n;
       return true;
     }
-    int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+    int n = read_(buf_.data(), (unsigned)buf_.size());
     if (n <= 0) {
       eof_ = true;
-      int zerr = Z_OK;
-      (void)gzerror(f_, &zerr);  // a stream that stops short reads as 0 bytes + Z_BUF_ERROR, not as -1
-      last_rc_ = n < 0 || zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR ? -3 : -1;
+      last_rc_ = n < 0 ? -3 : -1;
       return false;
     }
     cur_ = buf_.data();
@@ -135,7 +135,7 @@ class ByteStream {
     pos_ = 0, end_ = (size_t)n;
     return true;
   }
-  gzFile f_ = nullptr;
+  std::function<int(char *, unsigned)> read_;
   const char *mem_ = nullptr;
   size_t mem_len_ = 0, mem_pos_ = 0, consumed_ = 0;
   std::vector<char> buf_, pre_;
@@ -148,6 +148,48 @@ class ByteStream {
 
 }  // namespace
 
+namespace {
+// ---- BGZF blocks (the SAM specification, section 4.1: a gzip member with the extra subfield 'B' 'C' = block size - 1) ----
+struct BgzfBlock {
+  size_t at = 0, payload = 0, payload_len = 0;  // member offset, start and length of its deflate stream
+  uint32_t isize = 0, crc = 0;                   // uncompressed length and CRC-32 from the trailer
+  size_t next = 0;                               // offset of the next member
+};
+// false: no well-formed BGZF member at z[at] (or it runs past the end of the file)
+bool bgzf_block_at(const unsigned char *z, size_t len, size_t at, BgzfBlock *b) {
+  if (at + 18 > len) return false;
+  const unsigned char *h = z + at;
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+  const size_t xlen = h[10] | (size_t)h[11] << 8;
+  if (at + 12 + xlen > len) return false;
+  size_t bsize = 0;
+  for (size_t x = 0; x + 4 <= xlen;) {  // subfields: SI1 SI2 SLEN(2) data
+    const unsigned char *sf = h + 12 + x;
+    const size_t slen = sf[2] | (size_t)sf[3] << 8;
+    if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (sf[4] | (size_t)sf[5] << 8) + 1;
+    x += 4 + slen;
+  }
+  if (bsize < 12 + xlen + 8 || at + bsize > len) return false;
+  b->at = at, b->payload = at + 12 + xlen, b->payload_len = bsize - (12 + xlen) - 8, b->next = at + bsize;
+  const unsigned char *t = z + at + bsize - 8;
+  b->crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+  b->isize = t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+  return b->isize <= 65536u;
+}
+bool bgzf_inflate(const unsigned char *z, const BgzfBlock &b, char *out) {
+  if (b.isize == 0) return true;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<Bytef *>(z + b.payload), zs.avail_in = (uInt)b.payload_len;
+  zs.next_out = (Bytef *)out, zs.avail_out = b.isize;
+  const int rc = inflate(&zs, Z_FINISH);
+  const bool ok = rc == Z_STREAM_END && zs.total_out == b.isize;
+  inflateEnd(&zs);
+  return ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)out, b.isize) == b.crc;
+}
+}  // namespace
+
 struct fem_seqfile {
   gzFile gz = nullptr;
   ByteStream *in = nullptr;
@@ -158,6 +200,11 @@ struct fem_seqfile {
   std::vector<char> win;
   size_t win_lo = 0, win_len = 0;  // unparsed bytes of the window: [win_lo, win_len)
   bool gz_eof = false, gz_err = false;
+  // BGZF (bgzip; gzip members of at most 64 KiB that carry their own size): the compressed file is mapped and the blocks
+  // of a window are inflated by all threads
+  const unsigned char *zmap = nullptr;
+  size_t zlen = 0, zpos = 0;
+  int threads = 1;  // host threads the caller of the current batch call allows
   bool fast_ok = true;        // 4-line FASTQ so far: the multi-threaded parser may be used
   int last_char = 0;  // header character already consumed by the previous record
   std::string name, comment, seq, qual;
@@ -227,6 +274,27 @@ fem_seqfile *fem_seqfile_open(const char *path) {
       return f;
     }
   }
+  // BGZF: regular file whose first member carries the 'BC' subfield -> map the compressed bytes, inflate block-wise
+  if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 28) {
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    BgzfBlock b;
+    if (m != MAP_FAILED && bgzf_block_at((const unsigned char *)m, (size_t)st.st_size, 0, &b)) {
+      close(fd);
+      f->zmap = (const unsigned char *)m, f->zlen = (size_t)st.st_size;
+      f->in = new ByteStream([f](char *buf, unsigned cap) -> int {  // the sequential reader: one block at a time
+        for (;;) {
+          if (f->zpos >= f->zlen) return 0;
+          BgzfBlock blk;
+          if (!bgzf_block_at(f->zmap, f->zlen, f->zpos, &blk) || blk.isize > cap) return -1;
+          f->zpos = blk.next;
+          if (blk.isize == 0) continue;  // (the empty end-of-file block, or an empty member in between)
+          return bgzf_inflate(f->zmap, blk, buf) ? (int)blk.isize : -1;
+        }
+      });
+      return f;
+    }
+    if (m != MAP_FAILED) munmap(m, (size_t)st.st_size);
+  }
   close(fd);
   gzFile gz = gzopen(path, "r");
   if (!gz) {
@@ -235,7 +303,12 @@ fem_seqfile *fem_seqfile_open(const char *path) {
   }
   gzbuffer(gz, 1u << 20);
   f->gz = gz;
-  f->in = new ByteStream(gz);
+  f->in = new ByteStream([gz](char *buf, unsigned cap) -> int {
+    const int n = gzread(gz, buf, cap);
+    int zerr = Z_OK;
+    if (n <= 0) (void)gzerror(gz, &zerr);  // a stream that stops short reads as 0 bytes + Z_BUF_ERROR, not as -1
+    return n < 0 || zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR ? -1 : n;
+  });
   return f;
 }
 
@@ -243,6 +316,7 @@ void fem_seqfile_close(fem_seqfile *f) {
   if (!f) return;
   delete f->in;
   if (f->map) munmap((void *)f->map, f->map_len);
+  if (f->zmap) munmap((void *)f->zmap, f->zlen);
   if (f->gz) gzclose(f->gz);
   delete f;
 }
@@ -395,7 +469,7 @@ bool fast_view(fem_seqfile *f, uint64_t approx_bytes, FastView *v) {
     v->m = f->map, v->len = f->map_len, v->lo = f->in->tell(), v->whole = true;
     return true;
   }
-  if (!f->gz || f->gz_err) return false;
+  if ((!f->gz && !f->zmap) || f->gz_err) return false;
   // gzip: drop what has been parsed, inflate until the window holds approx_bytes (+ room for the record that straddles
   // its end), or everything when approx_bytes == 0
   if (f->win_lo > 0) {
@@ -404,7 +478,36 @@ bool fast_view(fem_seqfile *f, uint64_t approx_bytes, FastView *v) {
   }
   const size_t slack = 1u << 20;
   size_t target = approx_bytes ? (size_t)approx_bytes + slack : (size_t)64 << 20;
-  while (!f->gz_eof) {
+  while (f->zmap && !f->gz_eof) {  // BGZF: the blocks that fill the window, inflated side by side
+    std::vector<BgzfBlock> blocks;
+    std::vector<size_t> out_at;
+    size_t total = f->win_len, z = f->zpos;
+    while (total < target && z < f->zlen) {
+      BgzfBlock b;
+      if (!bgzf_block_at(f->zmap, f->zlen, z, &b)) {
+        f->gz_err = true;  // cut off inside a block, or not BGZF any more
+        f->in->set_error();
+        return false;
+      }
+      blocks.push_back(b), out_at.push_back(total);
+      total += b.isize, z = b.next;
+    }
+    if (f->win.size() < total) f->win.resize(total);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(std::max(1, f->threads)) reduction(&& : ok)
+    for (int64_t i = 0; i < (int64_t)blocks.size(); ++i)
+      ok = bgzf_inflate(f->zmap, blocks[(size_t)i], f->win.data() + out_at[(size_t)i]) && ok;
+    if (!ok) {
+      f->gz_err = true;
+      f->in->set_error();
+      return false;
+    }
+    f->win_len = total, f->zpos = z;
+    if (z >= f->zlen) f->gz_eof = true;
+    if (approx_bytes || f->gz_eof) break;
+    target *= 2;  // the whole file was asked for
+  }
+  while (f->gz && !f->gz_eof) {
     if (f->win.size() < target) f->win.resize(target);
     while (f->win_len < target && !f->gz_eof) {
       const int n = gzread(f->gz, f->win.data() + f->win_len, (unsigned)std::min<size_t>(target - f->win_len, 1u << 26));
@@ -445,7 +548,7 @@ void fast_view_abandon(fem_seqfile *f, size_t pos0) {
 
 int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
   if (!f || !out) return -1;
-  if (f->gz && f->win_len > f->win_lo) {  // after batches read through the window: hand its rest to this reader
+  if ((f->gz || f->zmap) && f->win_len > f->win_lo) {  // after batches read through the window: hand its rest to this reader
     f->fast_ok = false;
     fast_view_abandon(f, 0);
   }
@@ -469,6 +572,7 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
   if (!f || !out) return -1;
   if (n_threads < 1) n_threads = 1;
   const size_t pos0 = f->in->tell();
+  f->threads = n_threads;
   // ---- mapped plain file, or inflated window of a gzip stream, at a record boundary: split it between threads ----
   FastView fv;
   if (fast_view(f, approx_bytes, &fv)) {
@@ -613,6 +717,7 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
   fem_batch_plan *pl = new (std::nothrow) fem_batch_plan();
   if (!pl) return -4;
   const size_t pos0 = f->in->tell();
+  f->threads = n_threads;
   FastView fv;
   if (fast_view(f, approx_bytes, &fv)) {
     // (Reading a plain file's window out of the page cache with pread by all threads, into a reusable buffer, was tried in

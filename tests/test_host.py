@@ -306,3 +306,78 @@ def test_gzip_input_is_parsed_window_by_window(tmp_path):
     cut.write_bytes(gzp.read_bytes()[:gzp.stat().st_size * 2 // 3])
     with pytest.raises(ValueError):
         host.read_planned_batches(str(cut), 100_000, threads=2)
+
+
+def _bgzf(data, block=65280, level=1, eof_block=True):
+    """bgzip's format (SAM specification 4.1): gzip members with the 'BC' extra subfield, one per <= 64 KiB of input."""
+    import struct
+    import zlib
+    out = []
+    for at in list(range(0, len(data), block)) + ([None] if eof_block else []):
+        chunk = b"" if at is None else data[at:at + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        bsize = 18 + len(payload) + 8
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+def test_bgzf_input_is_inflated_block_parallel(tmp_path):
+    # bgzip-compressed FASTQ / FASTA: the blocks of a window are inflated by all threads (fem_host.cc: bgzf_*), the window
+    # goes through the multi-threaded parser; the sequential reader (references, multi-line records) reads block by block
+    rng = np.random.default_rng(14)
+    n, L = 9_000, 100
+    recs = []
+    for i in range(n):
+        ln = L if i % 6 else int(rng.integers(1, 3 * L))
+        seq = util.rand_seq(rng, ln)
+        qual = bytes(rng.integers(33, 74, size=ln).astype(np.uint8))
+        recs.append(b"@z%d c\n" % i + seq + b"\n+\n" + qual + b"\n")
+    text = b"".join(recs)
+    plain = tmp_path / "b.fq"
+    plain.write_bytes(text)
+    whole = host.read_sequences(str(plain))
+    assert whole.n == n
+    for block, name in ((65280, "b.fq.gz"), (777, "small_blocks.fq.gz")):
+        p = tmp_path / name
+        p.write_bytes(_bgzf(text, block=block))
+        assert gzip.decompress(p.read_bytes()) == text  # (it is a valid multi-member gzip file)
+        for approx, threads in ((100_000, 4), (1 << 21, 8), (0, 3)):
+            parts = host.read_planned_batches(str(p), approx, threads=threads)
+            assert sum(q.n for q in parts) == n
+            assert b"".join(q.bases[:int(q.off[q.n])].tobytes() for q in parts) == whole.bases.tobytes()
+            assert b"".join(q.quals[:int(q.off[q.n])].tobytes() for q in parts) == whole.quals.tobytes()
+            assert b"".join(q.names_raw[:int(q.name_off[q.n])].tobytes() for q in parts) == whole.names_raw.tobytes()
+        s = host.read_sequences(str(p))  # sequential reader, block by block
+        assert s.n == n and s.bases.tobytes() == whole.bases.tobytes()
+    # a bgzipped multi-line FASTA reference
+    fa = b"".join(b">chr%d d\n" % i + b"\n".join(util.rand_seq(rng, 200_000)[j:j + 60] for j in range(0, 200_000, 60)) + b"\n" for i in range(3))
+    fp, fz = tmp_path / "r.fa", tmp_path / "r.fa.gz"
+    fp.write_bytes(fa)
+    fz.write_bytes(_bgzf(fa))
+    a, b = host.read_sequences(str(fp)), host.read_sequences(str(fz))
+    assert a.n == b.n == 3 and a.bases.tobytes() == b.bases.tobytes() and a.names_raw.tobytes() == b.names_raw.tobytes()
+    # switch to the sequential reader in the middle (multi-line record), without the end-of-file block
+    mixed = b"".join(recs[:4000]) + b"@ml x\nACGT\nACG\n+\nIIII\nIII\n" + b"".join(recs[4000:])
+    mp, mz = tmp_path / "m.fq", tmp_path / "m.fq.gz"
+    mp.write_bytes(mixed)
+    mz.write_bytes(_bgzf(mixed, block=5000, eof_block=False))
+    ref = host.read_sequences(str(mp))
+    parts = host.read_planned_batches(str(mz), 120_000, threads=4)
+    assert sum(q.n for q in parts) == ref.n == n + 1
+    assert b"".join(q.bases[:int(q.off[q.n])].tobytes() for q in parts) == ref.bases.tobytes()
+    # damage: cut inside a block, and a flipped payload byte (CRC)
+    good = (tmp_path / "b.fq.gz").read_bytes()
+    cut = tmp_path / "cut_b.fq.gz"
+    cut.write_bytes(good[:len(good) // 2])
+    with pytest.raises(ValueError):
+        host.read_planned_batches(str(cut), 100_000, threads=2)
+    bad = bytearray(good)
+    bad[len(bad) // 3] ^= 0x55
+    flip = tmp_path / "flip.fq.gz"
+    flip.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        host.read_planned_batches(str(flip), 100_000, threads=2)
+    with pytest.raises(ValueError):
+        host.read_sequences(str(flip))
