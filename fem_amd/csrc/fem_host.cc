@@ -546,11 +546,144 @@ void fast_view_abandon(fem_seqfile *f, size_t pos0) {
 
 }  // namespace
 
+namespace {
+// A whole mapped FASTA file (a reference: few sequences, lines of 60-80 characters, gigabytes) read by all threads:
+// headers found by a parallel scan, every sequence body cut into pieces at line starts, lengths counted, then the lines
+// copied to their places.  kseq's rules (src/kseq.h:186-226) decide what a record is; anything this reader does not
+// reproduce exactly — FASTQ, a carriage return, a body line that begins with '@' or '+' (kseq looks at the first
+// character of every line) — makes it decline, and the sequential reader takes the file.
+bool read_fasta_parallel(fem_seqfile *f, fem_seqset *out) {
+  const char *m = f->map;
+  const size_t len = f->map_len;
+  size_t p0 = 0;
+  while (p0 < len && m[p0] != '>' && m[p0] != '@') ++p0;  // kseq skips to the first header character, wherever it is
+  if (p0 >= len || m[p0] != '>') return false;
+  size_t piece_bytes = (size_t)8 << 20;
+  if (const char *e = getenv("FEM_FASTA_PIECE")) piece_bytes = (size_t)std::max(16, atoi(e));  // (tests: many small pieces)
+  const int nt = std::max(1, std::min(omp_get_max_threads(), 16));
+  // ---- headers: '>' at the start of a line ----
+  std::vector<size_t> hdr;
+  {
+    const size_t span = len - p0, n_chunk = std::max<size_t>(1, std::min<size_t>((size_t)nt * 4, span / (1u << 20) + 1));
+    std::vector<std::vector<size_t>> found(n_chunk);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (int64_t c = 0; c < (int64_t)n_chunk; ++c) {
+      size_t lo = p0 + span * (size_t)c / n_chunk;
+      const size_t hi = p0 + span * ((size_t)c + 1) / n_chunk;
+      while (lo < hi) {
+        const char *g = (const char *)memchr(m + lo, '>', hi - lo);
+        if (!g) break;
+        const size_t at = (size_t)(g - m);
+        if (at == p0 || m[at - 1] == '\n') found[(size_t)c].push_back(at);
+        lo = at + 1;
+      }
+    }
+    for (const auto &v : found) hdr.insert(hdr.end(), v.begin(), v.end());
+  }
+  const size_t n_rec = hdr.size();
+  // ---- names and pieces ----
+  struct Piece {
+    size_t rec, lo, hi;
+    uint64_t out_len = 0;
+  };
+  std::vector<Piece> pieces;
+  std::vector<size_t> name_at(n_rec), name_len(n_rec), first_piece(n_rec + 1, 0);
+  for (size_t r = 0; r < n_rec; ++r) {
+    const size_t h = hdr[r], end = r + 1 < n_rec ? hdr[r + 1] : len;
+    const char *nl = (const char *)memchr(m + h, '\n', end - h);
+    const size_t line_end = nl ? (size_t)(nl - m) : end;
+    size_t q = h + 1;
+    while (q < line_end && !isspace((unsigned char)m[q])) ++q;
+    name_at[r] = h + 1, name_len[r] = q - (h + 1);
+    first_piece[r] = pieces.size();
+    size_t lo = nl ? line_end + 1 : end;
+    while (lo < end) {  // pieces begin at line starts
+      size_t hi = std::min(end, lo + piece_bytes);
+      if (hi < end) {
+        const char *e = (const char *)memchr(m + hi, '\n', end - hi);
+        hi = e ? (size_t)(e - m) + 1 : end;
+      }
+      pieces.push_back(Piece{r, lo, hi});
+      lo = hi;
+    }
+  }
+  first_piece[n_rec] = pieces.size();
+  // ---- pass 1: what each piece contributes; anything irregular -> decline ----
+  bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) reduction(&& : ok)
+  for (int64_t i = 0; i < (int64_t)pieces.size(); ++i) {
+    Piece &pc = pieces[(size_t)i];
+    if (memchr(m + pc.lo, '\r', pc.hi - pc.lo)) {
+      ok = false;
+      continue;
+    }
+    uint64_t n = 0;
+    for (size_t p = pc.lo; p < pc.hi;) {
+      const char *e = (const char *)memchr(m + p, '\n', pc.hi - p);
+      const size_t le = e ? (size_t)(e - m) : pc.hi;
+      if (le > p) {
+        if (m[p] == '@' || m[p] == '+' || m[p] == '>') ok = false;
+        n += le - p;
+      }
+      p = le + 1;
+    }
+    pc.out_len = n;
+  }
+  if (!ok) return false;
+  // ---- layout (zero-length records are skipped, src/sequence_batch.c:50-52) ----
+  std::vector<uint64_t> rec_len(n_rec, 0), piece_at(pieces.size(), 0);
+  for (const Piece &pc : pieces) rec_len[pc.rec] += pc.out_len;
+  uint64_t n_keep = 0, nb = 0, nn = 0;
+  for (size_t r = 0; r < n_rec; ++r)
+    if (rec_len[r]) ++n_keep, nb += rec_len[r], nn += name_len[r];
+  memset(out, 0, sizeof *out);
+  out->n = n_keep;
+  out->bases = (char *)malloc(nb + 64);
+  out->names = (char *)malloc(nn + 1);
+  out->off = (uint64_t *)malloc((n_keep + 1) * sizeof(uint64_t));
+  out->name_off = (uint64_t *)malloc((n_keep + 1) * sizeof(uint64_t));
+  if (!out->bases || !out->names || !out->off || !out->name_off) {
+    fem_seqset_free(out);
+    return false;
+  }
+  uint64_t b = 0, nm = 0, k = 0;
+  for (size_t r = 0; r < n_rec; ++r) {
+    if (!rec_len[r]) continue;
+    out->off[k] = b, out->name_off[k] = nm;
+    memcpy(out->names + nm, m + name_at[r], name_len[r]);
+    uint64_t at = b;
+    for (size_t i = first_piece[r]; i < first_piece[r + 1]; ++i) piece_at[i] = at, at += pieces[i].out_len;
+    b += rec_len[r], nm += name_len[r], ++k;
+  }
+  out->off[n_keep] = nb, out->name_off[n_keep] = nn;
+  // ---- pass 2: the lines to their places ----
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+  for (int64_t i = 0; i < (int64_t)pieces.size(); ++i) {
+    const Piece &pc = pieces[(size_t)i];
+    if (!rec_len[pc.rec]) continue;
+    char *w = out->bases + piece_at[(size_t)i];
+    for (size_t p = pc.lo; p < pc.hi;) {
+      const char *e = (const char *)memchr(m + p, '\n', pc.hi - p);
+      const size_t le = e ? (size_t)(e - m) : pc.hi;
+      memcpy(w, m + p, le - p);
+      w += le - p;
+      p = le + 1;
+    }
+  }
+  memset(out->bases + nb, 0, 64);
+  return true;
+}
+}  // namespace
+
 int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
   if (!f || !out) return -1;
   if ((f->gz || f->zmap) && f->win_len > f->win_lo) {  // after batches read through the window: hand its rest to this reader
     f->fast_ok = false;
     fast_view_abandon(f, 0);
+  }
+  if (f->map && max_seqs == 0 && f->last_char == 0 && f->in->tell() == 0 && read_fasta_parallel(f, out)) {
+    f->in->seek_mem(f->map_len);
+    return 0;
   }
   std::vector<ParsedChunk> parts(1);
   int rc = 0;

@@ -217,3 +217,50 @@ def test_golden_vectors_made_from_the_reference_klib(tmp_path):
         assert [m[0] for m in mine] == names and [m[1] for m in mine] == seqs
         planned, failed = ours_planned(p, 64, 2)
         assert not failed and [m[1] for m in planned] == seqs
+
+
+def _random_fasta(rng):
+    """Multi-line FASTA as references come, plus what kseq tolerates or reacts to: blank lines, '>' inside lines, empty
+    records, comments, junk in front, lines that begin with '@' or '+', a carriage return, no final newline."""
+    out = [b"junk before\n"] if rng.random() < 0.1 else []
+    for i in range(int(rng.integers(1, 12))):
+        ln = int(rng.integers(0, 400))
+        width = int(rng.integers(5, 80))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn>"), size=ln, p=[.2, .2, .2, .2, .05, .03, .03, .03, .03, .02, .01]).astype(np.uint8))
+        lines = [seq[j:j + width] for j in range(0, ln, width)]
+        if rng.random() < 0.15:
+            lines.insert(int(rng.integers(0, len(lines) + 1)), b"")  # blank line
+        quirk = rng.random()
+        if quirk < 0.03 and lines:
+            lines[int(rng.integers(0, len(lines)))] = b"@odd"
+        elif quirk < 0.06 and lines:
+            lines[int(rng.integers(0, len(lines)))] = b"+odd"
+        elif quirk < 0.09 and lines:
+            lines[int(rng.integers(0, len(lines)))] += b"\r"
+        name = b"s%d" % i + (b"\tdesc %d" % i if rng.random() < 0.4 else b"")
+        out.append(b">" + name + b"\n" + b"".join(l + b"\n" for l in lines))
+    data = b"".join(out)
+    return data[:-1] if rng.random() < 0.2 and data.endswith(b"\n") else data
+
+
+@needs_ref
+def test_parallel_fasta_reader_follows_kseq(tmp_path, monkeypatch):
+    # fem_seqfile_read on a plain FASTA file is read_fasta_parallel (fem_host.cc) when the file is regular enough, the
+    # sequential reader otherwise: either way kseq's records.  Small pieces so that every body is cut many times.
+    rng = np.random.default_rng(31)
+    n_multi = 0
+    for case in range(600):
+        monkeypatch.setenv("FEM_FASTA_PIECE", str(int(rng.choice([16, 40, 200, 100000]))))
+        data = _random_fasta(rng)
+        p = str(tmp_path / ("r%d.fa" % case))
+        with open(p, "wb") as f:
+            f.write(data)
+        ref, fatal = loader_view(*ref_klib.kseq_records(p))
+        mine, failed = ours_sequential(p)
+        assert failed == fatal, (case, data)
+        if not fatal:
+            assert len(ref) == len(mine), (case, data)
+            for (name, _c, seq, _q), (n2, s2, _q2) in zip(ref, mine):
+                assert name == n2 and seq == s2, (case, data)
+            n_multi += len(ref) > 1
+    assert n_multi > 300
