@@ -1024,10 +1024,32 @@ int fem_index_load(const char *path, int32_t *k, int32_t *step, uint32_t **looku
   }
   if (rc == 0) {
     *occ = (uint64_t *)malloc(std::max<size_t>(n, 1) * sizeof(uint64_t));
-    if (!*occ)
+    if (!*occ) {
       rc = -4;
-    else if (n && fread(*occ, sizeof(uint64_t), n, f) != n)
-      rc = -2;
+    } else if (n) {
+      // the occurrence table is the bulk (8 GB for a 3 Gbp reference): copied out of a mapping of the file by all threads
+      // (one fread stream: 1.6-1.9 s for 8 GB; a regular file that cannot be mapped still takes that way)
+      const long at = ftell(f);
+      struct stat st;
+      void *mp = MAP_FAILED;
+      const size_t want = (size_t)at + n * sizeof(uint64_t);
+      if (at > 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size >= want)
+        mp = mmap(nullptr, want, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+      if (mp != MAP_FAILED) {
+        const char *src = (const char *)mp + at;
+        const size_t bytes = n * sizeof(uint64_t), piece = (size_t)16 << 20, n_piece = (bytes + piece - 1) / piece;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(omp_get_max_threads(), 16)))
+        for (int64_t i = 0; i < (int64_t)n_piece; ++i)
+          memcpy((char *)*occ + (size_t)i * piece, src + (size_t)i * piece, std::min(piece, bytes - (size_t)i * piece));
+        munmap(mp, want);
+      } else if (fread(*occ, sizeof(uint64_t), n, f) != n) {
+        rc = -2;
+      }
+    }
+  }
+  if (rc == 0 && n && fseek(f, 0, SEEK_END) == 0) {  // (a file shorter than its header says: the mapping would have faulted)
+    const long end = ftell(f);
+    if (end >= 0 && (size_t)end < 8 + n_lookup * sizeof(uint32_t) + sizeof(size_t) + n * sizeof(uint64_t)) rc = -2;
   }
   fclose(f);
   if (rc != 0) {

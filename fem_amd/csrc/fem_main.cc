@@ -315,6 +315,7 @@ int map_main(int argc, char **argv) {
   std::vector<fem_dev *> devs((size_t)n_gpus, nullptr);
   // FEM_TEST_SHARE_GPU=1 (test hook for one-GPU boxes): all `--gpus N` workers open GPU 0, each with its own handle, and
   // the counters are summed on the host (RCCL refuses two ranks on one device)
+  const double t_dev = real_time();
   {  // one thread per GPU uploads the replicated reference + index (src/FEM_map.c:135-143)
     std::vector<int> up_rc((size_t)n_gpus, 0);
     std::vector<std::thread> up;
@@ -331,6 +332,7 @@ int map_main(int argc, char **argv) {
       if (up_rc[(size_t)g]) return dev_fail(devs[(size_t)g], "device setup (mapping runs on the GPU; no CPU path)", up_rc[(size_t)g]);
   }
   free(lookup), free(occ);
+  fprintf(stderr, "Reference and index resident on %d GPU%s in %fs.\n", n_gpus, n_gpus > 1 ? "s" : "", real_time() - t_dev);
 
   const int out_fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
   if (out_fd < 0) {
