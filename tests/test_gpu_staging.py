@@ -146,3 +146,48 @@ print("ok", node, cpus, len(before), len(after))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith(b"ok"), r.stderr.decode()
+
+
+def test_copying_pipeline_with_changing_batches(setup):
+    # fem_dev_stage_reads over all four slots, three batches in flight, with what the packed transfer and the results that
+    # come home behind the kernels are sensitive to: batch sizes going up and down, equal and mixed read lengths, lengths
+    # that are no multiple of four, unpackable bytes, empty batches — every batch against the oracle
+    rng, seqs, ref, idx, dev = setup
+    shapes = []
+    for i in range(36):
+        n = int(rng.choice([0, 1, 7, 300, 2500, 9000]))
+        L = int(rng.choice([100, 150, 101, 64]))
+        shapes.append((n, L, rng.random() < 0.3, rng.random() < 0.3))
+    batches, wants = [], []
+    for n, L, mixed, odd in shapes:
+        reads = util.make_reads(rng, seqs, n, L, 3)
+        if mixed and n > 3:
+            reads[1] = reads[1][:L - 5]
+        if odd and n:
+            for j in range(0, n, 5):
+                r = bytearray(reads[j])
+                r[int(rng.integers(0, len(r)))] = ord("N")
+                reads[j] = bytes(r) if j % 10 else bytes(r).lower()
+        b = fo.ReadBatch(reads)
+        batches.append(b)
+        wants.append(fo.map_reads(ref, idx, b, e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY))
+    depth, n_slots = 3, 4
+
+    def check(i):
+        got = dev.fetch(slot=i % n_slots, copy=False)
+        want = wants[i]
+        off, cand, ed, end = got.per_strand()
+        assert np.array_equal(got.stats, want.stats), i
+        assert np.array_equal(off, want.cand_off) and np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed), i
+        assert np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF]), i
+
+    n_packed = 0
+    for i, b in enumerate(batches):
+        if i >= depth:
+            check(i - depth)
+        dev.stage_reads(b.bases, b.off, slot=i % n_slots)
+        n_packed += dev.stage_info(i % n_slots)[1]
+        dev.map_staged(e=3, slot=i % n_slots)
+    for i in range(len(batches) - depth, len(batches)):
+        check(i)
+    assert 8 < n_packed < len(batches)
