@@ -165,7 +165,10 @@ int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p);          /* kernels only, asynchronous */
 int fem_dev_sync(fem_dev *h, int slot);                                     /* wait; re-runs on scratch overflow */
 int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* sync + the five counters */
-int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);             /* sync + full result to the host */
+/* sync + full result to the host.  The arrays are the slot's pinned result buffers: valid until the slot is mapped
+ * again (fem_dev_map_staged / fem_dev_map_batch_submit) — behind fem_dev_stage_reads the next batch's arrays are sent
+ * home right behind its kernels, so that this call usually finds them there. */
+int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);
 /* sync + the mapping tail on the device (replaces process_mappings, src/map.c:50-54 -> src/align.c:56-92, up to
  * the point where the reference packs a bam1_t): sorted records with CIGAR and MD.  Independent of fem_dev_fetch. */
 int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
