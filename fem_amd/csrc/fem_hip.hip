@@ -1437,6 +1437,16 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
 int fem_dev_set_timing(fem_dev *h, int on) {
   if (!h) return FEM_ERR_INVALID;
   h->timing = on != 0;
+  if (h->timing && h->event_pool.size() < 64) {
+    // the events of a few batches in flight, made now: created one by one inside the first timed launches they cost those
+    // launches a millisecond each (the pipeline of bench.py was visibly slower over its first steps)
+    HIP_TRY(h, hipSetDevice(h->device));
+    while (h->event_pool.size() < 64) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(h, hipEventCreate(&e));
+      h->event_pool.push_back(e);
+    }
+  }
   return FEM_OK;
 }
 
