@@ -143,22 +143,6 @@ class StagePool {
 
  private:
   void loop(unsigned id) {
-    if (const char *e = getenv("FEM_STAGE_PIN")) {  // experiment: worker i on the i-th CPU this process may use
-      if (e[0] == '1') {
-        cpu_set_t now, one;
-        CPU_ZERO(&now);
-        CPU_ZERO(&one);
-        if (sched_getaffinity(0, sizeof now, &now) == 0) {
-          unsigned k = 0;
-          for (int c = 0; c < CPU_SETSIZE; ++c)
-            if (CPU_ISSET(c, &now) && k++ == id) {
-              CPU_SET(c, &one);
-              (void)sched_setaffinity(0, sizeof one, &one);
-              break;
-            }
-        }
-      }
-    }
     uint64_t seen = 0;
     for (;;) {
       const std::function<void(unsigned)> *w = nullptr;
