@@ -191,3 +191,33 @@ def test_copying_pipeline_with_changing_batches(setup):
     for i in range(len(batches) - depth, len(batches)):
         check(i)
     assert 8 < n_packed < len(batches)
+
+
+def test_two_handles_from_two_threads(setup):
+    # handles are independent (include/fem_hip.h): two of them on one GPU, each driven by its own host thread through the
+    # copying entry point (own staging threads, own streams), give what one gives
+    import threading
+    from fem_amd import Device
+    rng, seqs, ref, idx, dev = setup
+    other = Device(0)
+    other.upload_reference(seqs)
+    other.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    batches = [fo.ReadBatch(util.make_reads(rng, seqs, 20_000, 100, 3)) for _ in range(2)]
+    wants = [fo.map_reads(ref, idx, b, e=3, stages=fo.STAGE_SEED | fo.STAGE_VERIFY) for b in batches]
+    errors = []
+
+    def work(d, b, want):
+        try:
+            for rep in range(6):
+                got = d.map_batch(b.bases, b.off, e=3, slot=rep % 4)
+                assert np.array_equal(got.stats, want.stats) and np.array_equal(got.per_strand()[1], want.cands)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(d, b, w)) for d, b, w in zip((dev, other), batches, wants)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    other.close()
+    assert not errors, errors
