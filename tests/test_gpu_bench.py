@@ -31,7 +31,11 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert d["config"]["counters"]["reads"] == 3 * 200000 and d["config"]["kernel_only_mreads"] > 0
     assert d["cpu_baseline"]["counters_match_device"] is True and d["cpu_baseline"]["kind"] == "port"
-    assert d["e2e_cli"].get("value", 0) > 0, d["e2e_cli"]
+    assert d["e2e_cli"].get("value", 0) > 0 and d["e2e_cli"]["to_dev_null"]["value"] > 0, d["e2e_cli"]
+    c = d["config"]
+    # the timed steps + the W warm-up steps + the disclosed priming steps are all the batches the workload saw before / in them
+    assert c["priming_steps"] == 12 - 2 and c["h2d_packed"] is True and c["h2d_bytes_per_step"] == 200000 * 25
+    assert c["zero_copy_ascii_mreads"] > 0 and c["zero_copy_h2d_bytes_per_step"] == 200000 * 100
 
 
 def test_two_ranks_start_by_themselves_and_reduce_their_counters():
