@@ -1,0 +1,72 @@
+"""Randomised differential run: device path vs oracle over references of every index density, random parameters, read
+lengths, damage.  Not collected by pytest (minutes of oracle time): FUZZ_SECONDS=420 FUZZ_SEED=11 python tests/fuzz_gpu.py."""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+from fem_amd import Device, host
+from oracle import fem_oracle as fo
+from tests import util
+
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+T_END = time.time() + float(os.environ.get("FUZZ_SECONDS", "240"))
+bad = 0
+n_trials = 0
+
+def reference(kind):
+    if kind == "dense":
+        text, off, lens = host.synth_reference(int(rng.integers(1, 1 << 30)), [72_000_000] * 3, threads=16)
+        return [text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+    if kind == "mid":
+        text, off, lens = host.synth_reference(int(rng.integers(1, 1 << 30)), [30_000_000, 5_000_000, 1000, 13], threads=16)
+        return [text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+    if kind == "sparse":
+        text, off, lens = host.synth_reference(int(rng.integers(1, 1 << 30)), [3_000_000, 2_000_000], threads=16)
+        return [text[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+    seqs = util.repeat_rich_reference(rng, n_seq=3, unit_len=300, n_units=6, copies=60, spacer=150)
+    seqs.append(util.rand_seq(rng, 200_000))
+    return seqs
+
+def trial(dev, ref, idx, seqs, kind):
+    global bad, n_trials
+    e = int(rng.integers(0, 8)); a = int(rng.choice([1, 1, 1, 2]))
+    L = int(rng.integers(30, 301)); n = int(rng.integers(500, 6000 if kind == "repeat" else 15000))
+    reads = util.make_reads(rng, seqs, n, L, min(e + 2, 9), n_rate=float(rng.choice([0, 0, 0.002, 0.02])))
+    if rng.random() < 0.4:  # mixed lengths
+        for j in range(0, n, 3):
+            reads[j] = reads[j][:int(rng.integers(max(1, L // 3), L + 1))]
+    if rng.random() < 0.3:
+        for j in range(0, n, 11):
+            reads[j] = reads[j].lower()
+    for j in range(0, n, 97):
+        reads[j] = util.rand_seq(rng, len(reads[j]))
+    b = fo.ReadBatch(reads)
+    full = kind != "dense" and n < 8000
+    want = fo.map_reads(ref, idx, b, e=e, a=a, threads=16, stages=(fo.STAGE_SEED | fo.STAGE_VERIFY | (fo.STAGE_ALIGN if full else 0)))
+    slot = int(rng.integers(0, 4))
+    dev.stage_reads(b.bases, b.off, slot=slot)
+    dev.map_staged(e=e, a=a, slot=slot)
+    got = dev.fetch(slot=slot)
+    o, cand, ed, end = got.per_strand()
+    ok = (np.array_equal(o, want.cand_off) and np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed)
+          and np.array_equal(got.stats, want.stats) and np.array_equal(end[ed != 255], want.v_end[want.v_ed != 255]))
+    if ok and full:
+        rec = dev.fetch_records(slot=slot)
+        ok = (np.array_equal(rec.rec_begin, want.rec_off) and np.array_equal(rec.flag & 0x7FFF, want.r_flag & 0x7FFF) and np.array_equal(rec.pos0, want.r_pos)
+              and np.array_equal(rec.nm, want.r_nm) and np.array_equal(rec.cigar_off, want.cig_off) and np.array_equal(rec.cigar, want.cig)
+              and np.array_equal(rec.md_off, want.md_off) and np.array_equal(rec.md, want.md))
+    n_trials += 1
+    print(kind, dict(e=e, a=a, L=L, n=n, packed=dev.stage_info(slot)[1], full=full, kernel=dev.seed_kernel(e=e, a=a)), "ok" if ok else "MISMATCH",
+          [int(x) for x in got.stats], flush=True)
+    bad += not ok
+
+for kind in ("repeat", "sparse", "mid", "dense"):
+    if time.time() > T_END: break
+    seqs = reference(kind)
+    ref = fo.Reference(seqs); idx = fo.OracleIndex(ref, threads=16)
+    dev = Device(0); dev.upload_reference(seqs); dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    t_kind = time.time() + (T_END - time.time()) / {"repeat": 4, "sparse": 3, "mid": 2, "dense": 1}[kind]
+    while time.time() < t_kind:
+        trial(dev, ref, idx, seqs, kind)
+    dev.close()
+print("trials", n_trials, "bad", bad)
+sys.exit(1 if bad else 0)
