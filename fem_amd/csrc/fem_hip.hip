@@ -62,6 +62,14 @@ struct Slot {
   uint64_t *h_off = nullptr;
   size_t h_off_cap = 0;
   uint64_t acq_reads = 0, acq_bases = 0;  // what the last fem_dev_acquire_stage asked for
+  // qualities and names for the device SAM text (fem_dev_acquire_text_stage / fem_dev_fetch_sam): pinned staging + copies in HBM
+  char *h_quals = nullptr, *h_names = nullptr;
+  uint64_t *h_name_off = nullptr;
+  size_t h_quals_cap = 0, h_names_cap = 0, h_name_off_cap = 0;
+  uint8_t *d_quals = nullptr, *d_names = nullptr;
+  uint64_t *d_name_off = nullptr;
+  size_t d_quals_cap = 0, d_names_cap = 0, d_name_off_cap = 0;
+  bool text_staged = false;
   uint8_t *d_packed = nullptr;            // packed transfer (fem_dev_stage_reads): 2-bit codes + positions of other characters
   size_t packed_cap = 0;
   // fem_dev_fetch callers get the result arrays sent home behind the kernels, without the host waiting for the batch first:
@@ -170,6 +178,8 @@ class StagePool {
 struct fem_dev {
   int device = 0;
   StagePool *stage_pool = nullptr;  // host threads of fem_dev_stage_reads
+  uint8_t *d_ref_names = nullptr;   // reference sequence names for the device SAM text
+  uint32_t *d_ref_name_off = nullptr;
   int n_cu = 256;
   std::string err;
   // index
@@ -199,8 +209,8 @@ struct fem_dev {
   Slot slot[kSlots];
   bool timing = false;
   int verify_blocks_per_cu = 0;  // resident 256-thread blocks of verify_kernel per CU (queried once)
-  double t_ms[7] = {0, 0, 0, 0, 0, 0, 0};
-  uint64_t t_n[7] = {0, 0, 0, 0, 0, 0, 0};
+  double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t t_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
   bool force_dense = false;    // FEM_FORCE_DENSE=1: build the 32-bit tables and run seed_dense_kernel whatever the index density (test hook)
@@ -938,15 +948,18 @@ int fem_dev_close(fem_dev *h) {
     drain_timing(h, s);
     for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
-                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_packed})
+                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_packed, (void *)s.d_quals, (void *)s.d_names,
+                    (void *)s.d_name_off})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
-                    (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off})
+                    (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off, (void *)s.h_quals, (void *)s.h_names, (void *)s.h_name_off})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     delete s.tail;
     s.tail = nullptr;
   }
+  if (h->d_ref_names) (void)hipFree(h->d_ref_names);
+  if (h->d_ref_name_off) (void)hipFree(h->d_ref_name_off);
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
@@ -1079,7 +1092,7 @@ int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n
   drain_timing(h, s);
   if ((rc = pinned_realloc(h, &s.h_bases, &s.h_bases_cap, (size_t)n_bases_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_off, &s.h_off_cap, (size_t)n_reads_cap + 1))) return rc;
-  s.staged = false, s.mapped = false, s.synced = false;
+  s.staged = false, s.mapped = false, s.synced = false, s.text_staged = false;
   s.acq_reads = n_reads_cap, s.acq_bases = n_bases_cap;
   *bases = s.h_bases, *offsets = s.h_off;
   return FEM_OK;
@@ -1401,6 +1414,101 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   return FEM_OK;
 }
 
+int fem_dev_upload_reference_names(fem_dev *h, uint32_t n_seq, const char *names, const uint64_t *name_off) {
+  if (!h || !names || !name_off || n_seq == 0) return FEM_ERR_INVALID;
+  if (h->n_seq && n_seq != h->n_seq) return fail(h, FEM_ERR_INVALID, "as many names as reference sequences, please");
+  if (name_off[n_seq] < name_off[0] || name_off[n_seq] - name_off[0] > 0xFFFFFFF0ull) return fail(h, FEM_ERR_INVALID, "name offsets out of range");
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<uint32_t> off(n_seq + 1);
+  for (uint32_t i = 0; i <= n_seq; ++i) {
+    if (name_off[i] < name_off[0] || (i && name_off[i] < name_off[i - 1])) return fail(h, FEM_ERR_INVALID, "name offsets must be ascending");
+    off[i] = (uint32_t)(name_off[i] - name_off[0]);
+  }
+  if (h->d_ref_names) (void)hipFree(h->d_ref_names);
+  if (h->d_ref_name_off) (void)hipFree(h->d_ref_name_off);
+  h->d_ref_names = nullptr, h->d_ref_name_off = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref_names, std::max<size_t>(off[n_seq], 1)));
+  HIP_TRY(h, hipMalloc((void **)&h->d_ref_name_off, (n_seq + 1) * sizeof(uint32_t)));
+  if (off[n_seq]) HIP_TRY(h, hipMemcpy(h->d_ref_names, names + name_off[0], off[n_seq], hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_ref_name_off, off.data(), (n_seq + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return FEM_OK;
+}
+
+int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, uint64_t n_name_bytes_cap, char **quals,
+                               char **names, uint64_t **name_off) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  if (!quals || !names || !name_off) return fail(h, FEM_ERR_INVALID, "null output pointer");
+  Slot &s = h->slot[slot];
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(s.stream));  // the previous batch's copies out of these buffers are done
+  if ((rc = pinned_realloc(h, &s.h_quals, &s.h_quals_cap, (size_t)n_bases_cap + 64))) return rc;
+  if ((rc = pinned_realloc(h, &s.h_names, &s.h_names_cap, (size_t)n_name_bytes_cap + 64))) return rc;
+  if ((rc = pinned_realloc(h, &s.h_name_off, &s.h_name_off_cap, (size_t)n_reads_cap + 1))) return rc;
+  s.text_staged = false;
+  *quals = s.h_quals, *names = s.h_names, *name_off = s.h_name_off;
+  return FEM_OK;
+}
+
+int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!s.staged) return fail(h, FEM_ERR_STATE, "commit the reads of the batch first");
+  if (!s.h_quals || !s.h_names || !s.h_name_off) return fail(h, FEM_ERR_STATE, "acquire the slot's text staging buffers first");
+  if (n_reads != s.n_reads) return fail(h, FEM_ERR_INVALID, "as many names as reads, please");
+  if (s.n_bases + 64 > s.h_quals_cap || n_name_bytes + 64 > s.h_names_cap || n_reads + 1 > s.h_name_off_cap)
+    return fail(h, FEM_ERR_INVALID, "more qualities or names than the text staging buffers were acquired for");
+  if (n_reads && (s.h_name_off[0] != 0 || s.h_name_off[n_reads] != n_name_bytes))
+    return fail(h, FEM_ERR_INVALID, "name offsets must start at 0 and end at the number of name bytes");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((rc = dev_realloc(h, &s.d_quals, &s.d_quals_cap, (size_t)s.n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_names, &s.d_names_cap, (size_t)n_name_bytes + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_name_off, &s.d_name_off_cap, (size_t)n_reads + 1))) return rc;
+  if (s.n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, s.n_bases, hipMemcpyHostToDevice, s.stream));
+  if (n_name_bytes) HIP_TRY(h, hipMemcpyAsync(s.d_names, s.h_names, n_name_bytes, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(h, hipMemcpyAsync(s.d_name_off, s.h_name_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  s.text_staged = true;
+  return FEM_OK;
+}
+
+int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out) {
+  int rc = fem_dev_sync(h, slot);
+  if (rc) return rc;
+  if (!out) return fail(h, FEM_ERR_INVALID, "null result");
+  Slot &s = h->slot[slot];
+  if (!s.text_staged) return fail(h, FEM_ERR_STATE, "qualities and names of this batch were not committed (fem_dev_commit_text_stage)");
+  if (!h->d_ref_names) return fail(h, FEM_ERR_STATE, "reference names must be uploaded first (fem_dev_upload_reference_names)");
+  s.prefetch_results = false;
+  if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
+  if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
+  femt::TailInput in{};
+  in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
+  in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
+  for (int q = 0; q < 4; ++q) in.plane[q] = h->d_plane[q];
+  in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
+  in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
+  femt::TailOutput t{};
+  double ms[3] = {0, 0, 0}, ms_text = 0;
+  std::string err;
+  rc = s.tail->run(in, s.stream, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr, false);
+  if (rc) return fail(h, rc, err);
+  femt::SamInput names{};
+  names.quals = s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
+  names.ref_names = h->d_ref_names, names.ref_name_off = h->d_ref_name_off;
+  femt::SamOutput text{};
+  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr);
+  if (rc) return fail(h, rc, err);
+  if (h->timing) {
+    for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;
+    h->t_ms[7] += ms_text, h->t_n[7] += 1;
+  }
+  out->text = text.text, out->len = text.len, out->n_asserted = text.n_asserted;
+  out->n_reads = t.n_reads, out->n_records = t.n_records;
+  memcpy(out->stats, s.stats, sizeof s.stats);
+  return FEM_OK;
+}
+
 int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fem_read_batch *reads) {
   int rc = fem_dev_stage_reads(h, slot, reads);
   if (rc) return rc;
@@ -1436,12 +1544,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
-  for (int i = 0; i < 7; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
+  for (int i = 0; i < 8; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
   return FEM_OK;
 }
 
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
-  if (!h || kernel < 0 || kernel > 6) return FEM_ERR_INVALID;
+  if (!h || kernel < 0 || kernel > 7) return FEM_ERR_INVALID;
   if (ms_total) *ms_total = h->t_ms[kernel];
   if (launches) *launches = h->t_n[kernel];
   return FEM_OK;

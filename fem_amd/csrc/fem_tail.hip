@@ -993,18 +993,160 @@ struct PinBuf {
   T *as() const { return (T *)p; }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------
+// SAM text.  One line per record, the fields generate_bam1_t packs (src/align.c:546-632) as htslib's sam_format1 prints
+// them: QNAME FLAG RNAME POS 255 CIGAR * 0 0 SEQ QUAL NM:i MD:Z.  SEQ is the read as it came (src/align.c:79) through
+// the 4-bit round trip of the BAM record (seq_nt16_table / seq_nt16_str: IUPAC letters upper-cased, anything else N);
+// only a read's first record carries SEQ and QUAL (src/align.c:83-88).  Same bytes as fem_records_sam (fem_host.cc).
+// ---------------------------------------------------------------------------------------------------------
+__device__ const uint8_t kSamSeqLut[256] = {
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78,
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 65, 67, 71, 84, 78, 78, 78, 78, 78, 78, 78, 78, 78, 61, 78, 78,
+    78, 65, 66, 67, 68, 78, 78, 71, 72, 78, 78, 75, 78, 77, 78, 78, 78, 78, 82, 83, 84, 78, 86, 87, 78, 89, 78, 78, 78, 78, 78, 78,
+    78, 65, 66, 67, 68, 78, 78, 71, 72, 78, 78, 75, 78, 77, 78, 78, 78, 78, 82, 83, 84, 78, 86, 87, 78, 89, 78, 78, 78, 78, 78, 78,
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78,
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78,
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78,
+    78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78, 78,
+};
+
+struct SamParams {
+  uint32_t n_records;
+  const uint32_t *rec_begin, *s_read;
+  const uint16_t *flag;
+  const uint32_t *tid, *pos0;
+  const uint8_t *nm;
+  const uint32_t *cigar_off, *cigar, *md_off;
+  const uint8_t *md;
+  const uint8_t *bases;
+  const uint64_t *read_off;
+  const uint8_t *quals, *names;
+  const uint64_t *name_off;
+  const uint8_t *ref_names;
+  const uint32_t *ref_name_off;
+  unsigned long long *line_len;        // n_records + 1 (the last one zero)
+  const unsigned long long *line_off;  // exclusive scan of line_len
+  uint8_t *text;
+  uint32_t *asserted;
+};
+
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+  return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u
+       : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ uint8_t *put_dec(uint8_t *w, uint32_t v) {
+  const uint32_t n = dec_digits(v);
+  for (uint32_t i = n; i-- > 0;) {
+    w[i] = (uint8_t)('0' + v % 10u);
+    v /= 10u;
+  }
+  return w + n;
+}
+
+__global__ void __launch_bounds__(256) sam_len_kernel(SamParams p) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j <= p.n_records; j += stride) {
+    if (j == p.n_records) {
+      p.line_len[j] = 0;
+      continue;
+    }
+    const uint32_t r = p.s_read[j];
+    const bool primary = p.rec_begin[r] == j;
+    const uint32_t L = (uint32_t)(p.read_off[r + 1] - p.read_off[r]);
+    const uint32_t name_len = (uint32_t)(p.name_off[r + 1] - p.name_off[r]);
+    const uint32_t t = p.tid[j], rname_len = p.ref_name_off[t + 1] - p.ref_name_off[t];
+    const uint16_t flag = p.flag[j];
+    if (flag & 0x8000u) atomicAdd(p.asserted, 1u);
+    uint32_t cig = 0;
+    const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1];
+    for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
+    if (c1 == c0) cig = 1;  // '*'
+    const uint32_t md_len = p.md_off[j + 1] - p.md_off[j];
+    const uint32_t seq_qual = primary && L > 0 ? L + 1u + (p.quals ? L : 1u) : 3u;
+    p.line_len[j] = (unsigned long long)name_len + 1u + dec_digits(flag & 0x7FFFu) + 1u + rname_len + 1u + dec_digits(p.pos0[j] + 1u) + 5u + cig +
+                    7u + seq_qual + 6u + dec_digits(p.nm[j]) + 6u + md_len + 1u;
+  }
+}
+
+// one wave per record: the long fields by all lanes, the numbers by lane 0
+__global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
+  const uint32_t ln = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t j = wave; j < p.n_records; j += n_waves) {
+    const uint32_t r = p.s_read[j];
+    const bool primary = p.rec_begin[r] == j;
+    const uint64_t ro = p.read_off[r];
+    const uint32_t L = (uint32_t)(p.read_off[r + 1] - ro);
+    const uint64_t no = p.name_off[r];
+    const uint32_t name_len = (uint32_t)(p.name_off[r + 1] - no);
+    const uint32_t t = p.tid[j], rn0 = p.ref_name_off[t], rname_len = p.ref_name_off[t + 1] - rn0;
+    const uint32_t flag = p.flag[j] & 0x7FFFu, pos1 = p.pos0[j] + 1u, nm = p.nm[j];
+    const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1], m0 = p.md_off[j], md_len = p.md_off[j + 1] - m0;
+    uint32_t cig = 0;
+    for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
+    if (c1 == c0) cig = 1;
+    const bool seq = primary && L > 0;
+    uint8_t *w = p.text + p.line_off[j];
+    // field starts
+    uint8_t *w_flag = w + name_len + 1u;
+    uint8_t *w_rname = w_flag + dec_digits(flag) + 1u;
+    uint8_t *w_pos = w_rname + rname_len + 1u;
+    uint8_t *w_cig = w_pos + dec_digits(pos1) + 5u;
+    uint8_t *w_seq = w_cig + cig + 7u;
+    uint8_t *w_nm = w_seq + (seq ? L + 1u + (p.quals ? L : 1u) : 3u) + 6u;
+    uint8_t *w_md = w_nm + dec_digits(nm) + 6u;
+    for (uint32_t k = ln; k < name_len; k += 64u) w[k] = p.names[no + k];
+    for (uint32_t k = ln; k < rname_len; k += 64u) w_rname[k] = p.ref_names[rn0 + k];
+    for (uint32_t k = ln; k < md_len; k += 64u) w_md[k] = p.md[m0 + k];
+    if (seq) {
+      for (uint32_t k = ln; k < L; k += 64u) w_seq[k] = kSamSeqLut[p.bases[ro + k]];
+      if (p.quals)
+        for (uint32_t k = ln; k < L; k += 64u) w_seq[L + 1u + k] = p.quals[ro + k];
+    }
+    if (ln == 0) {
+      w[name_len] = '\t';
+      put_dec(w_flag, flag)[0] = '\t';
+      w_rname[rname_len] = '\t';
+      uint8_t *q = put_dec(w_pos, pos1);
+      q[0] = '\t', q[1] = '2', q[2] = '5', q[3] = '5', q[4] = '\t';
+      q = w_cig;
+      if (c1 == c0) *q++ = '*';
+      for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t op = p.cigar[c];
+        q = put_dec(q, op >> 4);
+        *q++ = (uint8_t)"MIDNSHP=XB"[op & 0xFu];
+      }
+      q[0] = '\t', q[1] = '*', q[2] = '\t', q[3] = '0', q[4] = '\t', q[5] = '0', q[6] = '\t';
+      if (seq) {
+        w_seq[L] = '\t';
+        if (!p.quals) w_seq[L + 1u] = '*';
+      } else {
+        w_seq[0] = '*', w_seq[1] = '\t', w_seq[2] = '*';
+      }
+      q = w_nm - 6u;
+      q[0] = '\t', q[1] = 'N', q[2] = 'M', q[3] = ':', q[4] = 'i', q[5] = ':';
+      q = put_dec(w_nm, nm);
+      q[0] = '\t', q[1] = 'M', q[2] = 'D', q[3] = ':', q[4] = 'Z', q[5] = ':';
+      w_md[md_len] = '\n';
+    }
+  }
+}
+
 }  // namespace
 
 struct Tail::Impl {
   DevBuf rec_begin, queue, ctl, u_cand, u_misc, s_cand, s_misc, s_read, t_ops, t_md, o_ops, o_md, ovf, rec_list, src_slot, n_ops, n_md,
       flag, tid, pos0, nm, cigar_off, md_off, cigar, md, scan_tmp;
-  PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md;
+  DevBuf line_len, line_off, text;
+  PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md, h_text;
+  uint32_t last_n = 0, last_nr = 0;  // what the last run() left on the device
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   ~Impl() {
     for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf, &rec_list,
-                      &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp})
+                      &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp, &line_len, &line_off, &text})
       b->release();
-    for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md})
+    for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md, &h_text})
       b->release();
     for (hipEvent_t e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -1022,7 +1164,8 @@ Tail::~Tail() { delete impl_; }
     }                                                                              \
   } while (0)
 
-int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms) {
+int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms,
+              bool copy_records) {
   if (!impl_) impl_ = new (std::nothrow) Impl();
   if (!impl_) return FEM_ERR_NOMEM;
   Impl &m = *impl_;
@@ -1177,6 +1320,24 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     TAIL_TRY(hipGetLastError());
   }
   TAIL_TRY(hipEventRecord(m.ev[3], stream));
+  m.last_n = n, m.last_nr = nr;
+  if (!copy_records) {  // the caller renders them on the device (sam())
+    TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipStreamSynchronize(stream));
+    if (h_ctl[2] != 0) {
+      if (err) *err = "device traceback: a record outgrew the overflow staging (internal error)";
+      return FEM_ERR_HIP;
+    }
+    if (ms) {
+      for (int i = 0; i < 3; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, m.ev[i], m.ev[i + 1]) == hipSuccess) ms[i] += t;
+      }
+    }
+    memset(out, 0, sizeof *out);
+    out->n_reads = n, out->n_records = nr;
+    return FEM_OK;
+  }
   // ---- copy back ----
   TAIL_TRY(m.h_rec_begin.need(((size_t)n + 1) * 4));
   TAIL_TRY(m.h_flag.need(r1 * 2));
@@ -1216,6 +1377,58 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   out->nm = m.h_nm.as<uint8_t>();
   out->cigar_off = m.h_cigar_off.as<uint32_t>(), out->cigar = m.h_cigar.as<uint32_t>();
   out->md_off = m.h_md_off.as<uint32_t>(), out->md = m.h_md.as<char>();
+  return FEM_OK;
+}
+
+
+int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms) {
+  if (!impl_ || !out) return FEM_ERR_STATE;
+  Impl &m = *impl_;
+  const uint32_t nr = m.last_nr;
+  const size_t r1 = (size_t)nr + 1;
+  for (hipEvent_t &e : m.ev)
+    if (!e) TAIL_TRY(hipEventCreate(&e));
+  TAIL_TRY(m.line_len.need(r1 * 8));
+  TAIL_TRY(m.line_off.need(r1 * 8));
+  TAIL_TRY(m.h_ctl.need(32));
+  size_t tmp = 0;
+  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp, m.line_len.as<unsigned long long>(), m.line_off.as<unsigned long long>(), 0ull, r1,
+                                   rocprim::plus<unsigned long long>(), stream));
+  TAIL_TRY(m.scan_tmp.need(std::max<size_t>(tmp, 16)));
+  SamParams p{};
+  p.n_records = nr, p.rec_begin = m.rec_begin.as<uint32_t>(), p.s_read = m.s_read.as<uint32_t>();
+  p.flag = m.flag.as<uint16_t>(), p.tid = m.tid.as<uint32_t>(), p.pos0 = m.pos0.as<uint32_t>(), p.nm = m.nm.as<uint8_t>();
+  p.cigar_off = m.cigar_off.as<uint32_t>(), p.cigar = m.cigar.as<uint32_t>(), p.md_off = m.md_off.as<uint32_t>(), p.md = m.md.as<uint8_t>();
+  p.bases = in.bases, p.read_off = in.read_off;
+  p.quals = names.quals, p.names = names.names, p.name_off = names.name_off, p.ref_names = names.ref_names, p.ref_name_off = names.ref_name_off;
+  p.line_len = m.line_len.as<unsigned long long>(), p.line_off = m.line_off.as<unsigned long long>();
+  p.asserted = m.ctl.as<uint32_t>() + 2;  // (ctl[2] is zero after a successful run())
+  unsigned long long *h_total = (unsigned long long *)(m.h_ctl.as<uint32_t>() + 6);
+  TAIL_TRY(hipEventRecord(m.ev[0], stream));
+  hipLaunchKernelGGL(sam_len_kernel, dim3(std::max<uint32_t>(1u, std::min<uint32_t>((nr + 256u) / 256u, (uint32_t)n_cu * 16u))), dim3(256), 0, stream, p);
+  TAIL_TRY(hipGetLastError());
+  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, m.scan_tmp.cap, m.line_len.as<unsigned long long>(), m.line_off.as<unsigned long long>(), 0ull,
+                                   r1, rocprim::plus<unsigned long long>(), stream));
+  TAIL_TRY(hipMemcpyAsync(h_total, m.line_off.as<unsigned long long>() + nr, 8, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(m.h_ctl.as<uint32_t>() + 2, m.ctl.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipStreamSynchronize(stream));
+  const uint64_t total = *h_total;
+  TAIL_TRY(m.text.need(std::max<size_t>((size_t)total, 16)));
+  TAIL_TRY(m.h_text.need(std::max<size_t>((size_t)total + total / 8, 1u << 20)));
+  if (nr) {
+    p.text = m.text.as<uint8_t>();
+    const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((nr + 3u) / 4u, (uint32_t)n_cu * 32u));
+    hipLaunchKernelGGL(sam_write_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    TAIL_TRY(hipGetLastError());
+  }
+  TAIL_TRY(hipEventRecord(m.ev[1], stream));
+  if (total) TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, (size_t)total, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipStreamSynchronize(stream));
+  if (ms) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, m.ev[0], m.ev[1]) == hipSuccess) *ms += t;
+  }
+  out->text = m.h_text.as<char>(), out->len = total, out->n_asserted = m.h_ctl.as<uint32_t>()[2];
   return FEM_OK;
 }
 

@@ -44,6 +44,21 @@ struct TailOutput {  // pinned host memory owned by the Tail object, valid until
   const char *md;
 };
 
+// ---- SAM text on the device: the records of the last run() rendered as the reference's output lines
+//      (generate_bam1_t + htslib's SAM writer, src/align.c:546-632, src/output_queue.c:93-116) ----
+struct SamInput {  // device pointers
+  const uint8_t *quals;          // quality characters, same offsets as the bases
+  const uint8_t *names;          // read names, concatenated
+  const uint64_t *name_off;      // n_reads + 1
+  const uint8_t *ref_names;      // reference sequence names, concatenated
+  const uint32_t *ref_name_off;  // n_seq + 1
+};
+struct SamOutput {  // pinned host memory owned by the Tail object, valid until its next sam()
+  const char *text;
+  uint64_t len;
+  uint64_t n_asserted;  // records on which the reference would have tripped an assertion (written with CIGAR *)
+};
+
 class Tail {
  public:
   Tail() = default;
@@ -52,7 +67,11 @@ class Tail {
   Tail &operator=(const Tail &) = delete;
   // Runs on `stream` and waits for it.  ms[0..2] (optional) receive the device time of: ordering, traceback, compaction.
   // tiny = test hook: per-record CIGAR/MD staging starts far too small so that the overflow pass runs.
-  int run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms);
+  // copy_records = false: the records stay on the device (for sam()); *out then only carries the counts.
+  int run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms,
+          bool copy_records = true);
+  // The records of the last run() as SAM lines, in record order.  ms (optional) receives the device time.
+  int sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms);
 
  private:
   struct Impl;

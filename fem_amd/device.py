@@ -14,6 +14,7 @@ ABI_SYMBOLS = [
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
+    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_fetch_sam",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
     "fem_device_numa", "fem_bind_thread_near_device",
@@ -44,6 +45,11 @@ class _BatchRecords(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_records", C.c_uint64), ("rec_begin", C.c_void_p), ("flag", C.c_void_p),
                 ("tid", C.c_void_p), ("pos0", C.c_void_p), ("nm", C.c_void_p), ("cigar_off", C.c_void_p),
                 ("cigar", C.c_void_p), ("md_off", C.c_void_p), ("md", C.c_void_p), ("stats", C.c_uint64 * 5)]
+
+
+class _BatchSam(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("len", C.c_uint64), ("n_reads", C.c_uint64), ("n_records", C.c_uint64),
+                ("n_asserted", C.c_uint64), ("stats", C.c_uint64 * 5)]
 
 
 def hip_library_path():
@@ -92,6 +98,10 @@ def load_hip():
     L.fem_dev_copy_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_h2d_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
     L.fem_dev_allreduce_stats.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.fem_dev_upload_reference_names.argtypes = [vp, C.c_uint32, C.c_char_p, vp]
+    L.fem_dev_acquire_text_stage.argtypes = [vp, C.c_int, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
+    L.fem_dev_fetch_sam.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_stage_info.argtypes = [vp, C.c_int, C.POINTER(u64), C.POINTER(C.c_int32)]
     L.fem_device_numa.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_char_p, u64]
     L.fem_bind_thread_near_device.argtypes = [C.c_int]
@@ -287,6 +297,36 @@ class Device:
         r = _BatchRecords()
         self._check(self._L.fem_dev_fetch_records(self._h, slot, C.byref(r)))
         return BatchRecords(r)
+
+    def upload_reference_names(self, names):
+        """names: list of str / bytes, one per reference sequence (the @SQ names)."""
+        raw = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+        off = np.zeros(len(raw) + 1, np.uint64)
+        off[1:] = np.cumsum([len(n) for n in raw])
+        self._check(self._L.fem_dev_upload_reference_names(self._h, len(raw), b"".join(raw), off.ctypes.data))
+
+    def stage_text(self, quals, names, slot=0):
+        """Qualities (uint8 array / bytes, same offsets as the staged bases) and read names (list) of the slot's batch."""
+        raw = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+        q = np.frombuffer(bytes(quals), np.uint8) if not isinstance(quals, np.ndarray) else quals
+        nn = sum(len(n) for n in raw)
+        pq, pn, po = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._L.fem_dev_acquire_text_stage(self._h, slot, len(raw), len(q), nn, C.byref(pq), C.byref(pn), C.byref(po)))
+        if len(q):
+            C.memmove(pq.value, q.ctypes.data, len(q))
+        if nn:
+            C.memmove(pn.value, b"".join(raw), nn)
+        off = np.zeros(len(raw) + 1, np.uint64)
+        off[1:] = np.cumsum([len(n) for n in raw])
+        C.memmove(po.value, off.ctypes.data, 8 * (len(raw) + 1))
+        self._check(self._L.fem_dev_commit_text_stage(self._h, slot, len(raw), nn))
+
+    def fetch_sam(self, slot=0):
+        """(SAM text of the slot's batch as bytes, n_records, n_asserted, stats) — rendered on the device."""
+        r = _BatchSam()
+        self._check(self._L.fem_dev_fetch_sam(self._h, slot, C.byref(r)))
+        text = C.string_at(r.text, r.len) if r.len else b""
+        return text, int(r.n_records), int(r.n_asserted), np.array(list(r.stats), dtype=np.uint64)
 
     def map_batch(self, bases, offsets, e=3, a=1, k=12, step=3, slot=0):
         b, keep = self._batch(bases, offsets)

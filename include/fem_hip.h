@@ -99,6 +99,18 @@ typedef struct {
   uint64_t stats[5];
 } fem_batch_records;
 
+/* The batch's output as SAM text, rendered on the device (replaces process_mappings + generate_bam1_t + the SAM writer,
+ * src/align.c:56-92,546-632, src/output_queue.c:93-116, for the batch): the lines of every mapped read, reads in batch
+ * order, a read's records in the reference's order.  Pinned host memory owned by the library, valid until the slot is
+ * fetched this way again. */
+typedef struct {
+  const char *text;
+  uint64_t len;
+  uint64_t n_reads, n_records;
+  uint64_t n_asserted; /* records on which the reference would have tripped an assertion: written with CIGAR * */
+  uint64_t stats[5];
+} fem_batch_sam;
+
 typedef struct fem_dev fem_dev;
 
 /* ---- lifetime ---- */
@@ -173,6 +185,18 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);
  * the point where the reference packs a bam1_t): sorted records with CIGAR and MD.  Independent of fem_dev_fetch. */
 int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
 
+/* ---- SAM text on the device ----
+ * upload_reference_names: the @SQ names (first token of every FASTA header), once, next to the reference.
+ * acquire_text_stage / commit_text_stage: pinned staging for the batch's quality strings (same offsets as the bases)
+ *   and read names (name i = names[name_off[i] .. name_off[i+1])), filled by the parser like the bases; commit after
+ *   fem_dev_commit_stage* of the same batch, asynchronous.
+ * fetch_sam: sync + mapping tail + text, all on the device; one D2H copy of the finished lines. */
+int fem_dev_upload_reference_names(fem_dev *h, uint32_t n_seq, const char *names, const uint64_t *name_off);
+int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, uint64_t n_name_bytes_cap,
+                               char **quals, char **names, uint64_t **name_off);
+int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes);
+int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out);
+
 /* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident
  * index ("seed_dense_kernel", "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or "seed_filter_kernel"); the
  * generic seed_filter_kernel always follows for whatever that one queues.  Static string. */
@@ -186,7 +210,7 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
  * form queued, or every read when the fast form does not apply); of
  * fem_dev_fetch_records: 3 = ordering of the mappings, 4 = traceback + MD,
  * 5 = compaction (one entry per call, several kernels each);
- * 6 = per-read mapping counts + counters after verification. */
+ * 6 = per-read mapping counts + counters after verification; of fem_dev_fetch_sam: 7 = the SAM text kernels. */
 int fem_dev_set_timing(fem_dev *h, int on);
 int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);

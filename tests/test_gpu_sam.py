@@ -1,0 +1,89 @@
+"""SAM text rendered on the device (fem_dev_fetch_sam: mapping tail + sam_len_kernel / sam_write_kernel, fem_tail.hip)
+against the host formatter on the device's records (fem_records_sam) and against the text built from the oracle's records
+(field rules of src/align.c:546-632, src/output_queue.c:93-116).  Needs a GPU: -m gpu."""
+import numpy as np
+import pytest
+
+from fem_amd import host
+from oracle import fem_oracle as fo
+from tests import util
+from tests.test_host import expected_sam
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, e, L, n_reads, repeats, odd):
+    from fem_amd import Device
+    rng = np.random.default_rng(seed)
+    if repeats:
+        seqs = util.repeat_rich_reference(rng, n_seq=3, unit_len=300, n_units=4, copies=50, spacer=200)
+        seqs.append(util.rand_seq(rng, 120_000))
+    else:
+        seqs = [util.rand_seq(rng, 200_000), util.rand_seq(rng, 50_000)]
+    names = ["chr%d_%s" % (i, "x" * (i * 7)) for i in range(len(seqs))]
+    reads = util.make_reads(rng, seqs, n_reads, L, e, n_rate=0.003)
+    if odd:
+        reads[3] = reads[3].lower()
+        reads[5] = reads[5][:L // 2] + b"RYKM=.-*"[:min(8, L - L // 2)] + reads[5][L // 2 + 8:]
+        reads[7] = reads[7][:L - 17]  # a different length
+    rnames = ["read_%d/%s" % (i, "n" * (i % 40)) for i in range(len(reads))]
+    quals = ["".join(chr(33 + (11 * i + j) % 60) for j in range(len(r))) for i, r in enumerate(reads)]
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    dev = Device(0)
+    dev.upload_reference(seqs)
+    dev.upload_reference_names(names)
+    dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    return dev, ref, idx, seqs, names, reads, rnames, quals
+
+
+@pytest.mark.parametrize("seed,e,L,n,repeats,odd", [(1, 3, 100, 1500, False, True), (2, 7, 150, 800, True, True),
+                                                     (3, 2, 64, 3000, True, False), (4, 0, 36, 500, False, False)])
+def test_device_sam_text_equals_host_text_and_oracle_text(seed, e, L, n, repeats, odd):
+    dev, ref, idx, seqs, names, reads, rnames, quals = _case(seed, e, L, n, repeats, odd)
+    try:
+        batch = fo.ReadBatch(reads)
+        want = fo.map_reads(ref, idx, batch, e=e)
+        q = np.frombuffer("".join(quals).encode(), np.uint8)
+        for slot in (0, 2):
+            dev.stage_reads(batch.bases, batch.off, slot=slot)
+            dev.stage_text(q, rnames, slot=slot)
+            dev.map_staged(e=e, slot=slot)
+            text, n_records, n_asserted, stats = dev.fetch_sam(slot=slot)
+            assert np.array_equal(stats, want.stats) and n_records == int(want.rec_off[-1])
+            # the host formatter on the records the device tail hands out
+            rec = dev.fetch_records(slot=slot)
+            tref = host.TailReference(ref.text, ref.off, ref.len, names=names)
+            host_text, host_asserted = host.records_sam(tref, rnames, batch.bases, batch.off, q, rec, threads=3, parts=True)
+            assert text.decode("latin-1") == host_text
+            assert n_asserted == host_asserted == int(np.count_nonzero(rec.flag & 0x8000))
+            if n_asserted == 0:
+                exp = expected_sam(names, reads, rnames, quals, want)
+                # SEQ goes through the 4-bit round trip of the BAM record: IUPAC letters stay, anything else is N
+                assert [l.split("\t")[:9] + l.split("\t")[10:] for l in text.decode("latin-1").splitlines()] == \
+                       [l.split("\t")[:9] + l.split("\t")[10:] for l in exp.splitlines()]
+        assert n_records > n // 2 or L < 40
+    finally:
+        dev.close()
+
+
+def test_fetch_sam_needs_its_inputs():
+    from fem_amd import FemError
+    dev, ref, idx, seqs, names, reads, rnames, quals = _case(9, 3, 100, 50, False, False)
+    try:
+        batch = fo.ReadBatch(reads)
+        dev.stage_reads(batch.bases, batch.off)
+        dev.map_staged(e=3)
+        with pytest.raises(FemError):
+            dev.fetch_sam()  # no qualities / names committed for this batch
+        q = np.frombuffer("".join(quals).encode(), np.uint8)
+        with pytest.raises(FemError):
+            dev.stage_text(q, rnames[:-1])  # one name short
+        empty = fo.ReadBatch([])
+        dev.stage_reads(empty.bases, empty.off, slot=1)
+        dev.stage_text(np.zeros(0, np.uint8), [], slot=1)
+        dev.map_staged(e=3, slot=1)
+        text, n_records, n_asserted, stats = dev.fetch_sam(slot=1)
+        assert text == b"" and n_records == 0
+    finally:
+        dev.close()
