@@ -1450,6 +1450,23 @@ int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint6
   return FEM_OK;
 }
 
+int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if ((rc = dev_realloc(h, &s.d_quals, &s.d_quals_cap, (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_names, &s.d_names_cap, (size_t)n_name_bytes + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_name_off, &s.d_name_off_cap, (size_t)n_reads + 1))) return rc;
+  if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
+  if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
+  std::string err;
+  if ((rc = s.tail->reserve_text(text_bytes, &err))) return fail(h, rc, err);
+  return FEM_OK;
+}
+
 int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) {
   int rc = check_slot(h, slot);
   if (rc) return rc;

@@ -215,7 +215,11 @@ struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pa
   char *bases = nullptr;      // pinned staging lent by the device library (fem_dev_acquire_stage)
   uint64_t *off = nullptr;
   uint64_t reads_cap = 0, bases_cap = 0;
-  Growable quals, names, name_off;  // read names and qualities never go to the GPU
+  Growable quals, names, name_off;  // host formatting (FEM_HOST_FORMAT=1 / FEM_HOST_TAIL=1): names and qualities stay on the host
+  char *q_stage = nullptr, *n_stage = nullptr;  // device SAM text: pinned staging lent by the library
+  uint64_t *no_stage = nullptr;
+  uint64_t names_cap = 0, want_names = 0;
+  fem_batch_sam sam{};
   fem_batch_shape shape{};
   uint64_t want_reads = 0, want_bases = 0;  // set by the reader when the staging buffers are too small
   fem_batch_records rec{};                  // device tail's records (default path)
@@ -312,6 +316,16 @@ int map_main(int argc, char **argv) {
     exit(EXIT_FAILURE);
   }
 
+  const char *ht = getenv("FEM_HOST_TAIL");
+  const bool host_tail = ht && ht[0] == '1';
+  // SAM text is rendered on the device (fem_dev_fetch_sam) unless FEM_HOST_FORMAT=1 (records from the device, text by the
+  // host threads) or FEM_HOST_TAIL=1 (ordering, traceback and text by the host threads)
+  const char *hf = getenv("FEM_HOST_FORMAT");
+  const bool device_text = !host_tail && !(hf && hf[0] == '1');
+  const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
+  // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are unusual
+  // (the reader asks for larger buffers when a batch needs them)
+  const uint64_t reads_cap0 = batch_bytes / 32 + 16, bases_cap0 = batch_bytes / 2 + 4096, names_cap0 = bases_cap0 / 2 + 4096;
   std::vector<fem_dev *> devs((size_t)n_gpus, nullptr);
   // FEM_TEST_SHARE_GPU=1 (test hook for one-GPU boxes): all `--gpus N` workers open GPU 0, each with its own handle, and
   // the counters are summed on the host (RCCL refuses two ranks on one device)
@@ -325,6 +339,17 @@ int map_main(int argc, char **argv) {
         int rc = fem_dev_open(share_gpu ? 0 : g, &devs[(size_t)g]);
         if (!rc) rc = ref.upload(devs[(size_t)g]);
         if (!rc) rc = fem_dev_upload_index(devs[(size_t)g], ik, istep, lookup, ((uint64_t)1 << (2 * ik)) + 1, occ, n_occ);
+        // the slots' pinned staging (and, for the device's SAM text, its buffers): pinning host memory takes ~0.25 ms per
+        // MB, 35 ms per slot here, and belongs to the setup rather than to the first batches
+        int32_t ns = 4;
+        if (!rc) (void)fem_dev_limits(devs[(size_t)g], nullptr, &ns);
+        for (int sl = 0; !rc && sl < ns; ++sl) {
+          char *pb = nullptr, *pq = nullptr, *pn = nullptr;
+          uint64_t *po = nullptr, *pno = nullptr;
+          rc = fem_dev_acquire_stage(devs[(size_t)g], sl, reads_cap0, bases_cap0, &pb, &po);
+          if (!rc && device_text) rc = fem_dev_acquire_text_stage(devs[(size_t)g], sl, reads_cap0, bases_cap0, names_cap0, &pq, &pn, &pno);
+          if (!rc && device_text) rc = fem_dev_reserve_text(devs[(size_t)g], sl, reads_cap0, bases_cap0, names_cap0, batch_bytes + batch_bytes / 4);
+        }
         up_rc[(size_t)g] = rc;
       });
     for (auto &t : up) t.join();
@@ -362,22 +387,25 @@ int map_main(int argc, char **argv) {
     free(hdr);
   }
 
+  if (device_text)
+    for (fem_dev *h : devs) {
+      int rc = fem_dev_upload_reference_names(h, (uint32_t)ref.set.n, ref.set.names, ref.set.name_off);
+      if (rc) return dev_fail(h, "reference names", rc);
+    }
+
   double t_start = real_time();
   // -t threads are shared by the two host stages that run side by side (FEM_SPLIT_THREADS=0: each gets all of them)
   const char *sp_env = getenv("FEM_SPLIT_THREADS");
   const bool split = !(sp_env && sp_env[0] == '0') && n_threads >= 4;
   int rd_share = 50;  // per cent of the threads that parse (FEM_READER_SHARE)
   if (const char *rs = getenv("FEM_READER_SHARE")) rd_share = std::min(90, std::max(10, atoi(rs)));
-  const int rd_threads = split ? std::max(1, std::min(n_threads - 1, (n_threads * rd_share + 50) / 100)) : n_threads;
-  const int fmt_threads = split ? n_threads - rd_threads : n_threads;
-  const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
+  const int rd_threads = !device_text && split ? std::max(1, std::min(n_threads - 1, (n_threads * rd_share + 50) / 100)) : n_threads;
+  const int fmt_threads = !device_text && split ? n_threads - rd_threads : n_threads;
   int32_t n_slots = 4;
   (void)fem_dev_limits(devs[0], nullptr, &n_slots);
   // FEM_STAGE_TIMES=1: busy seconds of each pipeline stage on stderr at the end
   const char *st_env = getenv("FEM_STAGE_TIMES");
   const bool stage_times = st_env && st_env[0] == '1';
-  const char *ht = getenv("FEM_HOST_TAIL");
-  const bool host_tail = ht && ht[0] == '1';
   double busy_read = 0, busy_text = 0, busy_write = 0;
   double wait_slot = 0, wait_records = 0, wait_text_buf = 0;  // reader waiting for a free slot, formatter for records / a text buffer
   std::vector<double> busy_submit((size_t)n_gpus, 0.0), busy_recycle((size_t)n_gpus, 0.0);
@@ -388,7 +416,12 @@ int map_main(int argc, char **argv) {
   std::vector<BatchBuf> bufs((size_t)n_gpus * (size_t)n_slots);
   Channel<BatchBuf *> free_q, text_q, regrown_q;
   std::vector<Channel<Msg>> work_q((size_t)n_gpus);
-  Channel<TextOut *> text_free_q, write_q;
+  struct WriteItem {
+    TextOut *t = nullptr;   // host-rendered text, or
+    BatchBuf *b = nullptr;  // a batch whose text the device rendered (b->sam)
+  };
+  Channel<TextOut *> text_free_q;
+  Channel<WriteItem> write_q;
   std::vector<TextOut> texts(3);
   for (TextOut &t : texts) text_free_q.push(&t);
   std::vector<uint64_t> per_gpu((size_t)n_gpus * 5, 0);
@@ -396,8 +429,18 @@ int map_main(int argc, char **argv) {
   // ---- writer (src/output_queue.c:60-91) ----
   std::thread writer([&] {
     for (;;) {
-      TextOut *t = write_q.pop();
-      if (!t) break;
+      WriteItem it = write_q.pop();
+      if (!it.t && !it.b) break;
+      if (it.b) {  // text rendered on the device: one stretch of the library's pinned memory
+        double t0 = real_time();
+        bool ok = it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
+        if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
+        busy_write += real_time() - t0;
+        fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - it.b->t_submit);
+        free_q.push(it.b);  // written: the slot's buffers may be refilled
+        continue;
+      }
+      TextOut *t = it.t;
       double t0 = real_time();
       bool ok = true;
       for (const fem_text_part &p : t->parts)
@@ -451,7 +494,7 @@ int map_main(int argc, char **argv) {
         if (!exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] out of memory while formatting SAM records\n");
         t->parts.clear();
       }
-      write_q.push(t);
+      write_q.push(WriteItem{t, nullptr});
       fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - b->t_submit);
       free_q.push(b);  // fetched and rendered: the staging buffers may be refilled (they stay acquired, include/fem_hip.h)
     }
@@ -472,14 +515,21 @@ int map_main(int argc, char **argv) {
           return false;
         }
         b->bases = pb, b->off = po, b->reads_cap = reads_cap, b->bases_cap = bases_cap;
+        if (device_text) {  // qualities and names go to the GPU as well: pinned staging for them
+          const uint64_t names_cap = std::max<uint64_t>(b->want_names, std::max<uint64_t>(b->names_cap, names_cap0));
+          rc = fem_dev_acquire_text_stage(h, b->slot, reads_cap, bases_cap, names_cap, &b->q_stage, &b->n_stage, &b->no_stage);
+          if (rc) {
+            if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "text staging buffers", rc);
+            return false;
+          }
+          b->names_cap = names_cap;
+        }
         return true;
       };
       for (int s = 0; s < n_slots; ++s) {
         BatchBuf *b = &bufs[(size_t)g * (size_t)n_slots + (size_t)s];
         b->gpu = g, b->slot = s;
-        // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are
-        // unusual (the reader asks for larger buffers when a batch needs them)
-        if (!acquire(b, batch_bytes / 32 + 16, batch_bytes / 2 + 4096)) b->bases = nullptr;
+        if (!acquire(b, reads_cap0, bases_cap0)) b->bases = nullptr;  // (allocated during the setup: this only hands them out)
         free_q.push(b);  // (without buffers when the acquisition failed: the reader stops on it instead of waiting for ever)
       }
       std::deque<BatchBuf *> flight;
@@ -487,16 +537,23 @@ int map_main(int argc, char **argv) {
         BatchBuf *b = flight.front();
         flight.pop_front();
         double t0 = real_time();
-        int rc = host_tail ? fem_dev_map_batch_wait(h, b->slot, &b->res) : fem_dev_fetch_records(h, b->slot, &b->rec);
+        int rc = host_tail     ? fem_dev_map_batch_wait(h, b->slot, &b->res)
+                 : device_text ? fem_dev_fetch_sam(h, b->slot, &b->sam)
+                               : fem_dev_fetch_records(h, b->slot, &b->rec);
         busy_wait[(size_t)g] += real_time() - t0;
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "mapping", rc);
           work_q[(size_t)g].push(Msg{kRecycle, b});
           return;
         }
-        const uint64_t *st = host_tail ? b->res.stats : b->rec.stats;
+        const uint64_t *st = host_tail ? b->res.stats : device_text ? b->sam.stats : b->rec.stats;
         for (int i = 0; i < 5; ++i) per_gpu[(size_t)g * 5 + (size_t)i] += st[i];
-        text_q.push(b);
+        if (device_text) {
+          n_asserted += b->sam.n_asserted;
+          write_q.push(WriteItem{nullptr, b});
+        } else {
+          text_q.push(b);
+        }
       };
       for (;;) {
         Msg m;
@@ -525,6 +582,7 @@ int map_main(int argc, char **argv) {
                  : b->shape.min_len == b->shape.max_len  // reads of one length: the offsets need not cross the link
                      ? fem_dev_commit_stage_uniform(h, b->slot, b->shape.n_reads, b->shape.max_len)
                      : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
+        if (!rc && device_text) rc = fem_dev_commit_text_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes);
         if (!rc) rc = fem_dev_map_staged(h, b->slot, &params);
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "batch submit", rc);
@@ -566,13 +624,16 @@ int map_main(int argc, char **argv) {
         exit_code = EXIT_FAILURE;
         ok = false;
       }
-      if (ok && b->shape.n_reads > 0 && (b->shape.n_reads > b->reads_cap || b->shape.n_bases + 64 > b->bases_cap)) {
-        b->want_reads = b->shape.n_reads + b->shape.n_reads / 8, b->want_bases = b->shape.n_bases + b->shape.n_bases / 8 + 4096;
+      if (ok && b->shape.n_reads > 0 &&
+          (b->shape.n_reads > b->reads_cap || b->shape.n_bases + 64 > b->bases_cap || (device_text && b->shape.n_name_bytes + 64 > b->names_cap))) {
+        b->want_reads = std::max(b->reads_cap, b->shape.n_reads + b->shape.n_reads / 8);
+        b->want_bases = std::max(b->bases_cap, b->shape.n_bases + b->shape.n_bases / 8 + 4096);
+        b->want_names = b->shape.n_name_bytes + b->shape.n_name_bytes / 8 + 4096;
         work_q[(size_t)b->gpu].push(Msg{kRegrow, b});
         BatchBuf *back = regrown_q.pop();  // (one request at a time: it is ours)
         ok = back->bases != nullptr;
       }
-      if (ok && b->shape.n_reads > 0) {
+      if (ok && b->shape.n_reads > 0 && !device_text) {
         ok = b->quals.reserve(b->shape.n_bases + 1) && b->names.reserve(b->shape.n_name_bytes + 1) &&
              b->name_off.reserve((b->shape.n_reads + 1) * sizeof(uint64_t));
         if (!ok) {
@@ -585,7 +646,8 @@ int map_main(int argc, char **argv) {
         busy_read += real_time() - t0;
         break;  // end of input (or failure)
       }
-      rc = fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
+      rc = device_text ? fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->q_stage, b->n_stage, b->no_stage)
+                       : fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
       busy_read += real_time() - t0;
       if (rc) {
         fprintf(stderr, "[FEM] reading failed\n");
@@ -604,7 +666,7 @@ int map_main(int argc, char **argv) {
   t_workers_done = real_time();
   text_q.push(nullptr);
   formatter.join();
-  write_q.push(nullptr);
+  write_q.push(WriteItem{});
   writer.join();
   if (stage_times) {
     double bw = 0;

@@ -1381,6 +1381,14 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
 }
 
 
+int Tail::reserve_text(uint64_t bytes, std::string *err) {
+  if (!impl_) impl_ = new (std::nothrow) Impl();
+  if (!impl_) return FEM_ERR_NOMEM;
+  TAIL_TRY(impl_->text.need((size_t)bytes));
+  TAIL_TRY(impl_->h_text.need((size_t)bytes));
+  return FEM_OK;
+}
+
 int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms) {
   if (!impl_ || !out) return FEM_ERR_STATE;
   Impl &m = *impl_;

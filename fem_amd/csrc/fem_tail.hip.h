@@ -70,6 +70,9 @@ class Tail {
   // copy_records = false: the records stay on the device (for sam()); *out then only carries the counts.
   int run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms,
           bool copy_records = true);
+  // Makes room for `bytes` of SAM text ahead of time (pinning host memory costs ~0.25 ms per MB: better spent before
+  // the first batch than inside it).
+  int reserve_text(uint64_t bytes, std::string *err);
   // The records of the last run() as SAM lines, in record order.  ms (optional) receives the device time.
   int sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms);
 

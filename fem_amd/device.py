@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
-    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_fetch_sam",
+    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
     "fem_device_numa", "fem_bind_thread_near_device",
@@ -101,6 +101,7 @@ def load_hip():
     L.fem_dev_upload_reference_names.argtypes = [vp, C.c_uint32, C.c_char_p, vp]
     L.fem_dev_acquire_text_stage.argtypes = [vp, C.c_int, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
+    L.fem_dev_reserve_text.argtypes = [vp, C.c_int, u64, u64, u64, u64]
     L.fem_dev_fetch_sam.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_stage_info.argtypes = [vp, C.c_int, C.POINTER(u64), C.POINTER(C.c_int32)]
     L.fem_device_numa.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_char_p, u64]

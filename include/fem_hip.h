@@ -195,6 +195,9 @@ int fem_dev_upload_reference_names(fem_dev *h, uint32_t n_seq, const char *names
 int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, uint64_t n_name_bytes_cap,
                                char **quals, char **names, uint64_t **name_off);
 int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes);
+/* Optional: device and pinned buffers of the slot for batches of this shape and `text_bytes` of SAM text, allocated now
+ * (pinning host memory costs ~0.25 ms per MB; otherwise the first batch of every slot pays for it). */
+int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes);
 int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out);
 
 /* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident

@@ -87,6 +87,11 @@ def test_index_and_map_end_to_end(tmp_path, e, L, gz, batch):
              "--batch", str(batch), env={"FEM_HOST_TAIL": "1"})
     assert r2.returncode == 0, r2.stderr.decode()
     assert open(host_sam).read() == text
+    # ... and with the records from the device but the text rendered by the host threads (the default renders it on the device)
+    r3 = run("map", "-e", str(e), "-t", "3", "--ref", fa, "--index", index_path, "--read1", fq, "-o", host_sam,
+             "--batch", str(batch), env={"FEM_HOST_FORMAT": "1"})
+    assert r3.returncode == 0, r3.stderr.decode()
+    assert open(host_sam).read() == text
     err = r.stderr.decode()
     for label, v in zip(["The number of read", "The number of mapped read",
                          "The number of candidate before additional q-gram filter", "The number of candidate",
