@@ -157,14 +157,14 @@ int index_main(int argc, char **argv) {
 // The reference runs 1 reader + T mapping threads + 1 writer over two queues (src/FEM_map.c:172-198,
 // src/input_queue.c, src/output_queue.c).  Here the T mapping threads are the GPUs:
 //
-//   reader     parses the next FASTQ window (all -t threads) STRAIGHT INTO the pinned staging buffers of a free
+//   reader     parses the next FASTQ window (all -t threads; bases, qualities, names) STRAIGHT INTO the pinned staging buffers of a free
 //              (GPU, slot) pair — whichever GPU has one free, so the GPUs balance by themselves
 //   worker[g]  one thread per GPU, the only one that talks to that GPU's handle: starts H2D + kernels of a filled
-//              slot (asynchronous), keeps two batches in flight, then fetches the finished batch's records
-//              (sort + traceback + CIGAR/MD run on the device, fem_dev_fetch_records)
-//   formatter  renders the records as SAM text (all -t threads) into a reusable buffer
+//              slot (asynchronous), keeps two batches in flight, then fetches the finished batch's SAM text
+//              (sort + traceback + CIGAR/MD + the text itself run on the device, fem_dev_fetch_sam)
 //   writer     writes the text
-// A slot goes  free -> filled -> in flight -> fetched -> formatted -> free  and there are four per GPU.
+//   formatter  only with FEM_HOST_FORMAT=1 / FEM_HOST_TAIL=1: renders records as SAM text on the host threads
+// A slot goes  free -> filled -> in flight -> fetched -> written -> free  and there are four per GPU.
 template <typename T>
 class Channel {  // unbounded hand-off between pipeline stages (the number of slots bounds what is in flight)
  public:
