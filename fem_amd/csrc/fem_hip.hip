@@ -1489,7 +1489,18 @@ int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n
   return FEM_OK;
 }
 
-int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out) {
+static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait);
+int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out) { return fetch_sam(h, slot, out, true); }
+int fem_dev_fetch_sam_nowait(fem_dev *h, int slot, fem_batch_sam *out) { return fetch_sam(h, slot, out, false); }
+int fem_dev_sam_wait(fem_dev *h, int slot) {
+  if (!h || slot < 0 || slot >= kSlots) return FEM_ERR_INVALID;
+  Slot &s = h->slot[slot];
+  if (!s.tail) return FEM_ERR_STATE;
+  if (hipSetDevice(h->device) != hipSuccess) return FEM_ERR_HIP;
+  return s.tail->wait_text();  // (touches nothing but the slot's event: safe next to the thread that drives the handle)
+}
+
+static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   int rc = fem_dev_sync(h, slot);
   if (rc) return rc;
   if (!out) return fail(h, FEM_ERR_INVALID, "null result");
@@ -1514,7 +1525,7 @@ int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out) {
   names.quals = s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
   names.ref_names = h->d_ref_names, names.ref_name_off = h->d_ref_name_off;
   femt::SamOutput text{};
-  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr);
+  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait);
   if (rc) return fail(h, rc, err);
   if (h->timing) {
     for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;

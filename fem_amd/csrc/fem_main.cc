@@ -432,8 +432,10 @@ int map_main(int argc, char **argv) {
       WriteItem it = write_q.pop();
       if (!it.t && !it.b) break;
       if (it.b) {  // text rendered on the device: one stretch of the library's pinned memory
+        const int wrc = fem_dev_sam_wait(devs[(size_t)it.b->gpu], it.b->slot);  // the copy of the text to the host has arrived
+        if (wrc && !exit_code.exchange(EXIT_FAILURE)) dev_fail(devs[(size_t)it.b->gpu], "SAM text", wrc);
         double t0 = real_time();
-        bool ok = it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
+        bool ok = wrc != 0 || it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
         if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
         busy_write += real_time() - t0;
         fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - it.b->t_submit);
@@ -533,12 +535,14 @@ int map_main(int argc, char **argv) {
         free_q.push(b);  // (without buffers when the acquisition failed: the reader stops on it instead of waiting for ever)
       }
       std::deque<BatchBuf *> flight;
+      size_t max_flight = 2;
+      if (const char *fl = getenv("FEM_FLIGHT")) max_flight = (size_t)std::max(1, std::min(n_slots - 1, atoi(fl)));
       auto retire = [&] {
         BatchBuf *b = flight.front();
         flight.pop_front();
         double t0 = real_time();
         int rc = host_tail     ? fem_dev_map_batch_wait(h, b->slot, &b->res)
-                 : device_text ? fem_dev_fetch_sam(h, b->slot, &b->sam)
+                 : device_text ? fem_dev_fetch_sam_nowait(h, b->slot, &b->sam)  // (the writer waits for the text itself)
                                : fem_dev_fetch_records(h, b->slot, &b->rec);
         busy_wait[(size_t)g] += real_time() - t0;
         if (rc) {
@@ -591,7 +595,7 @@ int map_main(int argc, char **argv) {
         }
         busy_submit[(size_t)g] += real_time() - b->t_submit;
         flight.push_back(b);
-        while (flight.size() > 2) retire();  // two batches in flight per GPU
+        while (flight.size() > max_flight) retire();  // batches in flight per GPU (FEM_FLIGHT, default 2)
       }
       while (!flight.empty()) retire();
     });

@@ -1142,7 +1142,9 @@ struct Tail::Impl {
   PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md, h_text;
   uint32_t last_n = 0, last_nr = 0;  // what the last run() left on the device
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_text = nullptr;  // the SAM text has arrived in h_text
   ~Impl() {
+    if (ev_text) (void)hipEventDestroy(ev_text);
     for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf, &rec_list,
                       &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp, &line_len, &line_off, &text})
       b->release();
@@ -1389,7 +1391,13 @@ int Tail::reserve_text(uint64_t bytes, std::string *err) {
   return FEM_OK;
 }
 
-int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms) {
+int Tail::wait_text() {
+  if (!impl_ || !impl_->ev_text) return FEM_ERR_STATE;
+  return hipEventSynchronize(impl_->ev_text) == hipSuccess ? FEM_OK : FEM_ERR_HIP;
+}
+
+int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms,
+              bool wait) {
   if (!impl_ || !out) return FEM_ERR_STATE;
   Impl &m = *impl_;
   const uint32_t nr = m.last_nr;
@@ -1431,8 +1439,10 @@ int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, in
   }
   TAIL_TRY(hipEventRecord(m.ev[1], stream));
   if (total) TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, (size_t)total, hipMemcpyDeviceToHost, stream));
-  TAIL_TRY(hipStreamSynchronize(stream));
-  if (ms) {
+  if (!m.ev_text) TAIL_TRY(hipEventCreateWithFlags(&m.ev_text, hipEventDisableTiming));
+  TAIL_TRY(hipEventRecord(m.ev_text, stream));
+  if (wait) TAIL_TRY(hipStreamSynchronize(stream));
+  if (ms && wait) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, m.ev[0], m.ev[1]) == hipSuccess) *ms += t;
   }

@@ -74,7 +74,11 @@ class Tail {
   // the first batch than inside it).
   int reserve_text(uint64_t bytes, std::string *err);
   // The records of the last run() as SAM lines, in record order.  ms (optional) receives the device time.
-  int sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms);
+  // wait = false: returns once the copy of the text to the host has been queued; wait_text() (which may be called from
+  // another thread) returns when it has arrived.
+  int sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms,
+          bool wait = true);
+  int wait_text();
 
  private:
   struct Impl;

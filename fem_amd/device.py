@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
-    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam",
+    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
     "fem_device_numa", "fem_bind_thread_near_device",
@@ -103,6 +103,8 @@ def load_hip():
     L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
     L.fem_dev_reserve_text.argtypes = [vp, C.c_int, u64, u64, u64, u64]
     L.fem_dev_fetch_sam.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
+    L.fem_dev_fetch_sam_nowait.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
+    L.fem_dev_sam_wait.argtypes = [vp, C.c_int]
     L.fem_dev_stage_info.argtypes = [vp, C.c_int, C.POINTER(u64), C.POINTER(C.c_int32)]
     L.fem_device_numa.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_char_p, u64]
     L.fem_bind_thread_near_device.argtypes = [C.c_int]
@@ -322,10 +324,15 @@ class Device:
         C.memmove(po.value, off.ctypes.data, 8 * (len(raw) + 1))
         self._check(self._L.fem_dev_commit_text_stage(self._h, slot, len(raw), nn))
 
-    def fetch_sam(self, slot=0):
-        """(SAM text of the slot's batch as bytes, n_records, n_asserted, stats) — rendered on the device."""
+    def fetch_sam(self, slot=0, nowait=False):
+        """(SAM text of the slot's batch as bytes, n_records, n_asserted, stats) — rendered on the device.
+        nowait: through fem_dev_fetch_sam_nowait + fem_dev_sam_wait."""
         r = _BatchSam()
-        self._check(self._L.fem_dev_fetch_sam(self._h, slot, C.byref(r)))
+        if nowait:
+            self._check(self._L.fem_dev_fetch_sam_nowait(self._h, slot, C.byref(r)))
+            self._check(self._L.fem_dev_sam_wait(self._h, slot))
+        else:
+            self._check(self._L.fem_dev_fetch_sam(self._h, slot, C.byref(r)))
         text = C.string_at(r.text, r.len) if r.len else b""
         return text, int(r.n_records), int(r.n_asserted), np.array(list(r.stats), dtype=np.uint64)
 

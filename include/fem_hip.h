@@ -199,6 +199,11 @@ int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n
  * (pinning host memory costs ~0.25 ms per MB; otherwise the first batch of every slot pays for it). */
 int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes);
 int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out);
+/* The same, returning as soon as the copy of the text to the host is queued: out->text must not be read before
+ * fem_dev_sam_wait(h, slot) has returned — the one call that may be made from another thread than the one driving
+ * the handle (a writer thread waits there while the GPU's thread starts on the next batch). */
+int fem_dev_fetch_sam_nowait(fem_dev *h, int slot, fem_batch_sam *out);
+int fem_dev_sam_wait(fem_dev *h, int slot);
 
 /* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident
  * index ("seed_dense_kernel", "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or "seed_filter_kernel"); the

@@ -49,7 +49,7 @@ def test_device_sam_text_equals_host_text_and_oracle_text(seed, e, L, n, repeats
             dev.stage_reads(batch.bases, batch.off, slot=slot)
             dev.stage_text(q, rnames, slot=slot)
             dev.map_staged(e=e, slot=slot)
-            text, n_records, n_asserted, stats = dev.fetch_sam(slot=slot)
+            text, n_records, n_asserted, stats = dev.fetch_sam(slot=slot, nowait=slot == 2)
             assert np.array_equal(stats, want.stats) and n_records == int(want.rec_off[-1])
             # the host formatter on the records the device tail hands out
             rec = dev.fetch_records(slot=slot)
