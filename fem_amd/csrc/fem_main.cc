@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -181,6 +182,13 @@ class Channel {  // unbounded hand-off between pipeline stages (the number of sl
     T v = std::move(q_.front());
     q_.pop_front();
     return v;
+  }
+  bool try_pop_for(T &v, double seconds) {  // waits up to `seconds` for an element
+    std::unique_lock<std::mutex> l(m_);
+    if (!cv_.wait_for(l, std::chrono::duration<double>(seconds), [&] { return !q_.empty(); })) return false;
+    v = std::move(q_.front());
+    q_.pop_front();
+    return true;
   }
   bool try_pop(T &v) {
     std::lock_guard<std::mutex> l(m_);
@@ -535,6 +543,11 @@ int map_main(int argc, char **argv) {
         free_q.push(b);  // (without buffers when the acquisition failed: the reader stops on it instead of waiting for ever)
       }
       std::deque<BatchBuf *> flight;
+      // Below max_flight batches in flight the thread lingers a moment for the reader's next batch before it blocks in a
+      // fetch: a batch submitted just before a fetch has its copy and kernels run behind that fetch instead of in front
+      // of the next one (FEM_LINGER_US).
+      double linger = 300e-6;
+      if (const char *lg = getenv("FEM_LINGER_US")) linger = std::max(0, atoi(lg)) * 1e-6;
       size_t max_flight = 2;
       if (const char *fl = getenv("FEM_FLIGHT")) max_flight = (size_t)std::max(1, std::min(n_slots - 1, atoi(fl)));
       auto retire = [&] {
@@ -563,7 +576,7 @@ int map_main(int argc, char **argv) {
         Msg m;
         if (flight.empty()) {
           m = work_q[(size_t)g].pop();
-        } else if (!work_q[(size_t)g].try_pop(m)) {
+        } else if (!(flight.size() < max_flight ? work_q[(size_t)g].try_pop_for(m, linger) : work_q[(size_t)g].try_pop(m))) {
           retire();  // nothing new to start: finish the oldest batch in flight
           continue;
         }
