@@ -224,6 +224,7 @@ struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pa
   uint64_t *off = nullptr;
   uint64_t reads_cap = 0, bases_cap = 0;
   Growable quals, names, name_off;  // host formatting (FEM_HOST_FORMAT=1 / FEM_HOST_TAIL=1): names and qualities stay on the host
+  Growable bases_host, off_host;                // packed transfer: the parser's bases, packed into the staging by the library
   char *q_stage = nullptr, *n_stage = nullptr;  // device SAM text: pinned staging lent by the library
   uint64_t *no_stage = nullptr;
   uint64_t names_cap = 0, want_names = 0;
@@ -330,6 +331,10 @@ int map_main(int argc, char **argv) {
   // host threads) or FEM_HOST_TAIL=1 (ordering, traceback and text by the host threads)
   const char *hf = getenv("FEM_HOST_FORMAT");
   const bool device_text = !host_tail && !(hf && hf[0] == '1');
+  // With the text on the device the link is what bounds the run: the bases then cross it packed (fem_dev_stage_reads: two
+  // bits per base for equal-length reads) instead of through the zero-copy staging (FEM_PACK_BASES=0: as characters).
+  const char *pk = getenv("FEM_PACK_BASES");
+  const bool pack_bases = device_text && !(pk && pk[0] == '0');
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
   // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are unusual
   // (the reader asks for larger buffers when a batch needs them)
@@ -519,7 +524,16 @@ int map_main(int argc, char **argv) {
       auto acquire = [&](BatchBuf *b, uint64_t reads_cap, uint64_t bases_cap) -> bool {
         char *pb = nullptr;
         uint64_t *po = nullptr;
-        int rc = fem_dev_acquire_stage(h, b->slot, reads_cap, bases_cap, &pb, &po);
+        int rc = 0;
+        if (pack_bases) {  // the parser writes to ordinary memory; the library packs from there into its staging
+          if (!b->bases_host.reserve(bases_cap + 64) || !b->off_host.reserve((reads_cap + 1) * sizeof(uint64_t))) {
+            if (!exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] out of memory\n");
+            return false;
+          }
+          pb = b->bases_host.p, po = (uint64_t *)b->off_host.p;
+        } else {
+          rc = fem_dev_acquire_stage(h, b->slot, reads_cap, bases_cap, &pb, &po);
+        }
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "staging buffers", rc);
           return false;
@@ -595,7 +609,9 @@ int map_main(int argc, char **argv) {
         }
         BatchBuf *b = m.b;  // kFilled
         b->t_submit = real_time();
+        fem_read_batch rb{b->bases, b->off, b->shape.n_reads};
         int rc = exit_code ? FEM_ERR_STATE
+                 : pack_bases ? fem_dev_stage_reads(h, b->slot, &rb)
                  : b->shape.min_len == b->shape.max_len  // reads of one length: the offsets need not cross the link
                      ? fem_dev_commit_stage_uniform(h, b->slot, b->shape.n_reads, b->shape.max_len)
                      : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
