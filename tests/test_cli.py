@@ -163,3 +163,31 @@ def test_allreduce_stats_over_two_handles():
         assert np.array_equal(st[0], st[1]) and st[0].tolist() == [11, 22, 33, 44, 2 ** 40 + rep + 5]
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_map_regrows_its_staging_for_unusual_records(tmp_path):
+    # very long read names and short reads: a FASTQ window holds far more name bytes than the staging buffers were sized
+    # for (fem_main.cc: kRegrow), with the text rendered on the device and on the host
+    rng = np.random.default_rng(8)
+    seqs = [util.rand_seq(rng, 120_000)]
+    reads = util.make_reads(rng, seqs, 700, 64, 1)
+    rnames = ["read_%d_%s" % (i, "x" * (250 + i % 90)) for i in range(len(reads))]
+    quals = ["".join(chr(40 + (i + j) % 30) for j in range(64)) for i in range(len(reads))]
+    fa, fq = tmp_path / "r.fa", tmp_path / "r.fq"
+    fa.write_bytes(b">chrL\n" + seqs[0] + b"\n")
+    with open(fq, "wb") as f:
+        for n, r, q in zip(rnames, reads, quals):
+            f.write(b"@" + n.encode() + b"\n" + r + b"\n+\n" + q.encode() + b"\n")
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    want = fo.map_reads(ref, idx, fo.ReadBatch(reads), e=1)
+    ix = str(tmp_path / "r.idx")
+    assert run("index", "12", "3", str(fa), ix).returncode == 0
+    exp = "@SQ\tSN:chrL\tLN:%d\n" % len(seqs[0]) + expected_sam(["chrL"], reads, rnames, quals, want)
+    for env in (None, {"FEM_HOST_FORMAT": "1"}, {"FEM_PACK_BASES": "0"}):
+        out = str(tmp_path / "o.sam")
+        r = run("map", "-e", "1", "-t", "4", "--ref", str(fa), "--index", ix, "--read1", str(fq), "-o", out, "--batch", "200", env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        assert open(out).read() == exp
+    assert want.stats[1] > 300
