@@ -1069,26 +1069,59 @@ __global__ void __launch_bounds__(256) sam_len_kernel(SamParams p) {
   }
 }
 
-// one wave per record: the long fields by all lanes, the numbers by lane 0
+// One wave per record: the long fields by all lanes, the numbers by lane 0.  The kernel is bound by memory latency (a
+// dozen small loads per record, then the fields' bytes), so everything that does not depend on something else is
+// requested together: the record's numbers, then the table entries they point to, then two bytes per lane of every
+// field at once (fields over 128 bytes finish in a loop).
 __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
   const uint32_t ln = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t j = wave; j < p.n_records; j += n_waves) {
+    // level 1
     const uint32_t r = p.s_read[j];
+    const uint32_t t = p.tid[j];
+    const uint32_t flag = p.flag[j] & 0x7FFFu, pos1 = p.pos0[j] + 1u, nm = p.nm[j];
+    const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1], m0 = p.md_off[j], md_len = p.md_off[j + 1] - m0;
+    const unsigned long long at = p.line_off[j];
+    // level 2
     const bool primary = p.rec_begin[r] == j;
     const uint64_t ro = p.read_off[r];
     const uint32_t L = (uint32_t)(p.read_off[r + 1] - ro);
     const uint64_t no = p.name_off[r];
     const uint32_t name_len = (uint32_t)(p.name_off[r + 1] - no);
-    const uint32_t t = p.tid[j], rn0 = p.ref_name_off[t], rname_len = p.ref_name_off[t + 1] - rn0;
-    const uint32_t flag = p.flag[j] & 0x7FFFu, pos1 = p.pos0[j] + 1u, nm = p.nm[j];
-    const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1], m0 = p.md_off[j], md_len = p.md_off[j + 1] - m0;
-    uint32_t cig = 0;
-    for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
-    if (c1 == c0) cig = 1;
+    const uint32_t rn0 = p.ref_name_off[t], rname_len = p.ref_name_off[t + 1] - rn0;
+    uint32_t op_a = 0, op_b = 0, op_c = 0;  // the first CIGAR operations (most records have one to three)
+    const uint32_t n_ops = c1 - c0;
+    if (n_ops > 0) op_a = p.cigar[c0];
+    if (n_ops > 1) op_b = p.cigar[c0 + 1];
+    if (n_ops > 2) op_c = p.cigar[c0 + 2];
     const bool seq = primary && L > 0;
-    uint8_t *w = p.text + p.line_off[j];
-    // field starts
+    // level 3: two bytes per lane of every field
+    const uint32_t k1 = ln + 64u;
+    uint8_t nA = 0, nB = 0, rA = 0, mA = 0, mB = 0, sA = 0, sB = 0, qA = 0, qB = 0;
+    if (ln < name_len) nA = p.names[no + ln];
+    if (k1 < name_len) nB = p.names[no + k1];
+    if (ln < rname_len) rA = p.ref_names[rn0 + ln];
+    if (ln < md_len) mA = p.md[m0 + ln];
+    if (k1 < md_len) mB = p.md[m0 + k1];
+    if (seq) {
+      if (ln < L) sA = p.bases[ro + ln];
+      if (k1 < L) sB = p.bases[ro + k1];
+      if (p.quals) {
+        if (ln < L) qA = p.quals[ro + ln];
+        if (k1 < L) qB = p.quals[ro + k1];
+      }
+    }
+    uint32_t cig = 0;
+    if (n_ops <= 3u) {
+      if (n_ops > 0) cig += dec_digits(op_a >> 4) + 1u;
+      if (n_ops > 1) cig += dec_digits(op_b >> 4) + 1u;
+      if (n_ops > 2) cig += dec_digits(op_c >> 4) + 1u;
+    } else {
+      for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
+    }
+    if (n_ops == 0) cig = 1;
+    uint8_t *w = p.text + at;
     uint8_t *w_flag = w + name_len + 1u;
     uint8_t *w_rname = w_flag + dec_digits(flag) + 1u;
     uint8_t *w_pos = w_rname + rname_len + 1u;
@@ -1096,13 +1129,23 @@ __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
     uint8_t *w_seq = w_cig + cig + 7u;
     uint8_t *w_nm = w_seq + (seq ? L + 1u + (p.quals ? L : 1u) : 3u) + 6u;
     uint8_t *w_md = w_nm + dec_digits(nm) + 6u;
-    for (uint32_t k = ln; k < name_len; k += 64u) w[k] = p.names[no + k];
-    for (uint32_t k = ln; k < rname_len; k += 64u) w_rname[k] = p.ref_names[rn0 + k];
-    for (uint32_t k = ln; k < md_len; k += 64u) w_md[k] = p.md[m0 + k];
+    if (ln < name_len) w[ln] = nA;
+    if (k1 < name_len) w[k1] = nB;
+    for (uint32_t k = ln + 128u; k < name_len; k += 64u) w[k] = p.names[no + k];
+    if (ln < rname_len) w_rname[ln] = rA;
+    for (uint32_t k = k1; k < rname_len; k += 64u) w_rname[k] = p.ref_names[rn0 + k];
+    if (ln < md_len) w_md[ln] = mA;
+    if (k1 < md_len) w_md[k1] = mB;
+    for (uint32_t k = ln + 128u; k < md_len; k += 64u) w_md[k] = p.md[m0 + k];
     if (seq) {
-      for (uint32_t k = ln; k < L; k += 64u) w_seq[k] = kSamSeqLut[p.bases[ro + k]];
-      if (p.quals)
-        for (uint32_t k = ln; k < L; k += 64u) w_seq[L + 1u + k] = p.quals[ro + k];
+      if (ln < L) w_seq[ln] = kSamSeqLut[sA];
+      if (k1 < L) w_seq[k1] = kSamSeqLut[sB];
+      for (uint32_t k = ln + 128u; k < L; k += 64u) w_seq[k] = kSamSeqLut[p.bases[ro + k]];
+      if (p.quals) {
+        if (ln < L) w_seq[L + 1u + ln] = qA;
+        if (k1 < L) w_seq[L + 1u + k1] = qB;
+        for (uint32_t k = ln + 128u; k < L; k += 64u) w_seq[L + 1u + k] = p.quals[ro + k];
+      }
     }
     if (ln == 0) {
       w[name_len] = '\t';
@@ -1111,11 +1154,17 @@ __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
       uint8_t *q = put_dec(w_pos, pos1);
       q[0] = '\t', q[1] = '2', q[2] = '5', q[3] = '5', q[4] = '\t';
       q = w_cig;
-      if (c1 == c0) *q++ = '*';
-      for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t op = p.cigar[c];
-        q = put_dec(q, op >> 4);
-        *q++ = (uint8_t)"MIDNSHP=XB"[op & 0xFu];
+      if (n_ops == 0) *q++ = '*';
+      if (n_ops <= 3u) {
+        if (n_ops > 0) q = put_dec(q, op_a >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_a & 0xFu];
+        if (n_ops > 1) q = put_dec(q, op_b >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_b & 0xFu];
+        if (n_ops > 2) q = put_dec(q, op_c >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_c & 0xFu];
+      } else {
+        for (uint32_t c = c0; c < c1; ++c) {
+          const uint32_t op = p.cigar[c];
+          q = put_dec(q, op >> 4);
+          *q++ = (uint8_t)"MIDNSHP=XB"[op & 0xFu];
+        }
       }
       q[0] = '\t', q[1] = '*', q[2] = '\t', q[3] = '0', q[4] = '\t', q[5] = '0', q[6] = '\t';
       if (seq) {
