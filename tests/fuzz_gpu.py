@@ -11,6 +11,7 @@ rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 T_END = time.time() + float(os.environ.get("FUZZ_SECONDS", "240"))
 bad = 0
 n_trials = 0
+TREF = [None]
 
 def reference(kind):
     if kind == "dense":
@@ -44,6 +45,10 @@ def trial(dev, ref, idx, seqs, kind):
     want = fo.map_reads(ref, idx, b, e=e, a=a, threads=16, stages=(fo.STAGE_SEED | fo.STAGE_VERIFY | (fo.STAGE_ALIGN if full else 0)))
     slot = int(rng.integers(0, 4))
     dev.stage_reads(b.bases, b.off, slot=slot)
+    if full:  # qualities and names for the device's SAM text
+        quals = rng.integers(33, 100, size=len(b.bases)).astype(np.uint8)
+        rnames = ["q%d_%s" % (j, "z" * int(rng.integers(0, 70))) for j in range(n)]
+        dev.stage_text(quals, rnames, slot=slot)
     dev.map_staged(e=e, a=a, slot=slot)
     got = dev.fetch(slot=slot)
     o, cand, ed, end = got.per_strand()
@@ -54,6 +59,10 @@ def trial(dev, ref, idx, seqs, kind):
         ok = (np.array_equal(rec.rec_begin, want.rec_off) and np.array_equal(rec.flag & 0x7FFF, want.r_flag & 0x7FFF) and np.array_equal(rec.pos0, want.r_pos)
               and np.array_equal(rec.nm, want.r_nm) and np.array_equal(rec.cigar_off, want.cig_off) and np.array_equal(rec.cigar, want.cig)
               and np.array_equal(rec.md_off, want.md_off) and np.array_equal(rec.md, want.md))
+    if ok and full:  # the text rendered on the device against the host formatter on the same records
+        text, n_rec, n_assert, st = dev.fetch_sam(slot=slot, nowait=bool(rng.integers(0, 2)))
+        host_text, host_assert = host.records_sam(TREF[0], rnames, b.bases, b.off, quals, rec, threads=4, parts=True)
+        ok = text.decode("latin-1") == host_text and n_assert == host_assert and n_rec == rec.n_records
     n_trials += 1
     print(kind, dict(e=e, a=a, L=L, n=n, packed=dev.stage_info(slot)[1], full=full, kernel=dev.seed_kernel(e=e, a=a)), "ok" if ok else "MISMATCH",
           [int(x) for x in got.stats], flush=True)
@@ -64,6 +73,9 @@ for kind in ("repeat", "sparse", "mid", "dense"):
     seqs = reference(kind)
     ref = fo.Reference(seqs); idx = fo.OracleIndex(ref, threads=16)
     dev = Device(0); dev.upload_reference(seqs); dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+    ref_names = ["ref%d%s" % (i, "_" * (i % 5)) for i in range(len(seqs))]
+    dev.upload_reference_names(ref_names)
+    TREF[0] = host.TailReference(ref.text, ref.off, ref.len, names=ref_names)
     t_kind = time.time() + (T_END - time.time()) / {"repeat": 4, "sparse": 3, "mid": 2, "dense": 1}[kind]
     while time.time() < t_kind:
         trial(dev, ref, idx, seqs, kind)
