@@ -39,6 +39,7 @@ constexpr uint32_t kMaxReadLen = 1024;
 constexpr size_t kFrontPad = 16;  // kernels fetch a reverse-strand chunk from up to 15 bytes in front of a read
 constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;
 
+constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 verify, 2 generic seed, 3-5 tail, 6 count, 7 SAM text, 8 seed selection
 struct TimedLaunch {
   int kernel;
   hipEvent_t start, stop;
@@ -93,6 +94,9 @@ struct Slot {
   uint64_t arena_cap = 0;
   uint32_t *d_slow = nullptr;  // reads the fast seed kernel leaves to the generic one
   uint32_t slow_cap = 0;
+  // dense indexes: what seed_select_kernel hands seed_join_kernel (6 R selected seeds + one header per read)
+  uint2 *d_sel = nullptr, *d_sel_hdr = nullptr;
+  size_t sel_cap = 0, sel_hdr_cap = 0;
   // pinned host results
   uint32_t *h_begin = nullptr, *h_count = nullptr;
   size_t h_per_read_cap = 0;
@@ -112,7 +116,7 @@ struct Slot {
 // ctr[4] | arena_ctr[2] | stats[4]
 constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
 // ... and, in a cache line of its own behind them, the work cursor of seed_fast_kernel
-constexpr size_t kCtlWorkCursor = 128, kCtlAlloc = 256;
+constexpr size_t kCtlWorkCursor = 128, kCtlWorkCursor2 = 192, kCtlAlloc = 256;  // (seed_select_kernel / seed_join_kernel)
 static_assert(kCtlBytes <= kCtlWorkCursor, "control block layout");
 
 }  // namespace
@@ -193,8 +197,11 @@ struct fem_dev {
   uint32_t *d_summary = nullptr;  // bucket summaries (femk::SeedParams::summary), built for sparse indexes only
   // dense indexes: occurrence table in 32-bit global coordinates + its sequence tables (fem_seed_dense.hip.h)
   uint32_t *d_occ32 = nullptr, *d_goff = nullptr, *d_blkseq = nullptr;
+  uint32_t *d_freq11 = nullptr;  // saturated byte frequencies per 11-mer (fem_seed_select.hip.h), 64 MiB
   int dense_occ_blocks = 0;
   uint64_t dense_occ_key = ~0ull;
+  int select_occ_blocks = 0, join_occ_blocks = 0;
+  uint64_t select_occ_key = ~0ull, join_occ_key = ~0ull;
   // reference
   uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
@@ -209,12 +216,13 @@ struct fem_dev {
   Slot slot[kSlots];
   bool timing = false;
   int verify_blocks_per_cu = 0;  // resident 256-thread blocks of verify_kernel per CU (queried once)
-  double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t t_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double t_ms[kTimedKernels] = {};
+  uint64_t t_n[kTimedKernels] = {};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
   bool force_dense = false;    // FEM_FORCE_DENSE=1: build the 32-bit tables and run seed_dense_kernel whatever the index density (test hook)
   bool no_dense = false;       // FEM_NO_DENSE=1: never run seed_dense_kernel (measurement / A-B hook)
+  bool fused_dense = false;    // FEM_DENSE_FUSED=1: the round-2 fused seed_dense_kernel instead of select + join (A-B hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
   std::vector<hipEvent_t> event_pool;
   // The slots' streams overlap copies with kernels, but the kernels of different batches run one after the other
@@ -385,6 +393,72 @@ femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
   return l;
 }
 
+// LDS of one wave of seed_select_kernel (fem_seed_select.hip.h): the block's read offsets, the sub-block's two 2-bit
+// streams, one frequency byte per seed, strand and phase group, the per-read words.  The reads of a block are worked
+// on `nb` at a time, as many as a budget of 8 KB of frequency bytes holds.
+femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
+  femk::SeedLayout l{};
+  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
+  l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
+  // a phase group's DP takes at most kSelMaxCols columns: groups of more than kSelMaxCols - 1 + 4 R seeds go to the generic kernel
+  const uint32_t g_max = std::min<uint32_t>((l.smax + 2u) / 3u, femk::kSelMaxCols - 1u + 4u * R);
+  l.gstride = ((g_max + 3u) & ~3u) + 4u;
+  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 8192u / (6u * l.gstride)));
+  l.strm_words = (l.nb * max_len + 15u) / 16u + 2u;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  l.rb = take((femk::kReadBlock + 2u) * 8u);
+  l.rinfo = take(4u * femk::kReadBlock * 4u);
+  l.strm = take(2u * l.strm_words * 4u);
+  l.fq = take(l.nb * 6u * l.gstride + 64u);
+  l.wave_bytes = o;
+  return l;
+}
+
+// LDS of one wave of seed_join_kernel: the strands' candidates, flagged values per phase group, scatter, the block's
+// begin/count entries, the sequence table, the join's bitmap
+femk::SeedLayout make_layout_join(const fem_params &p) {
+  femk::SeedLayout l{};
+  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  l.sf = take(2u * 64u * 4u);
+  l.X = take(64u * 4u);
+  l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
+  l.B = take(2u * femk::kReadBlock * 8u);
+  l.picked = take(64u * 8u);
+  l.F = take(femk::dense_bitmap_words((int)R) * 4u);
+  l.wave_bytes = o;
+  return l;
+}
+
+template <int R>
+void launch_select_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL((femk::seed_select_kernel<R>), grid, block, lds, st, sp);
+}
+template <int R>
+int select_blocks_per_cu_r(int block, uint32_t lds) {
+  int nb = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_select_kernel<R>, block, lds) == hipSuccess ? nb : 0;
+}
+template <int R>
+void launch_join_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL((femk::seed_join_kernel<R>), grid, block, lds, st, sp);
+}
+template <int R>
+int join_blocks_per_cu_r(int block, uint32_t lds) {
+  int nb = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_join_kernel<R>, block, lds) == hipSuccess ? nb : 0;
+}
+
 template <int R>
 void launch_dense_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
   hipLaunchKernelGGL((femk::seed_dense_kernel<R>), grid, block, lds, st, sp);
@@ -416,6 +490,30 @@ int dense_blocks_per_cu(int R, int block, uint32_t lds) {
 }
 void launch_dense(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
 #define FEM_CALL(r) launch_dense_r<r>(grid, block, lds, st, sp)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+}
+int select_blocks_per_cu(int R, int block, uint32_t lds) {
+  int nb = 0;
+#define FEM_CALL(r) nb = select_blocks_per_cu_r<r>(block, lds)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+  return nb;
+}
+void launch_select(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+#define FEM_CALL(r) launch_select_r<r>(grid, block, lds, st, sp)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+}
+int join_blocks_per_cu(int R, int block, uint32_t lds) {
+  int nb = 0;
+#define FEM_CALL(r) nb = join_blocks_per_cu_r<r>(block, lds)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+  return nb;
+}
+void launch_join(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+#define FEM_CALL(r) launch_join_r<r>(grid, block, lds, st, sp)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
 }
@@ -618,8 +716,46 @@ int launch_batch(fem_dev *h, Slot &s) {
       h->verify_blocks_per_cu = nb;
     }
     const uint32_t vgrid = (uint32_t)h->n_cu * (uint32_t)h->verify_blocks_per_cu;
-    if (use_fast && h->d_occ32) {
-      // dense index: 32-bit coordinates, bitmap join (fem_seed_dense.hip.h)
+    if (use_fast && h->d_occ32 && h->d_freq11 && !h->fused_dense) {
+      // dense index: seed selection for blocks of reads (fem_seed_select.hip.h), then the bitmap join on 32-bit
+      // coordinates, a wave per read (fem_seed_dense.hip.h)
+      const uint32_t max_len = std::max<uint32_t>(s.max_len, (uint32_t)p.k);
+      const size_t want_sel = (size_t)s.n_reads * 6u * (size_t)R;
+      if ((rc = dev_realloc(h, &s.d_sel, &s.sel_cap, want_sel))) return rc;
+      if ((rc = dev_realloc(h, &s.d_sel_hdr, &s.sel_hdr_cap, (size_t)s.n_reads))) return rc;
+      femk::SeedParams fp = sp;
+      fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
+      fp.freq11 = h->d_freq11, fp.sel = s.d_sel, fp.sel_hdr = s.d_sel_hdr;
+      fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
+      const uint64_t blocks_of_reads = (s.n_reads + femk::kReadBlock - 1) / femk::kReadBlock;
+      {
+        fp.lay = make_layout_select(p, max_len);
+        if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
+        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
+        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
+        const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
+        if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
+        const uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
+        fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
+        rc = timed(8, s.stream, [&] { launch_select(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+        if (rc) return rc;
+      }
+      {
+        fp.lay = make_layout_join(p);
+        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
+        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
+        const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
+        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
+        const uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
+        fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
+        rc = timed(0, s.stream, [&] { launch_join(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+        if (rc) return rc;
+      }
+      sp.work_queue = s.d_slow;  // the generic kernel finishes what the two queued
+    } else if (use_fast && h->d_occ32) {
+      // (A-B hook FEM_DENSE_FUSED=1: round 2's fused kernel)
       femk::SeedParams fp = sp;
       fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
       fp.lay = make_layout_dense(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
@@ -742,9 +878,9 @@ int refresh_summary(fem_dev *h) {
 // form of seed_fast_kernel runs instead) when the coordinates do not fit 32 bits.
 constexpr double kDenseMinAvgBucket = 4.0;
 int refresh_dense(fem_dev *h) {
-  for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq})
+  for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11})
     if (p) (void)hipFree(p);
-  h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr;
+  h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr;
   if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
   const uint64_t n_buckets = h->n_lookup - 1;
   if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
@@ -781,7 +917,13 @@ int refresh_dense(fem_dev *h) {
   if (bad) {  // the index names sequences the reference does not have: leave that to the 64-bit path's checks
     (void)hipFree(h->d_occ32);
     h->d_occ32 = nullptr;
+    return FEM_OK;
   }
+  // byte frequencies per 11-mer for seed_select_kernel (fem_seed_select.hip.h)
+  HIP_TRY(h, hipMalloc((void **)&h->d_freq11, (size_t)femk::kX11 * 4u * sizeof(uint32_t)));
+  hipLaunchKernelGGL(femk::freq11_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, h->d_freq11);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipDeviceSynchronize());
   return FEM_OK;
 }
 
@@ -928,6 +1070,8 @@ int fem_dev_open(int device, fem_dev **out) {
   h->force_dense = fd && fd[0] == '1';
   const char *nd = getenv("FEM_NO_DENSE");
   h->no_dense = nd && nd[0] == '1';
+  const char *fu = getenv("FEM_DENSE_FUSED");
+  h->fused_dense = fu && fu[0] == '1';
   const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
   h->tiny_buffers = tb && tb[0] == '1';
   *out = h;
@@ -948,7 +1092,7 @@ int fem_dev_close(fem_dev *h) {
     drain_timing(h, s);
     for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
-                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_packed, (void *)s.d_quals, (void *)s.d_names,
+                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_sel, (void *)s.d_sel_hdr, (void *)s.d_packed, (void *)s.d_quals, (void *)s.d_names,
                     (void *)s.d_name_off})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
@@ -964,7 +1108,8 @@ int fem_dev_close(fem_dev *h) {
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
-                  (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq})
+                  (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
+                  (void *)h->d_freq11})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -1550,7 +1695,7 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
   const int R = p->e + 1 + p->a;
   const bool use_fast = !h->force_generic && p->k == femk::kK && p->step == femk::kStep && R >= 1 && R <= femk::kMaxR;
   if (!use_fast) return "seed_filter_kernel";
-  if (h->d_occ32) return "seed_dense_kernel";
+  if (h->d_occ32) return h->d_freq11 && !h->fused_dense ? "seed_join_kernel" : "seed_dense_kernel";
   return (h->force_hash || (double)h->n_occ > (double)h->n_lookup) ? "seed_fast_kernel<hash>" : "seed_fast_kernel<lean>";
 }
 
@@ -1572,12 +1717,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
-  for (int i = 0; i < 8; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
+  for (int i = 0; i < kTimedKernels; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
   return FEM_OK;
 }
 
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches) {
-  if (!h || kernel < 0 || kernel > 7) return FEM_ERR_INVALID;
+  if (!h || kernel < 0 || kernel >= kTimedKernels) return FEM_ERR_INVALID;
   if (ms_total) *ms_total = h->t_ms[kernel];
   if (launches) *launches = h->t_n[kernel];
   return FEM_OK;

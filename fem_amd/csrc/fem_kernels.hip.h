@@ -47,6 +47,8 @@ struct SeedLayout {
   uint32_t gq, gq_cap;       // seed_fast_kernel, lean form: queue of live phase groups (rows of gq_cap words, then descriptors)
   uint32_t strm, strm_words; // seed_fast_kernel, lean form: three 2-bit streams over one block of reads (forward bases,
                              // their reverse complement, N marks), strm_words words each, a pad word at either end included
+  uint32_t fq, gstride, nb;  // seed_select_kernel: byte frequencies [nb reads][2][3][gstride], reads per sub-block
+  uint32_t rinfo;            // seed_select_kernel: uint32[4][16] per-read place / length / flags / pre-filter count
   uint32_t wave_bytes;
 };
 
@@ -83,6 +85,12 @@ struct SeedParams {
   const uint32_t *occ32;
   const uint32_t *goff;
   const uint32_t *blkseq;
+  // seed_select_kernel -> seed_join_kernel (fem_seed_select.hip.h): saturated byte frequencies per 11-mer; per read and
+  // (strand, phase group) the R selected seeds in run order (lookup[h], start | frequency << 16); per read
+  // (status | length << 8, pre-filter count)
+  const uint32_t *freq11;
+  uint2 *sel;
+  uint2 *sel_hdr;
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries

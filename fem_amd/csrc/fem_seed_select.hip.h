@@ -1,0 +1,379 @@
+// fem_seed_select.hip.h — seed selection for DENSE indexes as a kernel of its own (k = 12, step = 3, R at compile time):
+// hash_all_seeds_in_sequence + the frequency lookups + generate_optimal_prefix_qgram_for_group_seeding + the stable
+// qsort of the selected seeds (reference src/utils.h:83-117, src/index.h:22-28, src/filter.c:3-43,146-204), for both
+// strands of every read.  Its output — per read and (strand, phase group) the R selected seeds in run order as
+// (lookup[h], start | frequency << 16) — is what seed_join_kernel (fem_seed_dense.hip.h) walks the lists of.
+//
+// Why a kernel of its own: inside the wave-per-read kernel this front end used 6..60 of the 64 lanes and 178 random
+// 8-byte table reads per read, each of which moves a 64-byte sector across the fabric.  Here the work is laid out so
+// that every lane is busy, over blocks of reads:
+//   * FREQUENCY PAIRS BY 11-MER.  The DP only needs frequencies, and the seeds at read offsets j and j + 1 share eleven
+//     bases X.  The derived table freq11 holds, per 11-mer X, sixteen saturated byte frequencies: of the four 12-mers
+//     a.X and the four X.b, and of the reverse complements of those eight (which are again extensions of rc(X)).  Lane
+//     j reads ONE dword of it — X = the seed's last eleven bases when j is even, its first eleven when j is odd — and
+//     has the frequency of seed j on the forward strand and of its reverse complement (seed S-1-j of the reverse
+//     strand).  89 four-byte lane-loads in 45 sectors per 100-base read instead of 178 eight-byte ones in 178 sectors.
+//     lookup[h] itself is fetched for the 6 R selected seeds only.  A frequency of 255 or more sends the read to the
+//     generic kernel (never on BASELINE's references: their buckets hold 60 +- 8 entries).
+//   * ONE LANE PER PHASE GROUP.  The DP table of a group is R rows by C - 1 <= 64 columns.  A lane walks it column by
+//     column with the R running row values in registers; the frequencies it needs for a column are byte b of R
+//     consecutive dwords of the group's byte array (seed index = column + 4 (row - 1)), so four columns cost one LDS
+//     read.  Six cells' worth of vector instructions per cell, 64 groups (ten reads) at a time, against one DPP
+//     prefix-min chain per row and group before.  Take bits are shifted into per-row masks; the traceback, the
+//     frequency sort (a sorting network on frequency << 14 | traceback order << 10 | start: stable by construction)
+//     and the lookup of the selected seeds' list bases stay in the lane.
+#pragma once
+#include "fem_seed_fast.hip.h"
+
+namespace femk {
+
+constexpr uint32_t kSelOk = 0u, kSelNone = 1u, kSelSlow = 2u;  // sel_hdr[read].x & 3: joined / no candidates / generic kernel
+constexpr uint32_t kSelMaxCols = 64u;                          // DP columns a lane's take masks hold
+constexpr uint32_t kSelMaxList = 128u;                         // longest list seed_join_kernel takes (kDenseMaxList)
+constexpr uint32_t kX11 = 1u << 22;                            // number of 11-mers
+
+// wave-wide min / max of a 32-bit value (DPP scans; the result is wave-uniform)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+  constexpr uint32_t kFill = 0xFFFFFFFFu;
+  x = dpp_min_step<0x111, 0xF>(x, kFill), x = dpp_min_step<0x112, 0xF>(x, kFill), x = dpp_min_step<0x114, 0xF>(x, kFill);
+  x = dpp_min_step<0x118, 0xF>(x, kFill), x = dpp_min_step<0x142, 0xA>(x, kFill), x = dpp_min_step<0x143, 0xC>(x, kFill);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(x), 63);
+}
+
+// reverse complement of an 11-mer (22 bits)
+__device__ __forceinline__ uint32_t rc11(uint32_t x) {
+  const uint32_t r = __brev(~x & (kX11 - 1u)) >> 10;
+  return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+// freq11[X * 4 + i], bytes: 0 = f(i.X)   1 = f(rc(i.X))   2 = f(X.i)   3 = f(rc(X.i)),  f saturated at 255
+__global__ void freq11_kernel(const uint32_t *lookup, uint32_t *freq11) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < kX11 * 4u; t += stride) {
+    const uint32_t X = t >> 2, i = t & 3u, rx = rc11(X);
+    auto f = [&](uint32_t h) -> uint32_t {
+      const uint32_t d = lookup[h + 1u] - lookup[h];
+      return d < 255u ? d : 255u;
+    };
+    const uint32_t h_l = (i << 22) | X, h_r = (X << 2) | i;
+    const uint32_t h_lrc = (rx << 2) | (3u - i), h_rrc = ((3u - i) << 22) | rx;
+    freq11[t] = f(h_l) | (f(h_lrc) << 8) | (f(h_r) << 16) | (f(h_rrc) << 24);
+  }
+}
+
+// 32 consecutive bits of a big-endian packed 2-bit stream, starting at base `pos`
+__device__ __forceinline__ uint32_t stream_window(const uint32_t *strm, uint32_t pos) {
+  const uint32_t w = pos >> 4, sh = 2u * (pos & 15u);
+  const uint32_t w0 = strm[w], w1 = strm[w + 1u];
+  return sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+}
+// hash of the reverse complement of a 12-mer whose forward hash is hf (N counted as A on both strands: nm marks them)
+__device__ __forceinline__ uint32_t rc_hash(uint32_t hf, uint32_t nm) {
+  const uint32_t r = __brev((~hf) & ~nm & kHashMask) >> (32 - 2 * kK);
+  return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The seed-selection DP of one phase group in one lane (src/filter.c:3-28).  F = the group's frequencies, one byte per
+// seed; ncols = C - 1 of this lane's group (0: idle lane), maxcols = the largest in the wave.  Column c (0-based)
+// of row r (0-based) uses seed c + 4 r.  take[r] receives the take bits: column c at bit iters - 1 - c.
+// ---------------------------------------------------------------------------------------------------------
+template <int R, bool WIDE>
+__device__ __forceinline__ void select_dp(const uint8_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&tlo)[R],
+                                          uint32_t (&thi)[R], uint32_t &m_last, uint32_t &iters) {
+  uint32_t M[R], W[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) M[r] = inf, tlo[r] = 0, thi[r] = 0, W[r] = *(const uint32_t *)(F + 4 * r);
+  const uint32_t n_grp = (maxcols + 3u) >> 2;
+  for (uint32_t cg = 0; cg < n_grp; ++cg) {
+    const uint32_t w_next = *(const uint32_t *)(F + 4u * (cg + (uint32_t)R));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool in = 4u * cg + (uint32_t)b < ncols;
+      uint32_t up = 0;  // M[0][c] = 0
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t v = up + __builtin_amdgcn_ubfe(W[r], 8u * (uint32_t)b, 8u);  // uint32 wrap as in the reference
+        const bool take = in && v < M[r];  // strict: ties go horizontal (src/filter.c:20); M[r][0] = inf (src/filter.c:9)
+        M[r] = take ? v : M[r];
+        up = M[r];
+        if (WIDE) thi[r] = (thi[r] << 1) | (tlo[r] >> 31);
+        tlo[r] = (tlo[r] << 1) | (uint32_t)take;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) W[r] = W[r + 1];
+    W[R - 1] = w_next;
+  }
+  m_last = M[R - 1];
+  iters = 4u * n_grp;
+}
+
+#ifndef FEM_SELECT_WAVES
+#define FEM_SELECT_WAVES 4
+#endif
+#ifndef FEM_SELECT_UNROLL
+#define FEM_SELECT_UNROLL 4
+#endif
+
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SELECT_WAVES, 8))) seed_select_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t ln = lane_id();
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
+  uint64_t *boff = (uint64_t *)(wbase + p.lay.rb);    // offsets of the block's reads (kReadBlock + 1)
+  uint32_t *fw = (uint32_t *)(wbase + p.lay.strm);    // the sub-block's bases, 2 bits each (N as A), 16 per big-endian word
+  uint32_t *nw = fw + p.lay.strm_words;               // ... and its N marks (3 = not one of ACGT)
+  uint8_t *fq = wbase + p.lay.fq;                     // [read][strand][phase][gstride] frequencies, one byte per seed
+  uint32_t *r_base = (uint32_t *)(wbase + p.lay.rinfo), *r_len = r_base + kReadBlock, *r_flag = r_len + kReadBlock,
+           *r_pre = r_flag + kReadBlock;              // per read of the sub-block
+  constexpr uint32_t kOk0 = 1u, kOk1 = 2u, kShape = 4u, kSlow = 8u;
+  const uint32_t gstride = p.lay.gstride, nb = p.lay.nb;
+  const uint32_t inf = p.inf32;
+  SlotChunk qchunk;
+
+  auto queue_slow = [&](uint32_t read) {
+    if (qchunk.left == 0) {
+      uint32_t base = 0;
+      if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
+      qchunk.next = bcast0(base);
+      qchunk.left = kQueueChunk;
+    }
+    if (qchunk.next < p.slow_cap) {
+      if (ln == 0) p.slow_queue[qchunk.next] = read;
+    } else if (ln == 0) {
+      atomicOr(&p.ctr[1], kFlagQueueOverflow);
+    }
+    ++qchunk.next, --qchunk.left;
+  };
+
+  for (;;) {
+    uint32_t pull = 0;
+    if (ln == 0) pull = atomicAdd(p.work_cursor, kReadBlock);
+    pull = bcast0(pull);
+    if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
+    const uint32_t r0 = p.read_begin + pull;
+    const uint32_t n_blk = p.n_reads - r0 < kReadBlock ? p.n_reads - r0 : kReadBlock;
+    wave_sync_lds();
+    if (ln <= n_blk) boff[ln] = p.read_off[r0 + ln];
+    wave_sync_lds();
+    for (uint32_t sb = 0; sb < n_blk; sb += nb) {
+      const uint32_t cnt = n_blk - sb < nb ? n_blk - sb : nb;
+      const uint32_t rd0 = r0 + sb;
+      const uint64_t o_first = boff[sb];
+      const uint64_t blk_off = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)o_first) |
+                               ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o_first >> 32)) << 32);
+      // ---- per read (lane i): place in the stream, length, gates (src/filter.c:161-172) and the shapes on which the
+      //      reference DP is undefined (src/filter.c:5-7) ----
+      uint32_t my_S = 0, my_flag = 0;
+      {
+        uint32_t L = 0, base = 0;
+        if (ln < cnt) {
+          const uint64_t o0 = boff[sb + ln], o1 = boff[sb + ln + 1u];
+          L = (uint32_t)(o1 - o0), base = (uint32_t)(o0 - blk_off);
+          const int S = (int)L - kK + 1;
+          bool shape_ok = S > 0 && R <= S / kStep;
+          if (shape_ok) shape_ok = (S - (kStep - 1)) / kStep - R * kLg + 2 >= 2;
+          if (shape_ok) {
+            my_S = (uint32_t)S;
+            my_flag = kShape | kOk0 | kOk1;
+            const uint32_t widest = (uint32_t)(S / kStep - R * kLg + 1);  // columns of phase group 0
+            if (widest > kSelMaxCols || p.a == 0) my_flag |= kSlow;
+          }
+        }
+        if (ln < kReadBlock) r_base[ln] = base, r_len[ln] = L, r_flag[ln] = my_flag, r_pre[ln] = 0;
+      }
+      const uint32_t total_chars = (uint32_t)(boff[sb + cnt] - blk_off);
+      // ---- encode the sub-block: four characters per lane -> one byte of each stream ----
+      uint32_t any_n = 0;
+      {
+        const uint8_t *src = p.bases + blk_off;
+        for (uint32_t q = ln; 4u * q < total_chars; q += (uint32_t)kWave) {
+          uint32_t code, nflag;
+          encode4(load_u32_unaligned(src + 4u * q), code, nflag);  // may run up to 3 bytes past the sub-block: masked
+          const uint32_t left = total_chars - 4u * q;
+          const uint32_t keep = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
+          nflag &= keep;
+          code &= keep & ~(nflag * 3u);  // N -> A (src/utils.h:92)
+          const uint32_t byte_addr = (q >> 2) * 4u + (3u - (q & 3u));
+          ((uint8_t *)fw)[byte_addr] = (uint8_t)pack4(code);
+          ((uint8_t *)nw)[byte_addr] = (uint8_t)pack4(nflag * 3u);
+          any_n |= nflag;
+        }
+      }
+      const bool has_n = __builtin_amdgcn_ballot_w64(any_n != 0) != 0;
+      wave_sync_lds();
+      if (has_n) {
+        // rare: the ambiguous-base gate per read and strand (src/utils.h:108-114, src/filter.c:180-182); bases at
+        // offsets >= k count on the forward strand, at offsets <= L - 1 - k on the reverse strand
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const uint32_t L = r_len[i], base = r_base[i];
+          uint32_t n_f = 0, n_r = 0;
+          for (uint32_t b0 = 0; b0 < L; b0 += (uint32_t)kWave) {
+            const uint32_t at = b0 + ln;
+            if (at < L) {
+              const uint32_t pos = base + at;
+              const uint32_t isn = (nw[pos >> 4] >> (30u - 2u * (pos & 15u))) & 1u;
+              n_f += isn & (uint32_t)(at >= (uint32_t)kK);
+              n_r += isn & (uint32_t)(L - 1u - at >= (uint32_t)kK);
+            }
+          }
+          for (int d = 32; d >= 1; d >>= 1) n_f += __shfl_xor(n_f, d), n_r += __shfl_xor(n_r, d);
+          if (ln == 0) {
+            uint32_t fl = r_flag[i];
+            if (n_f > (uint32_t)p.e) fl &= ~kOk0;
+            if (n_r > (uint32_t)p.e) fl &= ~kOk1;
+            r_flag[i] = fl;
+          }
+        }
+        wave_sync_lds();
+      }
+      // ---- frequencies of every seed on both strands: lane (read i, seed j), one freq11 dword each ----
+      const uint32_t SP = wave_max_u32(my_S);
+      if (SP != 0) {
+        const uint32_t magic = 0xFFFFFFFFu / SP + 1u;  // w / SP = umulhi(w, magic) for w * SP < 2^32
+        const uint32_t total = cnt * SP;
+        constexpr int U = FEM_SELECT_UNROLL;
+        for (uint32_t w0 = 0; w0 < total; w0 += (uint32_t)(U * kWave)) {
+          uint32_t d[U], hfv[U], nmv[U], ii[U], jj[U], Sv[U];
+          bool act[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + (uint32_t)(u * kWave) + ln;
+            const uint32_t i = __umulhi(w, magic), j = w - i * SP;
+            const uint32_t i_c = i < cnt ? i : 0u;
+            const uint32_t fl = r_flag[i_c], S = r_len[i_c] - (uint32_t)(kK - 1);
+            act[u] = w < total && (fl & kShape) && !(fl & kSlow) && j < S;
+            ii[u] = i_c, jj[u] = j, Sv[u] = S;
+            d[u] = 0, hfv[u] = 0, nmv[u] = 0;
+            if (act[u]) {
+              const uint32_t pos = r_base[i_c] + j;
+              const uint32_t hf = stream_window(fw, pos) >> 8;
+              hfv[u] = hf;
+              if (has_n) nmv[u] = stream_window(nw, pos) >> 8;
+              // even j: the seed's last eleven bases + its first base; odd j: its first eleven + its last
+              const uint32_t at = (j & 1u) ? hf : (((hf & (kX11 - 1u)) << 2) | (hf >> 22));
+              d[u] = p.freq11[at];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (act[u]) {
+              const uint32_t j = jj[u], S = Sv[u], i = ii[u];
+              const uint32_t sh = (j & 1u) * 16u;
+              const uint32_t f_fwd = (d[u] >> sh) & 255u;
+              uint32_t f_rev = (d[u] >> (sh + 8u)) & 255u;
+              if (has_n && nmv[u] != 0u) {  // the reverse strand counts N as A after complementing: its own hash
+                const uint32_t hr = rc_hash(hfv[u], nmv[u]);
+                const uint32_t df = p.lookup[hr + 1u] - p.lookup[hr];
+                f_rev = df < 255u ? df : 255u;
+              }
+              const uint32_t jr = S - 1u - j;
+              const uint32_t gi = __umulhi(j, 0x55555556u), gr = __umulhi(jr, 0x55555556u);  // / 3
+              uint8_t *row = fq + (size_t)i * 6u * gstride;
+              row[(j - 3u * gi) * gstride + gi] = (uint8_t)f_fwd;
+              row[(3u + jr - 3u * gr) * gstride + gr] = (uint8_t)f_rev;
+              if (f_fwd == 255u || f_rev == 255u) atomicOr(&r_flag[i], kSlow);
+            }
+          }
+        }
+      }
+      wave_sync_lds();
+      // ---- seed selection: lane (read i, strand, phase) ----
+      const uint32_t n_gl = cnt * 6u;
+      for (uint32_t gl0 = 0; gl0 < n_gl; gl0 += (uint32_t)kWave) {
+        const uint32_t gl = gl0 + ln;
+        const uint32_t i = __umulhi(gl, 0x2AAAAAABu), u = gl - 6u * i;  // / 6
+        const uint32_t i_c = gl < n_gl ? i : 0u;
+        const uint32_t strand = u >= 3u ? 1u : 0u, si = u - 3u * strand;
+        const uint32_t fl = r_flag[i_c], S = r_len[i_c] - (uint32_t)(kK - 1);
+        const bool read_ok = gl < n_gl && (fl & kShape) && !(fl & kSlow);
+        const bool valid = read_ok && ((fl >> strand) & 1u);
+        const uint32_t ncols = valid ? (S - si) / 3u - (uint32_t)(R * kLg) + 1u : 0u;
+        const uint32_t maxcols = wave_max_u32(ncols);
+        const uint8_t *F = fq + ((size_t)i_c * 6u + u) * gstride;
+        uint32_t key[R];  // frequency << 14 | traceback order << 10 | start, per selected seed
+#pragma unroll
+        for (int t = 0; t < R; ++t) key[t] = (uint32_t)t << 10;  // a seed that was never taken is all zero (see below)
+        if (maxcols != 0) {
+          uint32_t tlo[R], thi[R], m_last = 0, iters = 0;
+          if (maxcols <= 32u)
+            select_dp<R, false>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
+          else
+            select_dp<R, true>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
+          if (valid) atomicAdd(&r_pre[i_c], m_last);  // M[R][C-1] (src/filter.c:202)
+          // ---- traceback (src/filter.c:30-41): row R first; the highest taken column at or below the previous one.
+          //      If column 0 is reached before R seeds were taken the reference's remaining seeds are uninitialised
+          //      (src/filter.c:33-41): all zero here, as in the oracle ----
+          int col = (int)ncols - 1;
+          bool alive = valid;
+#pragma unroll
+          for (int r = R - 1; r >= 0; --r) {
+            const int t = R - 1 - r;
+            if (alive) {
+              const uint32_t shift = iters - 1u - (uint32_t)col;  // bits >= shift are the columns <= col
+              const uint64_t seg = ((((uint64_t)thi[r]) << 32) | tlo[r]) >> shift;
+              if (seg == 0) {
+                alive = false;
+              } else {
+                col -= __builtin_ctzll(seg);
+                const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
+                key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + 3u * idx);
+              }
+            }
+          }
+        }
+        // ---- qsort(compare_seed) (src/filter.c:204): ascending frequency, stable (glibc's merge sort):
+        //      the traceback order in the key breaks ties, so any sorting network gives the stable order ----
+#pragma unroll
+        for (int ps = 0; ps < R; ++ps) {
+#pragma unroll
+          for (int x = ps & 1; x + 1 < R; x += 2) {
+            const uint32_t lo = key[x] < key[x + 1] ? key[x] : key[x + 1], hi = key[x] < key[x + 1] ? key[x + 1] : key[x];
+            key[x] = lo, key[x + 1] = hi;
+          }
+        }
+        // ---- the selected seeds' list bases; hand-over ----
+        if (read_ok) {
+          const uint32_t base = r_base[i_c];
+          uint2 *out = p.sel + ((size_t)(rd0 + i_c) * 6u + u) * (uint32_t)R;
+          uint32_t lo[R];
+          bool too_long = false;
+#pragma unroll
+          for (int t = 0; t < R; ++t) {
+            const uint32_t f = key[t] >> 14, sidx = key[t] & 1023u;
+            lo[t] = 0;
+            if (f != 0u) {
+              const uint32_t j = strand ? S - 1u - sidx : sidx;
+              const uint32_t hf = stream_window(fw, base + j) >> 8;
+              uint32_t h = hf;
+              if (strand) h = rc_hash(hf, has_n ? stream_window(nw, base + j) >> 8 : 0u);
+              lo[t] = p.lookup[h];
+            }
+            too_long |= f > kSelMaxList;
+          }
+#pragma unroll
+          for (int t = 0; t < R; ++t) out[t] = make_uint2(lo[t], (key[t] & 1023u) | ((key[t] >> 14) << 16));
+          if (too_long) atomicOr(&r_flag[i_c], kSlow);
+        }
+      }
+      wave_sync_lds();
+      // ---- per read: what the join kernel is to do with it ----
+      {
+        const uint32_t fl = ln < cnt ? r_flag[ln] : 0u;
+        const uint32_t status = !(fl & kShape) ? kSelNone : (fl & kSlow) ? kSelSlow : kSelOk;
+        if (ln < cnt) p.sel_hdr[rd0 + ln] = make_uint2(status | (r_len[ln] << 8), r_pre[ln]);
+        for (uint64_t m = __builtin_amdgcn_ballot_w64(ln < cnt && status == kSelSlow); m; m &= m - 1) queue_slow(rd0 + (uint32_t)__builtin_ctzll(m));
+      }
+      wave_sync_lds();
+    }
+  }
+  for (uint32_t i = ln; i < qchunk.left; i += kWave)
+    if (qchunk.next + i < p.slow_cap) p.slow_queue[qchunk.next + i] = kInvalidRead;
+}
+
+}  // namespace femk
