@@ -26,7 +26,7 @@
 #include "fem_index_build.hip.h"
 #include "fem_kernels.hip.h"
 #include "fem_seed_fast.hip.h"
-#include "fem_seed_dense.hip.h"
+#include "fem_seed_join.hip.h"
 #include "fem_tail.hip.h"
 
 namespace {
@@ -230,6 +230,13 @@ struct fem_dev {
   // evict each other's index lines, and per-kernel event times stay those of a kernel that has the chip to itself.
   hipEvent_t ev_kernels_done = nullptr;
   bool have_kernels_done = false;
+  // Dense indexes: seed_select_kernel of batch i + 1 runs BESIDE batch i's seed_join_kernel (it is bound by the rate of
+  // table sectors the fabric delivers and needs four waves per CU for that; the join is bound by instruction issue):
+  // selections are chained among themselves, and a batch's join waits for its own selection and the previous batch's
+  // kernels.  FEM_NO_OVERLAP=1: one after the other (measurement hook).
+  hipEvent_t ev_select_done = nullptr;
+  bool have_select_done = false;
+  bool no_overlap = false;
 };
 
 namespace {
@@ -395,7 +402,8 @@ femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
 
 // LDS of one wave of seed_select_kernel (fem_seed_select.hip.h): the block's read offsets, the sub-block's two 2-bit
 // streams, one frequency byte per seed, strand and phase group, the per-read words.  The reads of a block are worked
-// on `nb` at a time, as many as a budget of 8 KB of frequency bytes holds.
+// on `nb` at a time, as many as a budget of 2 KB of frequency bytes holds (the kernel runs beside seed_join_kernel, whose
+// bitmaps want the LDS).
 femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   femk::SeedLayout l{};
   const uint32_t R = (uint32_t)(p.e + 1 + p.a);
@@ -403,7 +411,7 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   // a phase group's DP takes at most kSelMaxCols columns: groups of more than kSelMaxCols - 1 + 4 R seeds go to the generic kernel
   const uint32_t g_max = std::min<uint32_t>((l.smax + 2u) / 3u, femk::kSelMaxCols - 1u + 4u * R);
   l.gstride = ((g_max + 3u) & ~3u) + 4u;
-  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 8192u / (6u * l.gstride)));
+  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 2048u / (6u * l.gstride)));
   l.strm_words = (l.nb * max_len + 15u) / 16u + 2u;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) {
@@ -434,9 +442,9 @@ femk::SeedLayout make_layout_join(const fem_params &p) {
   l.X = take(64u * 4u);
   l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
-  l.picked = take(64u * 8u);
-  l.F = take(femk::dense_bitmap_words((int)R) * 4u);
+  l.F = take(femk::join_bitmap_words((int)R) * 4u);
   l.wave_bytes = o;
+  l.picked = 0;  // the block's sequence table: set by the launcher (behind the waves' regions)
   return l;
 }
 
@@ -492,6 +500,22 @@ void launch_dense(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, co
 #define FEM_CALL(r) launch_dense_r<r>(grid, block, lds, st, sp)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
+}
+template <int R>
+uint32_t kernel_regs_r(bool join) {
+  hipFuncAttributes a{};
+  const void *f = join ? (const void *)femk::seed_join_kernel<R> : (const void *)femk::seed_select_kernel<R>;
+  return hipFuncGetAttributes(&a, f) == hipSuccess && a.numRegs > 0 ? (uint32_t)a.numRegs : 128u;
+}
+// vector registers per lane of seed_join_kernel<R> / seed_select_kernel<R>
+uint32_t kernel_regs(int R, bool join) {
+  static uint32_t cache[2][femk::kMaxR + 1] = {};
+  uint32_t &c = cache[join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
+  if (c) return c;
+#define FEM_CALL(r) c = kernel_regs_r<r>(join)
+  FEM_DENSE_SWITCH(R, FEM_CALL)
+#undef FEM_CALL
+  return c;
 }
 int select_blocks_per_cu(int R, int block, uint32_t lds) {
   int nb = 0;
@@ -702,7 +726,9 @@ int launch_batch(fem_dev *h, Slot &s) {
 
   if (s.n_reads) {
     int rc;
-    if (h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
+    const bool split_dense = use_fast && h->d_occ32 && h->d_freq11 && !h->fused_dense;
+    const bool overlap = split_dense && !h->no_overlap;
+    if (!overlap && h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
     femk::VerifyParams vp{};
     vp.bases = s.bases(), vp.read_off = s.d_off;
     vp.plane[0] = h->d_plane[0], vp.plane[1] = h->d_plane[1], vp.plane[2] = h->d_plane[2], vp.seq_off = h->d_seq_off;
@@ -716,7 +742,7 @@ int launch_batch(fem_dev *h, Slot &s) {
       h->verify_blocks_per_cu = nb;
     }
     const uint32_t vgrid = (uint32_t)h->n_cu * (uint32_t)h->verify_blocks_per_cu;
-    if (use_fast && h->d_occ32 && h->d_freq11 && !h->fused_dense) {
+    if (split_dense) {
       // dense index: seed selection for blocks of reads (fem_seed_select.hip.h), then the bitmap join on 32-bit
       // coordinates, a wave per read (fem_seed_dense.hip.h)
       const uint32_t max_len = std::max<uint32_t>(s.max_len, (uint32_t)p.k);
@@ -728,6 +754,7 @@ int launch_batch(fem_dev *h, Slot &s) {
       fp.freq11 = h->d_freq11, fp.sel = s.d_sel, fp.sel_hdr = s.d_sel_hdr;
       fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
       const uint64_t blocks_of_reads = (s.n_reads + femk::kReadBlock - 1) / femk::kReadBlock;
+      uint32_t select_lds = 0, select_threads = 256;
       {
         fp.lay = make_layout_select(p, max_len);
         if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
@@ -735,19 +762,43 @@ int launch_batch(fem_dev *h, Slot &s) {
         const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
         const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
         if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
-        const uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
+        uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        if (overlap) per_cu = 1;  // (3.3 ms per 2.5 M reads of C3 with one block per CU as with five: sectors per second, not waves)
+        static const int sel_cap = getenv("FEM_SELECT_BLOCKS_PER_CU") ? atoi(getenv("FEM_SELECT_BLOCKS_PER_CU")) : 0;
+        if (sel_cap > 0) per_cu = std::min<uint64_t>(per_cu, (uint64_t)sel_cap);
+        select_lds = lds_bytes, select_threads = 64u * wpb;
+        if (overlap && h->have_select_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_select_done, 0));
+        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
+        static const int sel_grid = getenv("FEM_SELECT_GRID") ? atoi(getenv("FEM_SELECT_GRID")) : 0;
+        if (sel_grid > 0) grid = std::min<uint32_t>(grid, (uint32_t)sel_grid);
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
         rc = timed(8, s.stream, [&] { launch_select(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
         if (rc) return rc;
+        if (overlap) {
+          HIP_TRY(h, hipEventRecord(h->ev_select_done, s.stream));
+          h->have_select_done = true;
+          if (h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
+        }
       }
       {
         fp.lay = make_layout_join(p);
-        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
-        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
+        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / fp.lay.wave_bytes));
+        fp.lay.picked = wpb * fp.lay.wave_bytes;
+        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes + 64u * 8u;
         const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
         if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
-        const uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        if (overlap) {
+          // leave one block of the next batch's seed_select_kernel room on every CU: registers (512 per lane and SIMD,
+          // handed out in eights), LDS (160 KB) and wave slots (8 per SIMD) of both kernels together
+          const uint32_t vj = (kernel_regs(R, true) + 7u) & ~7u, vs = (kernel_regs(R, false) + 7u) & ~7u;
+          const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
+          while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lds_bytes + select_lds > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
+          static const bool dbg = getenv("FEM_DEBUG") != nullptr;
+          if (dbg) fprintf(stderr, "[femhip] overlap: join regs %u select regs %u, join lds %u select lds %u -> %llu join blocks per CU\n", vj, vs, lds_bytes, select_lds, (unsigned long long)per_cu);
+        }
+        static const int join_cap = getenv("FEM_JOIN_BLOCKS_PER_CU") ? atoi(getenv("FEM_JOIN_BLOCKS_PER_CU")) : 0;
+        if (join_cap > 0) per_cu = std::min<uint64_t>(per_cu, (uint64_t)join_cap);
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
         rc = timed(0, s.stream, [&] { launch_join(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
@@ -1058,10 +1109,13 @@ int fem_dev_open(int device, fem_dev **out) {
       return FEM_ERR_HIP;
     }
   }
-  if (hipEventCreateWithFlags(&h->ev_kernels_done, hipEventDisableTiming) != hipSuccess) {
+  if (hipEventCreateWithFlags(&h->ev_kernels_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_select_done, hipEventDisableTiming) != hipSuccess) {
     delete h;
     return FEM_ERR_HIP;
   }
+  const char *no = getenv("FEM_NO_OVERLAP");
+  h->no_overlap = no && no[0] == '1';
   const char *fg = getenv("FEM_FORCE_GENERIC");
   h->force_generic = fg && fg[0] == '1';
   const char *fh = getenv("FEM_FORCE_HASH");
@@ -1106,6 +1160,7 @@ int fem_dev_close(fem_dev *h) {
   if (h->d_ref_name_off) (void)hipFree(h->d_ref_name_off);
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
+  if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
                   (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,

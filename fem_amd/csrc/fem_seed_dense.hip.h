@@ -731,161 +731,4 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dense_
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// seed_join_kernel<R>: merge_candidate_locations .. remove_out_ranged_candidates (src/filter.c:80-144,205-222) for the
-// reads seed_select_kernel (fem_seed_select.hip.h) prepared: one wave per read, reads pulled in blocks of 16.  A read's
-// 6 R selected seeds come in with ONE coalesced load (lane (strand * 3 + group) * R + run: list base, start |
-// frequency << 16), requested while the previous read is joined; everything else is dense_join and the hand-over.
-// ---------------------------------------------------------------------------------------------------------
-#ifndef FEM_JOIN_WAVES_LO
-#define FEM_JOIN_WAVES_LO 5
-#endif
-#ifndef FEM_JOIN_WAVES_HI
-#define FEM_JOIN_WAVES_HI 4
-#endif
-constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_WAVES_HI; }
-
-template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(join_waves(R), 8))) seed_join_kernel(SeedParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
-  static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
-  const uint32_t ln = lane_id();
-  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
-  uint32_t *scatter = (uint32_t *)(wbase + p.lay.X);
-  uint32_t *flg = (uint32_t *)(wbase + p.lay.A);
-  uint32_t *bitmap = (uint32_t *)(wbase + p.lay.F);
-  uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
-  uint32_t *cand_lds = (uint32_t *)(wbase + p.lay.sf);  // 2 x 64 candidates
-  uint2 *seqtab = (uint2 *)(wbase + p.lay.picked);      // (goff, length) of the first 64 sequences
-  const bool small_ref = p.n_seq <= (uint32_t)kWave;
-  seqtab[ln] = ln < p.n_seq ? make_uint2(p.goff[ln], p.seq_len[ln]) : make_uint2(0xFFFFFFFFu, 0u);
-  for (uint32_t i = ln; i < dense_bitmap_words(R); i += kWave) bitmap[i] = 0;
-  wave_sync_lds();
-  if (ln == 0) bitmap[0] = 1u, bitmap[(dense_slots(R) + 1u) >> 4] = 1u << (((dense_slots(R) + 1u) << 1) & 31u);  // padding pairs: see dense_join
-  unsigned long long pre_sum = 0, cand_sum = 0;
-  SlotChunk chunk, qchunk;
-
-  auto queue_slow = [&](uint32_t read) {
-    if (qchunk.left == 0) {
-      uint32_t base = 0;
-      if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
-      qchunk.next = bcast0(base);
-      qchunk.left = kQueueChunk;
-    }
-    if (qchunk.next < p.slow_cap) {
-      if (ln == 0) p.slow_queue[qchunk.next] = read;
-    } else if (ln == 0) {
-      atomicOr(&p.ctr[1], kFlagQueueOverflow);
-    }
-    ++qchunk.next, --qchunk.left;
-  };
-
-  for (;;) {
-    uint32_t pull = 0;
-    if (ln == 0) pull = atomicAdd(p.work_cursor, kReadBlock);
-    pull = bcast0(pull);
-    if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
-    const uint32_t r0 = p.read_begin + pull;
-    const uint32_t n_blk = p.n_reads - r0 < kReadBlock ? p.n_reads - r0 : kReadBlock;
-    if (ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
-    // lane i: header of read r0 + i (status | length << 8, pre-filter count)
-    uint2 hdr = make_uint2(kSelSlow, 0u);
-    if (ln < n_blk) hdr = p.sel_hdr[r0 + ln];
-    uint2 sel_next = make_uint2(0u, 0u);
-    if (ln < 2u * kSeeds) sel_next = p.sel[(size_t)r0 * (2u * kSeeds) + ln];
-    for (uint32_t rb = 0; rb < n_blk; ++rb) {
-      const uint32_t read = r0 + rb;
-      const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hdr.x, (int)rb);
-      const uint32_t status = h0 & 3u, L = h0 >> 8;
-      const uint2 sel = sel_next;
-      if (rb + 1u < n_blk && ln < 2u * kSeeds) sel_next = p.sel[(size_t)(read + 1u) * (2u * kSeeds) + ln];
-      if (status == kSelSlow) continue;  // queued by seed_select_kernel
-      if (status == kSelNone) {
-        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);
-        continue;
-      }
-      const uint32_t s_lo = sel.x, s_start = sel.y & 0xFFFFu, s_freq = sel.y >> 16;
-      // ---- lists -> candidates, one strand after the other ----
-      uint32_t kept0 = 0, kept1 = 0;
-      if (!dense_join<R>(p, s_start, s_lo, s_freq, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
-        queue_slow(read);
-        continue;
-      }
-      pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, (int)rb);
-      // ---- back to (sequence, position), remove_out_ranged_candidates (src/filter.c:133-144), hand-over ----
-#pragma unroll 1
-      for (uint32_t strand = 0; strand < 2u; ++strand) {
-        const uint32_t kept = strand ? kept1 : kept0;
-        uint64_t out = 0;
-        bool ok = false;
-        if (kept == 0) {
-          if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(0u, 0u);
-          continue;
-        }
-        const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];  // written by this same lane
-        uint32_t sq = 0, pos = 0, slen = 0;
-        if (small_ref) {
-          // at most 64 sequences: their coordinates sit in the lanes; one ballot per candidate finds its sequence
-          const uint2 tab = seqtab[ln];
-          for (uint32_t i = 0; i < kept; ++i) {
-            const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
-            const uint32_t s_i = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tab.x <= vi)) - 1u;  // (vi >= goff[0] always)
-            const uint32_t g_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.x, (int)s_i);
-            const uint32_t l_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.y, (int)s_i);
-            if (ln == i) sq = s_i, pos = vi - g_i, slen = l_i;
-          }
-        } else if (ln < kept) {
-          sq = p.blkseq[v >> kDenseBlkShift];
-          while (sq + 1u < p.n_seq && p.goff[sq + 1u] <= v) ++sq;
-          pos = v - p.goff[sq];
-          slen = p.seq_len[sq];
-        }
-        if (ln < kept) {
-          ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
-          out = (((uint64_t)sq << 32) | pos) - (uint64_t)p.e;
-        }
-        const uint64_t mo = __ballot(ok);
-        const uint32_t n_out = (uint32_t)__popcll(mo);
-        uint32_t base = 0;
-        if (n_out > 0) {
-          if (n_out <= chunk.left) {
-            base = chunk.next;
-            chunk.next += n_out, chunk.left -= n_out;
-          } else {
-            pad_chunk(p, chunk);
-            if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
-            base = bcast0(base);
-            chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
-          }
-          if ((unsigned long long)base + n_out > p.cand_cap) {
-            if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
-          } else if (ok) {
-            const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
-            p.cand[at] = out;
-            p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
-          }
-        }
-        if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
-        cand_sum += n_out;
-      }
-    }
-    wave_sync_lds();
-    const uint2 entry = blk_entries[ln];
-    wave_sync_lds();
-    if (ln < 2u * kReadBlock && r0 + ln / 2u < p.n_reads && entry.x != kBlkSkip) {
-      __builtin_nontemporal_store(entry.x, &p.cand_begin[r0 * 2u + ln]);
-      __builtin_nontemporal_store(entry.y, &p.cand_count[r0 * 2u + ln]);
-    }
-  }
-  pad_chunk(p, chunk);
-  for (uint32_t i = ln; i < qchunk.left; i += kWave)
-    if (qchunk.next + i < p.slow_cap) p.slow_queue[qchunk.next + i] = kInvalidRead;
-  if (ln == 0) {
-    if (pre_sum) atomicAdd(&p.stats[0], pre_sum);
-    if (cand_sum) atomicAdd(&p.stats[1], cand_sum);
-  }
-}
-
 }  // namespace femk

@@ -1,0 +1,562 @@
+// fem_seed_join.hip.h — seed_join_kernel<R>: merge_candidate_locations .. remove_out_ranged_candidates
+// (reference src/filter.c:45-144,205-222) for the reads seed_select_kernel (fem_seed_select.hip.h) prepared, on dense
+// indexes (k = 12, step = 3).  One wave per read, reads pulled in blocks of 16.  A read's 6 R selected seeds come in
+// with ONE coalesced load (lane (strand * 3 + group) * R + run: list base, start | frequency << 16), requested while
+// the previous read is joined.
+//
+// The join works on the 32-bit global coordinates of fem_seed_dense.hip.h (occ32, goff, the remapped near-start
+// entries) and on the same idea as round 2's dense_join — a value survives merge + additional_qgram_filter iff a+1
+// values of the unit's multiset lie in [v, v+e], so a bitmap over slots of 8 positions finds the few values that can
+// have a partner and the filter is evaluated exactly on those — but is built to retire as few instructions as that
+// idea allows (the round-2 join ran the vector, scalar and LDS ports at 73 / 74 / 58 % at once):
+//   * ONE bit per slot, 32 Ki slots (64 Ki at R >= 7): slot and bit of a value are two shifts, and the three slots a
+//     within-e partner can sit in come out of one two-word read + v_alignbit.  A value is flagged when a neighbouring
+//     slot is present.  A slot hit TWICE is seen by its second value only (the returning atomic); that lane then sets
+//     both neighbours' bits, which flags the slot's first value like any other neighbour would (and, harmlessly,
+//     whatever sits two slots away).  The word behind the table is all ones: values in the first or last slot are
+//     always flagged instead of wrapping.
+//   * lists are read with CLAMPED lane offsets (lanes behind a list's end re-read its last entry: no exec masking of the
+//     loads, no extra traffic); a run of up to 128 entries is two such chunks, the second one only where some list of
+//     the unit is that long;
+//   * nothing in a chunk's insert / window / flag steps branches: a lane without an entry holds a sentinel, ORs a zero
+//     into a word of its own and is masked out of the flagged set, so all of a unit's atomics issue back to back, then
+//     all of its window reads;
+//   * the bitmap is cleared by four 16-byte stores per lane and unit instead of two random word stores per entry.
+#pragma once
+#include "fem_seed_dense.hip.h"
+
+namespace femk {
+
+constexpr uint32_t join_slots(int R) { return R >= 7 ? 65536u : 32768u; }
+constexpr uint32_t join_bitmap_words(int R) { return join_slots(R) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
+
+__device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
+  (void)__hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Both strands of one read.  Lane strand * 3R + g * R + t holds run t of phase group g of that strand: (start,
+// lookup[h], frequency), runs in the order of the stable frequency sort (src/filter.c:204); strands that failed the
+// gates have frequency 0 everywhere.  The six (strand, group) units run one after the other in ONE rolled loop, and
+// the first chunk of every run of unit u + 1 is requested before unit u is worked on.  Leaves each strand's candidates
+// (global coordinates, ascending, before the range clip) in cand_lds[strand * 64 + lane] and their counts in
+// kept0/kept1; false = hand the read to the generic kernel.  `bitmap` is all-zero (but for its guard word) on entry
+// and on exit.
+// ---------------------------------------------------------------------------------------------------------
+template <int R>
+__device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
+                          uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */,
+                          uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1) {
+  const uint32_t ln = lane_id();
+  constexpr uint32_t kSlots = join_slots(R);
+  constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : 15u;
+  constexpr uint32_t kWordBits = kSlotBits - 5u;     // words of 32 slots
+  constexpr uint32_t kWords = kSlots / 32u;          // the guard word sits at bitmap[kWords]
+  constexpr uint32_t kPeriodBits = kSlotBits + 3u;   // values this many bits apart share a slot
+  constexpr uint32_t kFlagCap = dense_flag_cap(R);   // flagged values one unit may have (one or two per lane)
+  constexpr bool kSecondProbe = R >= FEM_DENSE_PROBE_R;
+  constexpr uint32_t kProbeMin = FEM_DENSE_PROBE_MIN;
+  constexpr uint32_t kFlgStride = kFlagCap + 1u;     // the entry behind a group's array takes the overflow writes
+  constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
+  const uint32_t e = (uint32_t)p.e;
+  const uint32_t *occ32 = p.occ32;
+  kept0 = 0, kept1 = 0;
+  if (__builtin_amdgcn_ballot_w64(s_freq > kDenseMaxList)) return false;  // a list beyond two chunks: generic kernel
+  // per seed, in its lane: (start | frequency << 16 | byte offset of the first chunk's last entry << 24) and the list's
+  // address; a run then costs three readlanes and no scalar arithmetic to speak of
+  const uint32_t f_c = s_freq < (uint32_t)kWave ? s_freq : (uint32_t)kWave;
+  const uint32_t s_sf = s_start | (s_freq << 16) | ((f_c - (s_freq != 0u ? 1u : 0u)) << 26);  // (.. * 4) << 24; start < 1024, frequency <= 128
+  const uint64_t s_addr = (uint64_t)(uintptr_t)(occ32 + s_lo);
+  const uint32_t s_alo = (uint32_t)s_addr, s_ahi = (uint32_t)(s_addr >> 32);
+  const uint32_t lane4 = ln * 4u;
+  uint32_t nxt[R], nxt_sf[R];  // first chunk of every run of the next unit (raw table entries), its packed scalars
+  auto run_base = [&](uint32_t lane) -> const uint8_t * {
+    const uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s_alo, (int)lane) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s_ahi, (int)lane) << 32);
+    return (const uint8_t *)(uintptr_t)a;
+  };
+  auto prefetch = [&](uint32_t u) {
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      nxt_sf[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t));
+      const uint32_t last4 = nxt_sf[t] >> 24;
+      nxt[t] = *(const uint32_t *)(run_base(u * R + t) + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
+    }
+  };
+  // ---- the steps of the join for one chunk.  A lane without an entry holds kDenseSent (>= kDenseVLimit); nothing here
+  //      branches on that: such a lane ORs a zero into a word of its own (lane index: no bank conflict), reads some
+  //      window and is masked out of the flagged set ----
+  auto insert = [&](uint32_t v) -> uint32_t {  // -> own bit if the slot already held a value, else 0
+    const bool valid = v < kDenseVLimit;
+    const uint32_t bit = valid ? 1u << ((v >> 3) & 31u) : 0u;
+    const uint32_t widx = valid ? __builtin_amdgcn_ubfe(v, 8u, kWordBits) : ln;
+    return lds_or_rtn(bitmap + widx, bit) & bit;
+  };
+  auto mark = [&](uint32_t v, uint32_t hit) {  // second value of a slot: both neighbours "present"
+    if (hit) {
+      const uint32_t qm = (v >> 3) - 1u, qp = (v >> 3) + 1u;
+      lds_or(bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits), 1u << (qm & 31u));
+      lds_or(bitmap + __builtin_amdgcn_ubfe(qp, 5u, kWordBits), 1u << (qp & 31u));
+    }
+  };
+  auto window = [&](uint32_t v) -> uint32_t {  // bit 0: slot - 1 present, bit 1: own slot, bit 2: slot + 1
+    const uint32_t qm = (v >> 3) - 1u;
+    const uint32_t *w = bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits);
+    return __builtin_amdgcn_alignbit(w[1], w[0], qm & 31u);
+  };
+  prefetch(0);
+  uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
+  uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
+  uint32_t nf0 = 0, nf1 = 0, nf2 = 0;
+  bool any_hi = false;  // a survivor sits in the second flagged value of some lane
+#pragma unroll 1
+  for (uint32_t u = 0; u < kUnits; ++u) {
+    const uint32_t g = u >= (uint32_t)kStep ? u - (uint32_t)kStep : u;
+    // ---- the unit's runs as wave-uniform scalars ----
+    uint32_t f[R], st[R];
+    uint32_t n_g = 0, f_max = 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const uint32_t sf = nxt_sf[t];
+      f[t] = (sf >> 16) & 0xFFu, st[t] = sf & 0xFFFFu;
+      n_g += f[t];
+      f_max = f[t] > f_max ? f[t] : f_max;
+    }
+    uint32_t val[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) val[t] = nxt[t];
+    if (u + 1u < kUnits) prefetch(u + 1u);
+    // fewer than a+1 occurrences: nothing can pass the filter; no list but the last seed's: it is merged only while
+    // the list has elements (src/filter.c:85)
+    const bool skip = n_g <= (uint32_t)p.a || n_g == f[R - 1];
+    uint32_t n_flag = 0;
+    uint32_t *flg_g = flg + g * kFlgStride;
+    if (!skip) {
+      const bool long_lists = f_max > (uint32_t)kWave;  // some list has a second chunk (entries 64..127)
+      uint32_t hv[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) hv[t] = kDenseSent;
+      if (long_lists) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          const uint32_t last4 = f[t] > (uint32_t)kWave ? (f[t] - 1u) * 4u : 0u;
+          const uint32_t at4 = lane4 + 4u * (uint32_t)kWave;
+          hv[t] = *(const uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
+        }
+      }
+      bool remap;
+      {
+        uint32_t raw_max = val[0];  // (a lane behind a list's end holds the list's last entry: one compare for the unit)
+#pragma unroll
+        for (int t = 1; t < R; ++t) raw_max = val[t] > raw_max ? val[t] : raw_max;
+        if (long_lists) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) raw_max = hv[t] > raw_max ? hv[t] : raw_max;
+        }
+        remap = __builtin_amdgcn_ballot_w64(raw_max >= kDenseRemap) != 0;
+      }
+      uint32_t max_u = 0;
+      bool any_u = true;
+      if (__builtin_expect(remap || long_lists, 0)) {
+        // entries within kDenseNear of a sequence start are resolved exactly (pos >= start or dropped); then, as with
+        // long lists, the maximum of U comes from a wave reduction (a dropped entry may sit at the end of a run)
+        uint32_t mx = 0, have_u = 0;
+        auto settle = [&](uint32_t &v, bool have, uint32_t start) {
+          const uint32_t raw = v;
+          v = kDenseSent;
+          if (have) {
+            v = raw - start;
+            if (raw >= kDenseRemap) {
+              const uint32_t sq = (raw - kDenseRemap) >> 10, pos = raw & (kDenseNear - 1u);
+              v = pos >= start ? p.goff[sq] + pos - start : kDenseSent;
+            }
+          }
+        };
+#pragma unroll 1
+        for (int t = 0; t < R; ++t) {
+          // (rolled, the arrays through LDS-free selects: this path is rare and must stay small)
+          uint32_t a_ = 0, b_ = 0;
+#pragma unroll
+          for (int q = 0; q < R; ++q) a_ = q == t ? val[q] : a_, b_ = q == t ? hv[q] : b_;
+          uint32_t f_t = 0, st_t = 0;
+#pragma unroll
+          for (int q = 0; q < R; ++q) f_t = q == t ? f[q] : f_t, st_t = q == t ? st[q] : st_t;
+          settle(a_, ln < f_t, st_t);
+          settle(b_, long_lists && ln + (uint32_t)kWave < f_t, st_t);
+          if (t < R - 1) {
+            if (a_ < kDenseVLimit) mx = a_ > mx ? a_ : mx, have_u = 1;
+            if (b_ < kDenseVLimit) mx = b_ > mx ? b_ : mx, have_u = 1;
+          }
+#pragma unroll
+          for (int q = 0; q < R; ++q) val[q] = q == t ? a_ : val[q], hv[q] = q == t ? b_ : hv[q];
+        }
+        any_u = __builtin_amdgcn_ballot_w64(have_u != 0) != 0;
+        max_u = wave_max_u32(mx);
+      } else {
+        // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
+#pragma unroll
+        for (int t = 0; t < R; ++t) val[t] = ln < f[t] ? val[t] - st[t] : kDenseSent;
+#pragma unroll
+        for (int t = 0; t < R - 1; ++t) {
+          const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
+          max_u = f[t] && lastv > max_u ? lastv : max_u;
+        }
+      }
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 1
+      if (val[0] + val[R - 1] == 0x12345u) n_flag = 1;  // (keeps the loads alive)
+      any_u = false;
+#endif
+      if (any_u) {
+        // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
+        val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
+        if (long_lists) hv[R - 1] = hv[R - 1] <= max_u ? hv[R - 1] : kDenseSent;
+        // ---- insert: all of the unit's atomics back to back ----
+        uint32_t hit[R], hhit[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) hit[t] = insert(val[t]), hhit[t] = 0;
+        if (long_lists) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) hhit[t] = insert(hv[t]);
+        }
+        // a slot that took a second value (every true hit does): chunk by chunk, only where some lane saw one
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          if (__builtin_amdgcn_ballot_w64(hit[t] != 0u)) mark(val[t], hit[t]);
+        }
+        if (long_lists) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) {
+            if (__builtin_amdgcn_ballot_w64(hhit[t] != 0u)) mark(hv[t], hhit[t]);
+          }
+        }
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 2
+        {
+          uint32_t hh = 0;
+          for (int t = 0; t < R; ++t) hh |= hit[t];
+          if (hh == 0x12345u) n_flag = 1;
+          continue;
+        }
+#endif
+        wave_sync_lds();
+        // ---- flag: a neighbouring slot is present.  All window reads first, then the flagged values are compacted
+        //      into the group's array ----
+        uint32_t x[R], hx[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = window(val[t]), hx[t] = 0;
+        if (long_lists) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) hx[t] = window(hv[t]);
+        }
+        auto flag_chunk = [&](uint32_t v, uint32_t xw) {
+          const bool near = (xw & 5u) != 0u && v < kDenseVLimit;
+          const uint64_t m = __builtin_amdgcn_ballot_w64(near);
+          uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_flag));
+          pos = pos < kFlagCap ? pos : kFlagCap;
+          if (near) flg_g[pos] = v;
+          n_flag += (uint32_t)__popcll(m);
+        };
+#pragma unroll
+        for (int t = 0; t < R; ++t) flag_chunk(val[t], x[t]);
+        if (long_lists) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) flag_chunk(hv[t], hx[t]);
+        }
+        wave_sync_lds();
+        {  // leave the bitmap clean: every lane clears its 16-byte pieces (the guard word sits behind them)
+          uint4 *b4 = (uint4 *)bitmap;
+#pragma unroll
+          for (uint32_t k = 0; k < kWords / 4u / (uint32_t)kWave; ++k) b4[k * (uint32_t)kWave + ln] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        wave_sync_lds();
+        if (n_flag > kFlagCap) return false;
+      }
+    }
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 3
+    if (n_flag == 0x12345u) cmin = 0;
+    continue;
+#endif
+    if (kSecondProbe && n_flag > kProbeMin) {
+      // ---- second probe: most of the flagged values are chance flags — values whose slot or a neighbouring one was
+      //      also hit by a value 2^kPeriodBits k positions away.  The flagged values alone go through the (clean again)
+      //      bitmap once more, with the slot shifted by a multiple of the value's bits above the period: a true pair
+      //      (within e) lands in the same / adjacent slots again, chance partners scatter.  Values within e of a period
+      //      boundary are kept unseen (their partner may sit under another shift).  What survives is a superset of every
+      //      within-e pair, so the exact filter below gives the same result on far fewer values. ----
+      const bool have0 = ln < n_flag, have1 = ln + (uint32_t)kWave < n_flag;
+      const uint32_t v0 = have0 ? flg_g[ln] : 0u, v1 = have1 ? flg_g[ln + (uint32_t)kWave] : 0u;
+      auto key2 = [&](uint32_t v) -> uint32_t {
+        const uint32_t slot2 = (__builtin_amdgcn_ubfe(v, 3u, kSlotBits) + (v >> kPeriodBits) * 0x9E5u) & (kSlots - 1u);
+        return (slot2 << 3) | (v & 7u);
+      };
+      auto edge = [&](uint32_t v) -> bool {
+        const uint32_t lo = v & ((1u << kPeriodBits) - 1u);
+        return lo < e || lo + e >= (1u << kPeriodBits);
+      };
+      auto wipe = [&](uint32_t k) {  // the window's two words hold every bit this value set (its own and its marks)
+        const uint32_t qm = (k >> 3) - 1u;
+        uint32_t *w = bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits);
+        w[0] = 0u, w[1] = 0u;
+      };
+      const uint32_t k0 = key2(v0), k1 = key2(v1);
+      const uint32_t h0 = insert(have0 ? k0 : kDenseSent), h1 = insert(have1 ? k1 : kDenseSent);
+      if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u)) mark(k0, h0), mark(k1, h1);
+      wave_sync_lds();
+      const bool keep0 = have0 && (edge(v0) || (window(k0) & 5u) != 0u);
+      const bool keep1 = have1 && (edge(v1) || (window(k1) & 5u) != 0u);
+      wave_sync_lds();
+      if (have0) wipe(k0);
+      if (have1) wipe(k1);
+      wave_sync_lds();
+      if (ln == 0) bitmap[kWords] = 0xFFFFFFFFu;  // (a window at the table's end reaches the guard word)
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(keep0), m1 = __builtin_amdgcn_ballot_w64(keep1);
+      const uint32_t c0 = (uint32_t)__popcll(m0);
+      if (keep0) flg_g[__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = v0;
+      if (keep1) flg_g[__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c0))] = v1;
+      n_flag = c0 + (uint32_t)__popcll(m1);
+      wave_sync_lds();
+    }
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 4
+    if (n_flag == 0x12345u) cmin = 0;
+    continue;
+#endif
+    if (n_flag > (uint32_t)p.a) {
+      // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
+      const bool have = ln < n_flag;
+      const uint32_t fv = have ? flg_g[ln] : 0u;
+      const uint32_t n_lo = n_flag < (uint32_t)kWave ? n_flag : (uint32_t)kWave;
+      uint32_t cnt = 0;
+      bool pass_hi = false;
+      uint32_t fv_hi = 0;
+      if (kFlagCap > (uint32_t)kWave && n_flag > (uint32_t)kWave) {
+        // more than one flagged value per lane (long lists): the second goes through the same counts
+        const bool have_hi = ln + (uint32_t)kWave < n_flag;
+        fv_hi = have_hi ? flg_g[ln + (uint32_t)kWave] : 0u;
+        uint32_t cnt_hi = 0;
+        for (uint32_t j = 0; j < n_lo; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+        }
+        for (uint32_t j = (uint32_t)kWave; j < n_flag; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv_hi, (int)(j - (uint32_t)kWave));
+          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+        }
+        pass_hi = have_hi && cnt_hi > (uint32_t)p.a;
+      } else {
+        for (uint32_t j = 0; j < n_lo; ++j) {
+          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+          cnt += (uint32_t)(x - fv <= e);
+        }
+      }
+      const bool pass = have && cnt > (uint32_t)p.a;
+      const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+      if (__builtin_amdgcn_ballot_w64(pass_hi)) {
+        // survivors among the second values: they only take part in the one-candidate shortcut below
+        any_hi = true;
+        cmin = pass_hi && fv_hi < cmin ? fv_hi : cmin;
+        cmax = pass_hi && fv_hi > cmax ? fv_hi : cmax;
+      }
+      if (pm != 0) {
+        if (g == 0) pm0 = pm, nf0 = n_flag;
+        else if (g == 1) pm1 = pm, nf1 = n_flag;
+        else pm2 = pm, nf2 = n_flag;
+        cmin = pass && fv < cmin ? fv : cmin;
+        cmax = pass && fv > cmax ? fv : cmax;
+      }
+    }
+    if (g != (uint32_t)kStep - 1u) continue;
+    // ---- the strand's three groups are done: its candidates ----
+    uint32_t kept = 0, cv = 0;
+    if ((pm0 | pm1 | pm2) != 0 || any_hi) {
+      const uint32_t lo_all = wave_min_u32(cmin), hi_all = wave_max_u32(cmax);
+      if (hi_all - lo_all <= e) {  // every survivor within e of the smallest: the greedy merges keep exactly that one
+        cv = ln == 0 ? lo_all : 0u;
+        kept = 1;
+      } else if (any_hi) {
+        return false;  // (the general path below takes one survivor per lane)
+      } else {
+        // general case: per group, survivors sorted into lanes and merged greedily (src/filter.c:45-78)
+#pragma unroll 1
+        for (uint32_t gg = 0; gg < (uint32_t)kStep; ++gg) {
+          const uint64_t pm = gg == 0 ? pm0 : gg == 1 ? pm1 : pm2;
+          const uint32_t nfl = gg == 0 ? nf0 : gg == 1 ? nf1 : nf2;
+          if (pm == 0) continue;
+          const uint32_t nF = (uint32_t)__popcll(pm);
+          const bool mine = (pm >> ln) & 1ull;
+          const uint32_t fv = ln < nfl ? flg[gg * kFlgStride + ln] : 0u;
+          uint32_t rank = 0;
+          for (uint64_t m = pm; m;) {  // rank among the survivors (ties by lane)
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, j);
+            rank += (uint32_t)(x < fv || (x == fv && (uint32_t)j < ln));
+          }
+          wave_sync_lds();
+          if (mine) scatter[rank] = fv;
+          wave_sync_lds();
+          const uint32_t fs = ln < nF ? scatter[ln] : 0u;
+          kept = dense_merge_group(cv, kept, fs, nF, e);
+          if (kept == 0xFFFFFFFFu) return false;
+        }
+      }
+    }
+    cand_lds[(u >= (uint32_t)kStep ? (uint32_t)kWave : 0u) + ln] = cv;
+    if (u >= (uint32_t)kStep) kept1 = kept; else kept0 = kept;
+    cmin = 0xFFFFFFFFu, cmax = 0u, any_hi = false;
+    pm0 = pm1 = pm2 = 0, nf0 = nf1 = nf2 = 0;
+  }
+  return true;
+}
+
+#ifndef FEM_JOIN_WAVES_LO
+#define FEM_JOIN_WAVES_LO 7
+#endif
+#ifndef FEM_JOIN_WAVES_HI
+#define FEM_JOIN_WAVES_HI 4
+#endif
+constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_WAVES_HI; }
+
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(join_waves(R), 8))) seed_join_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
+  static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
+  const uint32_t ln = lane_id();
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t *wbase = smem + (size_t)wave_in_block * p.lay.wave_bytes;
+  uint32_t *scatter = (uint32_t *)(wbase + p.lay.X);
+  uint32_t *flg = (uint32_t *)(wbase + p.lay.A);
+  uint32_t *bitmap = (uint32_t *)(wbase + p.lay.F);
+  uint2 *blk_entries = (uint2 *)(wbase + p.lay.B);
+  uint32_t *cand_lds = (uint32_t *)(wbase + p.lay.sf);  // 2 x 64 candidates
+  uint2 *seqtab = (uint2 *)(smem + p.lay.picked);       // (goff, length) of the first 64 sequences: one table per block
+  const bool small_ref = p.n_seq <= (uint32_t)kWave;
+  if (wave_in_block == 0) seqtab[ln] = ln < p.n_seq ? make_uint2(p.goff[ln], p.seq_len[ln]) : make_uint2(0xFFFFFFFFu, 0u);
+  __syncthreads();
+  for (uint32_t i = ln; i < join_bitmap_words(R); i += kWave) bitmap[i] = i < join_slots(R) / 32u ? 0u : 0xFFFFFFFFu;  // (guard word)
+  wave_sync_lds();
+  unsigned long long pre_sum = 0, cand_sum = 0;
+  SlotChunk chunk, qchunk;
+
+  auto queue_slow = [&](uint32_t read) {
+    if (qchunk.left == 0) {
+      uint32_t base = 0;
+      if (ln == 0) base = atomicAdd(&p.ctr[2], kQueueChunk);
+      qchunk.next = bcast0(base);
+      qchunk.left = kQueueChunk;
+    }
+    if (qchunk.next < p.slow_cap) {
+      if (ln == 0) p.slow_queue[qchunk.next] = read;
+    } else if (ln == 0) {
+      atomicOr(&p.ctr[1], kFlagQueueOverflow);
+    }
+    ++qchunk.next, --qchunk.left;
+  };
+
+  for (;;) {
+    uint32_t pull = 0;
+    if (ln == 0) pull = atomicAdd(p.work_cursor, kReadBlock);
+    pull = bcast0(pull);
+    if ((uint64_t)p.read_begin + pull >= p.n_reads) break;
+    const uint32_t r0 = p.read_begin + pull;
+    const uint32_t n_blk = p.n_reads - r0 < kReadBlock ? p.n_reads - r0 : kReadBlock;
+    if (ln < 2u * kReadBlock) blk_entries[ln] = make_uint2(kBlkSkip, 0u);
+    // lane i: header of read r0 + i (status | length << 8, pre-filter count)
+    uint2 hdr = make_uint2(kSelSlow, 0u);
+    if (ln < n_blk) hdr = p.sel_hdr[r0 + ln];
+    uint2 sel_next = make_uint2(0u, 0u);
+    if (ln < 2u * kSeeds) sel_next = p.sel[(size_t)r0 * (2u * kSeeds) + ln];
+    for (uint32_t rb = 0; rb < n_blk; ++rb) {
+      const uint32_t read = r0 + rb;
+      const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hdr.x, (int)rb);
+      const uint32_t status = h0 & 3u, L = h0 >> 8;
+      const uint2 sel = sel_next;
+      if (rb + 1u < n_blk && ln < 2u * kSeeds) sel_next = p.sel[(size_t)(read + 1u) * (2u * kSeeds) + ln];
+      if (status == kSelSlow) continue;  // queued by seed_select_kernel
+      if (status == kSelNone) {
+        if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);
+        continue;
+      }
+      const uint32_t s_lo = sel.x, s_start = sel.y & 0xFFFFu, s_freq = sel.y >> 16;
+      // ---- lists -> candidates, one strand after the other ----
+      uint32_t kept0 = 0, kept1 = 0;
+      if (!join_read<R>(p, s_start, s_lo, s_freq, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
+        queue_slow(read);
+        continue;
+      }
+      pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, (int)rb);
+      // ---- back to (sequence, position), remove_out_ranged_candidates (src/filter.c:133-144), hand-over ----
+#pragma unroll 1
+      for (uint32_t strand = 0; strand < 2u; ++strand) {
+        const uint32_t kept = strand ? kept1 : kept0;
+        uint64_t out = 0;
+        bool ok = false;
+        if (kept == 0) {
+          if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(0u, 0u);
+          continue;
+        }
+        const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];  // written by this same lane
+        uint32_t sq = 0, pos = 0, slen = 0;
+        if (small_ref) {
+          // at most 64 sequences: their coordinates sit in the lanes; one ballot per candidate finds its sequence
+          const uint2 tab = seqtab[ln];
+          for (uint32_t i = 0; i < kept; ++i) {
+            const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
+            const uint32_t s_i = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tab.x <= vi)) - 1u;  // (vi >= goff[0] always)
+            const uint32_t g_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.x, (int)s_i);
+            const uint32_t l_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.y, (int)s_i);
+            if (ln == i) sq = s_i, pos = vi - g_i, slen = l_i;
+          }
+        } else if (ln < kept) {
+          sq = p.blkseq[v >> kDenseBlkShift];
+          while (sq + 1u < p.n_seq && p.goff[sq + 1u] <= v) ++sq;
+          pos = v - p.goff[sq];
+          slen = p.seq_len[sq];
+        }
+        if (ln < kept) {
+          ok = pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+          out = (((uint64_t)sq << 32) | pos) - (uint64_t)p.e;
+        }
+        const uint64_t mo = __ballot(ok);
+        const uint32_t n_out = (uint32_t)__popcll(mo);
+        uint32_t base = 0;
+        if (n_out > 0) {
+          if (n_out <= chunk.left) {
+            base = chunk.next;
+            chunk.next += n_out, chunk.left -= n_out;
+          } else {
+            pad_chunk(p, chunk);
+            if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+            base = bcast0(base);
+            chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+          }
+          if ((unsigned long long)base + n_out > p.cand_cap) {
+            if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+          } else if (ok) {
+            const uint32_t rank = (uint32_t)__popcll(mo & ((1ull << ln) - 1ull)), at = base + rank;
+            p.cand[at] = out;
+            p.cand_meta[at] = (read * 2u + strand) | (rank < (n_out & ~7u) ? kMeta16 : 0u);
+          }
+        }
+        if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
+        cand_sum += n_out;
+      }
+    }
+    wave_sync_lds();
+    const uint2 entry = blk_entries[ln];
+    wave_sync_lds();
+    if (ln < 2u * kReadBlock && r0 + ln / 2u < p.n_reads && entry.x != kBlkSkip) {
+      __builtin_nontemporal_store(entry.x, &p.cand_begin[r0 * 2u + ln]);
+      __builtin_nontemporal_store(entry.y, &p.cand_count[r0 * 2u + ln]);
+    }
+  }
+  pad_chunk(p, chunk);
+  for (uint32_t i = ln; i < qchunk.left; i += kWave)
+    if (qchunk.next + i < p.slow_cap) p.slow_queue[qchunk.next + i] = kInvalidRead;
+  if (ln == 0) {
+    if (pre_sum) atomicAdd(&p.stats[0], pre_sum);
+    if (cand_sum) atomicAdd(&p.stats[1], cand_sum);
+  }
+}
+
+
+}  // namespace femk

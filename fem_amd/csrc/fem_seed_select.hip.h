@@ -113,7 +113,7 @@ __device__ __forceinline__ void select_dp(const uint8_t *F, uint32_t ncols, uint
 }
 
 #ifndef FEM_SELECT_WAVES
-#define FEM_SELECT_WAVES 4
+#define FEM_SELECT_WAVES 6
 #endif
 #ifndef FEM_SELECT_UNROLL
 #define FEM_SELECT_UNROLL 4
@@ -238,39 +238,45 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         const uint32_t magic = 0xFFFFFFFFu / SP + 1u;  // w / SP = umulhi(w, magic) for w * SP < 2^32
         const uint32_t total = cnt * SP;
         constexpr int U = FEM_SELECT_UNROLL;
+        // U rounds of loads are issued before the first one is used.  The kernel is bound by the rate of table sectors
+        // the fabric delivers (57 G/s) whatever its occupancy — one block per CU takes the 3.3 ms per 2.5 M reads of C3
+        // that five take, U = 4 what U = 24 takes — and shares the chip with seed_join_kernel: it is built to be small
+        // (80 registers, 3 KB of LDS per wave).  Nothing but the table word is kept across the two halves: place, hash
+        // and gates are worked out again.
+        auto place = [&](uint32_t w, uint32_t &i_c, uint32_t &j, uint32_t &S) -> bool {
+          const uint32_t i = __umulhi(w, magic);
+          j = w - i * SP;
+          i_c = i < cnt ? i : 0u;
+          const uint32_t fl = r_flag[i_c];
+          S = r_len[i_c] - (uint32_t)(kK - 1);
+          return w < total && (fl & kShape) && !(fl & kSlow) && j < S;
+        };
         for (uint32_t w0 = 0; w0 < total; w0 += (uint32_t)(U * kWave)) {
-          uint32_t d[U], hfv[U], nmv[U], ii[U], jj[U], Sv[U];
-          bool act[U];
+          uint32_t d[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const uint32_t w = w0 + (uint32_t)(u * kWave) + ln;
-            const uint32_t i = __umulhi(w, magic), j = w - i * SP;
-            const uint32_t i_c = i < cnt ? i : 0u;
-            const uint32_t fl = r_flag[i_c], S = r_len[i_c] - (uint32_t)(kK - 1);
-            act[u] = w < total && (fl & kShape) && !(fl & kSlow) && j < S;
-            ii[u] = i_c, jj[u] = j, Sv[u] = S;
-            d[u] = 0, hfv[u] = 0, nmv[u] = 0;
-            if (act[u]) {
-              const uint32_t pos = r_base[i_c] + j;
-              const uint32_t hf = stream_window(fw, pos) >> 8;
-              hfv[u] = hf;
-              if (has_n) nmv[u] = stream_window(nw, pos) >> 8;
-              // even j: the seed's last eleven bases + its first base; odd j: its first eleven + its last
-              const uint32_t at = (j & 1u) ? hf : (((hf & (kX11 - 1u)) << 2) | (hf >> 22));
-              d[u] = p.freq11[at];
-            }
+            uint32_t i_c, j, S;
+            const bool act = place(w0 + (uint32_t)(u * kWave) + ln, i_c, j, S);
+            const uint32_t hf = stream_window(fw, act ? r_base[i_c] + j : 0u) >> 8;
+            // even j: the seed's last eleven bases + its first base; odd j: its first eleven + its last
+            const uint32_t at = (j & 1u) ? hf : (((hf & (kX11 - 1u)) << 2) | (hf >> 22));
+            d[u] = p.freq11[act ? at : 0u];
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            if (act[u]) {
-              const uint32_t j = jj[u], S = Sv[u], i = ii[u];
+            uint32_t i, j, S;
+            if (place(w0 + (uint32_t)(u * kWave) + ln, i, j, S)) {
               const uint32_t sh = (j & 1u) * 16u;
               const uint32_t f_fwd = (d[u] >> sh) & 255u;
               uint32_t f_rev = (d[u] >> (sh + 8u)) & 255u;
-              if (has_n && nmv[u] != 0u) {  // the reverse strand counts N as A after complementing: its own hash
-                const uint32_t hr = rc_hash(hfv[u], nmv[u]);
-                const uint32_t df = p.lookup[hr + 1u] - p.lookup[hr];
-                f_rev = df < 255u ? df : 255u;
+              if (has_n) {
+                const uint32_t pos = r_base[i] + j;
+                const uint32_t nm = stream_window(nw, pos) >> 8;
+                if (nm != 0u) {  // the reverse strand counts N as A after complementing: its own hash
+                  const uint32_t hr = rc_hash(stream_window(fw, pos) >> 8, nm);
+                  const uint32_t df = p.lookup[hr + 1u] - p.lookup[hr];
+                  f_rev = df < 255u ? df : 255u;
+                }
               }
               const uint32_t jr = S - 1u - j;
               const uint32_t gi = __umulhi(j, 0x55555556u), gr = __umulhi(jr, 0x55555556u);  // / 3
