@@ -457,14 +457,12 @@ int select_blocks_per_cu_r(int block, uint32_t lds) {
   int nb = 0;
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_select_kernel<R>, block, lds) == hipSuccess ? nb : 0;
 }
-template <int R>
-void launch_join_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL((femk::seed_join_kernel<R>), grid, block, lds, st, sp);
-}
-template <int R>
-int join_blocks_per_cu_r(int block, uint32_t lds) {
-  int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_join_kernel<R>, block, lds) == hipSuccess ? nb : 0;
+typedef void (*JoinKernel)(femk::SeedParams);
+JoinKernel join_kernel(int R) {
+  static const JoinKernel k[femk::kMaxR] = {femk::seed_join_kernel_r1, femk::seed_join_kernel_r2, femk::seed_join_kernel_r3, femk::seed_join_kernel_r4,
+                                            femk::seed_join_kernel_r5, femk::seed_join_kernel_r6, femk::seed_join_kernel_r7, femk::seed_join_kernel_r8,
+                                            femk::seed_join_kernel_r9, femk::seed_join_kernel_r10};
+  return k[std::min(std::max(R, 1), femk::kMaxR) - 1];
 }
 
 template <int R>
@@ -504,7 +502,7 @@ void launch_dense(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, co
 template <int R>
 uint32_t kernel_regs_r(bool join) {
   hipFuncAttributes a{};
-  const void *f = join ? (const void *)femk::seed_join_kernel<R> : (const void *)femk::seed_select_kernel<R>;
+  const void *f = join ? (const void *)join_kernel(R) : (const void *)femk::seed_select_kernel<R>;
   return hipFuncGetAttributes(&a, f) == hipSuccess && a.numRegs > 0 ? (uint32_t)a.numRegs : 128u;
 }
 // vector registers per lane of seed_join_kernel<R> / seed_select_kernel<R>
@@ -531,15 +529,10 @@ void launch_select(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, c
 }
 int join_blocks_per_cu(int R, int block, uint32_t lds) {
   int nb = 0;
-#define FEM_CALL(r) nb = join_blocks_per_cu_r<r>(block, lds)
-  FEM_DENSE_SWITCH(R, FEM_CALL)
-#undef FEM_CALL
-  return nb;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, join_kernel(R), block, lds) == hipSuccess ? nb : 0;
 }
 void launch_join(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-#define FEM_CALL(r) launch_join_r<r>(grid, block, lds, st, sp)
-  FEM_DENSE_SWITCH(R, FEM_CALL)
-#undef FEM_CALL
+  hipLaunchKernelGGL(join_kernel(R), grid, block, lds, st, sp);
 }
 
 template <int R>

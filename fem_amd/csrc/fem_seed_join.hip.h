@@ -27,7 +27,10 @@
 
 namespace femk {
 
-constexpr uint32_t join_slots(int R) { return R >= 7 ? 65536u : 32768u; }
+#ifndef FEM_JOIN_SLOTS_HI
+#define FEM_JOIN_SLOTS_HI 32768u
+#endif
+constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
 constexpr uint32_t join_bitmap_words(int R) { return join_slots(R) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
 
 __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
@@ -64,25 +67,31 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   if (__builtin_amdgcn_ballot_w64(s_freq > kDenseMaxList)) return false;  // a list beyond two chunks: generic kernel
   // per seed, in its lane: (start | frequency << 16 | byte offset of the first chunk's last entry << 24) and the list's
   // address; a run then costs three readlanes and no scalar arithmetic to speak of
-  const uint32_t f_c = s_freq < (uint32_t)kWave ? s_freq : (uint32_t)kWave;
-  const uint32_t s_sf = s_start | (s_freq << 16) | ((f_c - (s_freq != 0u ? 1u : 0u)) << 26);  // (.. * 4) << 24; start < 1024, frequency <= 128
+  auto pack_sf = [&](uint32_t start, uint32_t freq) -> uint32_t {
+    const uint32_t f_c = freq < (uint32_t)kWave ? freq : (uint32_t)kWave;
+    return start | (freq << 16) | ((f_c - (freq != 0u ? 1u : 0u)) << 26);  // (.. * 4) << 24; start < 1024, frequency <= 128
+  };
+  const uint32_t s_sf = pack_sf(s_start, s_freq);
   const uint64_t s_addr = (uint64_t)(uintptr_t)(occ32 + s_lo);
   const uint32_t s_alo = (uint32_t)s_addr, s_ahi = (uint32_t)(s_addr >> 32);
   const uint32_t lane4 = ln * 4u;
   uint32_t nxt[R], nxt_sf[R];  // first chunk of every run of the next unit (raw table entries), its packed scalars
-  auto run_base = [&](uint32_t lane) -> const uint8_t * {
-    const uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s_alo, (int)lane) |
-                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s_ahi, (int)lane) << 32);
-    return (const uint8_t *)(uintptr_t)a;
+  typedef const __attribute__((address_space(1))) uint8_t *GlobalBytes;  // (an address rebuilt from integers is "flat" to the compiler otherwise)
+  auto run_base_of = [&](uint32_t alo, uint32_t ahi, uint32_t lane) -> GlobalBytes {
+    const uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)alo, (int)lane) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ahi, (int)lane) << 32);
+    return (GlobalBytes)(uintptr_t)a;
   };
-  auto prefetch = [&](uint32_t u) {
+  auto run_base = [&](uint32_t lane) -> GlobalBytes { return run_base_of(s_alo, s_ahi, lane); };
+  auto prefetch_of = [&](uint32_t sf, uint32_t alo, uint32_t ahi, uint32_t u) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      nxt_sf[t] = (uint32_t)__builtin_amdgcn_readlane((int)s_sf, (int)(u * R + t));
+      nxt_sf[t] = (uint32_t)__builtin_amdgcn_readlane((int)sf, (int)(u * R + t));
       const uint32_t last4 = nxt_sf[t] >> 24;
-      nxt[t] = *(const uint32_t *)(run_base(u * R + t) + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
+      nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base_of(alo, ahi, u * R + t) + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
     }
   };
+  auto prefetch = [&](uint32_t u) { prefetch_of(s_sf, s_alo, s_ahi, u); };
   // ---- the steps of the join for one chunk.  A lane without an entry holds kDenseSent (>= kDenseVLimit); nothing here
   //      branches on that: such a lane ORs a zero into a word of its own (lane index: no bank conflict), reads some
   //      window and is masked out of the flagged set ----
@@ -104,6 +113,9 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     const uint32_t *w = bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits);
     return __builtin_amdgcn_alignbit(w[1], w[0], qm & 31u);
   };
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 0
+  if (s_alo != 0x12345u) return true;
+#endif
   prefetch(0);
   uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
   uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
@@ -141,7 +153,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         for (int t = 0; t < R; ++t) {
           const uint32_t last4 = f[t] > (uint32_t)kWave ? (f[t] - 1u) * 4u : 0u;
           const uint32_t at4 = lane4 + 4u * (uint32_t)kWave;
-          hv[t] = *(const uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
+          hv[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
         }
       }
       bool remap;
@@ -157,9 +169,9 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       }
       uint32_t max_u = 0;
       bool any_u = true;
-      if (__builtin_expect(remap || long_lists, 0)) {
-        // entries within kDenseNear of a sequence start are resolved exactly (pos >= start or dropped); then, as with
-        // long lists, the maximum of U comes from a wave reduction (a dropped entry may sit at the end of a run)
+      if (__builtin_expect(remap, 0)) {
+        // rare: entries within kDenseNear of a sequence start are resolved exactly (pos >= start or dropped); the maximum
+        // of U then comes from a wave reduction (a dropped entry may sit at the end of a run)
         uint32_t mx = 0, have_u = 0;
         auto settle = [&](uint32_t &v, bool have, uint32_t start) {
           const uint32_t raw = v;
@@ -174,7 +186,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         };
 #pragma unroll 1
         for (int t = 0; t < R; ++t) {
-          // (rolled, the arrays through LDS-free selects: this path is rare and must stay small)
+          // (rolled, the arrays through selects: this path must stay small)
           uint32_t a_ = 0, b_ = 0;
 #pragma unroll
           for (int q = 0; q < R; ++q) a_ = q == t ? val[q] : a_, b_ = q == t ? hv[q] : b_;
@@ -196,10 +208,22 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
 #pragma unroll
         for (int t = 0; t < R; ++t) val[t] = ln < f[t] ? val[t] - st[t] : kDenseSent;
+        if (long_lists) {
 #pragma unroll
-        for (int t = 0; t < R - 1; ++t) {
-          const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
-          max_u = f[t] && lastv > max_u ? lastv : max_u;
+          for (int t = 0; t < R; ++t) hv[t] = ln + (uint32_t)kWave < f[t] ? hv[t] - st[t] : kDenseSent;
+#pragma unroll
+          for (int t = 0; t < R - 1; ++t) {
+            const uint32_t l_lo = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
+            const uint32_t l_hi = (uint32_t)__builtin_amdgcn_readlane((int)hv[t], (int)((f[t] - 65u) & 63u));
+            const uint32_t lastv = f[t] > (uint32_t)kWave ? l_hi : l_lo;
+            max_u = f[t] && lastv > max_u ? lastv : max_u;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < R - 1; ++t) {
+            const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
+            max_u = f[t] && lastv > max_u ? lastv : max_u;
+          }
         }
       }
 #if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 1
@@ -411,13 +435,15 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
 #define FEM_JOIN_WAVES_LO 7
 #endif
 #ifndef FEM_JOIN_WAVES_HI
-#define FEM_JOIN_WAVES_HI 4
+#define FEM_JOIN_WAVES_HI 5
 #endif
 constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_WAVES_HI; }
+// Registers: six blocks of this kernel (R <= 6) share a CU with one block of the next batch's seed_select_kernel (80
+// registers): 6 x 72 + 80 = 512 per lane and SIMD.  (amdgpu_num_vgpr is not honoured by this compiler; the budget follows
+// from the waves per SIMD asked for, and that attribute wants a literal: one kernel per R instead of a template.)
 
 template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(join_waves(R), 8))) seed_join_kernel(SeedParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *smem) {
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
   const uint32_t ln = lane_id();
@@ -558,5 +584,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(join_w
   }
 }
 
+
+#define FEM_JOIN_KERNEL(R, WAVES)                                                                                               \
+  __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) seed_join_kernel_r##R(SeedParams p) {                         \
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
+    seed_join_body<R>(p, smem);                                                                                                  \
+  }
+FEM_JOIN_KERNEL(1, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(2, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(3, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(4, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(5, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(6, FEM_JOIN_WAVES_LO)
+FEM_JOIN_KERNEL(7, FEM_JOIN_WAVES_HI)
+FEM_JOIN_KERNEL(8, FEM_JOIN_WAVES_HI)
+FEM_JOIN_KERNEL(9, FEM_JOIN_WAVES_HI)
+FEM_JOIN_KERNEL(10, FEM_JOIN_WAVES_HI)
+#undef FEM_JOIN_KERNEL
 
 }  // namespace femk
