@@ -198,8 +198,6 @@ struct fem_dev {
   // dense indexes: occurrence table in 32-bit global coordinates + its sequence tables (fem_seed_dense.hip.h)
   uint32_t *d_occ32 = nullptr, *d_goff = nullptr, *d_blkseq = nullptr;
   uint32_t *d_freq11 = nullptr;  // saturated byte frequencies per 11-mer (fem_seed_select.hip.h), 64 MiB
-  int dense_occ_blocks = 0;
-  uint64_t dense_occ_key = ~0ull;
   int select_occ_blocks = 0, join_occ_blocks = 0;
   uint64_t select_occ_key = ~0ull, join_occ_key = ~0ull;
   // reference
@@ -220,9 +218,8 @@ struct fem_dev {
   uint64_t t_n[kTimedKernels] = {};
   bool force_generic = false;  // FEM_FORCE_GENERIC=1: skip the fast seed kernel (test hook)
   bool force_hash = false;     // FEM_FORCE_HASH=1: always use the hash-join form of the fast kernel (test hook)
-  bool force_dense = false;    // FEM_FORCE_DENSE=1: build the 32-bit tables and run seed_dense_kernel whatever the index density (test hook)
-  bool no_dense = false;       // FEM_NO_DENSE=1: never run seed_dense_kernel (measurement / A-B hook)
-  bool fused_dense = false;    // FEM_DENSE_FUSED=1: the round-2 fused seed_dense_kernel instead of select + join (A-B hook)
+  bool force_dense = false;    // FEM_FORCE_DENSE=1: build the 32-bit tables and run seed_select_kernel + seed_join_kernel whatever the index density (test hook)
+  bool no_dense = false;       // FEM_NO_DENSE=1: never take the dense-index path (measurement / A-B hook)
   bool tiny_buffers = false;   // FEM_TEST_TINY_BUFFERS=1: start every scratch buffer tiny so the grow + re-run paths run (test hook)
   std::vector<hipEvent_t> event_pool;
   // The slots' streams overlap copies with kernels, but the kernels of different batches run one after the other
@@ -372,34 +369,6 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
   return l;
 }
 
-// LDS of one wave of seed_dense_kernel: packed bases, (lookup, frequency) per seed (later the strands' candidates), DP
-// take bits, flagged values per phase group, scatter, the block's begin/count entries, the join's bitmap
-femk::SeedLayout make_layout_dense(const fem_params &p, uint32_t max_len) {
-  femk::SeedLayout l{};
-  const uint32_t R = (uint32_t)(p.e + 1 + p.a);
-  const uint32_t n_groups = 2u * (uint32_t)p.step;
-  l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
-  l.n_words = (max_len + 15u) / 16u + 2u;
-  uint32_t o = 0;
-  auto take = [&](uint32_t bytes) {
-    uint32_t at = o;
-    o += (bytes + 15u) & ~15u;
-    return at;
-  };
-  l.pkw = take(l.n_words * 4u);
-  l.nkw = take(l.n_words * 4u);
-  l.sf = take(std::max(2u * l.smax * 8u, 2u * 64u * 4u));
-  l.dp_bits = take(n_groups * R * 8u);
-  l.X = take(64u * 4u);
-  l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
-  l.B = take(2u * femk::kReadBlock * 8u);
-  l.rb = take((femk::kReadBlock + 2u) * 8u);  // the block's read offsets
-  l.picked = take(64u * 8u);                   // (goff, length) of up to 64 sequences
-  l.F = take(femk::dense_bitmap_words((int)R) * 4u);
-  l.wave_bytes = o;
-  return l;
-}
-
 // LDS of one wave of seed_select_kernel (fem_seed_select.hip.h): the block's read offsets, the sub-block's two 2-bit
 // streams, one frequency byte per seed, strand and phase group, the per-read words.  The reads of a block are worked
 // on `nb` at a time, as many as a budget of 2 KB of frequency bytes holds (the kernel runs beside seed_join_kernel, whose
@@ -465,15 +434,6 @@ JoinKernel join_kernel(int R) {
   return k[std::min(std::max(R, 1), femk::kMaxR) - 1];
 }
 
-template <int R>
-void launch_dense_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL((femk::seed_dense_kernel<R>), grid, block, lds, st, sp);
-}
-template <int R>
-int dense_blocks_per_cu_r(int block, uint32_t lds) {
-  int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_dense_kernel<R>, block, lds) == hipSuccess ? nb : 0;
-}
 #define FEM_DENSE_SWITCH(R, CALL)      \
   switch (R) {                         \
     case 1: CALL(1); break;            \
@@ -487,18 +447,6 @@ int dense_blocks_per_cu_r(int block, uint32_t lds) {
     case 9: CALL(9); break;            \
     default: CALL(10); break;          \
   }
-int dense_blocks_per_cu(int R, int block, uint32_t lds) {
-  int nb = 0;
-#define FEM_CALL(r) nb = dense_blocks_per_cu_r<r>(block, lds)
-  FEM_DENSE_SWITCH(R, FEM_CALL)
-#undef FEM_CALL
-  return nb;
-}
-void launch_dense(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-#define FEM_CALL(r) launch_dense_r<r>(grid, block, lds, st, sp)
-  FEM_DENSE_SWITCH(R, FEM_CALL)
-#undef FEM_CALL
-}
 template <int R>
 uint32_t kernel_regs_r(bool join) {
   hipFuncAttributes a{};
@@ -719,7 +667,7 @@ int launch_batch(fem_dev *h, Slot &s) {
 
   if (s.n_reads) {
     int rc;
-    const bool split_dense = use_fast && h->d_occ32 && h->d_freq11 && !h->fused_dense;
+    const bool split_dense = use_fast && h->d_occ32 && h->d_freq11;
     const bool overlap = split_dense && !h->no_overlap;
     if (!overlap && h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
     femk::VerifyParams vp{};
@@ -798,24 +746,6 @@ int launch_batch(fem_dev *h, Slot &s) {
         if (rc) return rc;
       }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the two queued
-    } else if (use_fast && h->d_occ32) {
-      // (A-B hook FEM_DENSE_FUSED=1: round 2's fused kernel)
-      femk::SeedParams fp = sp;
-      fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
-      fp.lay = make_layout_dense(p, std::max<uint32_t>(s.max_len, (uint32_t)p.k));
-      if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
-      const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
-      const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
-      const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
-      if (h->dense_occ_key != key) h->dense_occ_key = key, h->dense_occ_blocks = dense_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
-      static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 1;
-      const uint64_t per_cu = h->dense_occ_blocks > 0 ? (uint64_t)h->dense_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
-      const uint64_t wanted = (s.n_reads + (uint64_t)femk::kReadBlock * wpb - 1) / ((uint64_t)femk::kReadBlock * wpb);
-      const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wanted, (uint64_t)h->n_cu * per_cu * mult));
-      fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
-      rc = timed(0, s.stream, [&] { launch_dense(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
-      if (rc) return rc;
-      sp.work_queue = s.d_slow;  // the generic kernel finishes what the dense one queued
     } else if (use_fast) {
       femk::SeedParams fp = sp;
       // long occurrence lists (dense index): the hash-join form of the kernel; short ones: lists in lanes only
@@ -918,7 +848,7 @@ int refresh_summary(fem_dev *h) {
 }
 
 // After index AND reference are resident: for dense indexes (long occurrence lists) derive the occurrence table in
-// 32-bit global coordinates that seed_dense_kernel joins on (fem_seed_dense.hip.h).  Skipped (the 64-bit hash-join
+// 32-bit global coordinates that seed_join_kernel joins on (fem_seed_dense.hip.h) and the byte frequencies seed_select_kernel reads.  Skipped (the 64-bit hash-join
 // form of seed_fast_kernel runs instead) when the coordinates do not fit 32 bits.
 constexpr double kDenseMinAvgBucket = 4.0;
 int refresh_dense(fem_dev *h) {
@@ -1117,8 +1047,6 @@ int fem_dev_open(int device, fem_dev **out) {
   h->force_dense = fd && fd[0] == '1';
   const char *nd = getenv("FEM_NO_DENSE");
   h->no_dense = nd && nd[0] == '1';
-  const char *fu = getenv("FEM_DENSE_FUSED");
-  h->fused_dense = fu && fu[0] == '1';
   const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
   h->tiny_buffers = tb && tb[0] == '1';
   *out = h;
@@ -1743,7 +1671,7 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
   const int R = p->e + 1 + p->a;
   const bool use_fast = !h->force_generic && p->k == femk::kK && p->step == femk::kStep && R >= 1 && R <= femk::kMaxR;
   if (!use_fast) return "seed_filter_kernel";
-  if (h->d_occ32) return h->d_freq11 && !h->fused_dense ? "seed_join_kernel" : "seed_dense_kernel";
+  if (h->d_occ32 && h->d_freq11) return "seed_join_kernel";
   return (h->force_hash || (double)h->n_occ > (double)h->n_lookup) ? "seed_fast_kernel<hash>" : "seed_fast_kernel<lean>";
 }
 

@@ -80,7 +80,7 @@ struct SeedParams {
   // such seeds that end up selected.  One load answers both questions; 2.7 MiB for k = 12, which each XCD's L2 keeps.
   // Sparse indexes only (nullptr otherwise): most of the lookups per read then never touch the 64 MiB table.
   const uint32_t *summary;
-  // seed_dense_kernel (fem_seed_dense.hip.h): the occurrence table in 32-bit global coordinates, the coordinate of
+  // seed_join_kernel (fem_seed_dense.hip.h): the occurrence table in 32-bit global coordinates, the coordinate of
   // each sequence's first base (n_seq + 1 entries) and, per 2^20 coordinates, the last sequence starting at or before
   const uint32_t *occ32;
   const uint32_t *goff;

@@ -5,7 +5,7 @@
 // the previous read is joined.
 //
 // The join works on the 32-bit global coordinates of fem_seed_dense.hip.h (occ32, goff, the remapped near-start
-// entries) and on the same idea as round 2's dense_join — a value survives merge + additional_qgram_filter iff a+1
+// entries) and on the idea of round 2's fused seed_dense_kernel — a value survives merge + additional_qgram_filter iff a+1
 // values of the unit's multiset lie in [v, v+e], so a bitmap over slots of 8 positions finds the few values that can
 // have a partner and the filter is evaluated exactly on those — but is built to retire as few instructions as that
 // idea allows (the round-2 join ran the vector, scalar and LDS ports at 73 / 74 / 58 % at once):
@@ -57,8 +57,8 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   constexpr uint32_t kWords = kSlots / 32u;          // the guard word sits at bitmap[kWords]
   constexpr uint32_t kPeriodBits = kSlotBits + 3u;   // values this many bits apart share a slot
   constexpr uint32_t kFlagCap = dense_flag_cap(R);   // flagged values one unit may have (one or two per lane)
-  constexpr bool kSecondProbe = R >= FEM_DENSE_PROBE_R;
-  constexpr uint32_t kProbeMin = FEM_DENSE_PROBE_MIN;
+  constexpr bool kSecondProbe = true;  // weed the chance flags out before the exact filter ...
+  constexpr uint32_t kProbeMin = 8u;   // ... when there are more flagged values than this
   constexpr uint32_t kFlgStride = kFlagCap + 1u;     // the entry behind a group's array takes the overflow writes
   constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;

@@ -206,19 +206,22 @@ int fem_dev_fetch_sam_nowait(fem_dev *h, int slot, fem_batch_sam *out);
 int fem_dev_sam_wait(fem_dev *h, int slot);
 
 /* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident
- * index ("seed_dense_kernel", "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or "seed_filter_kernel"); the
- * generic seed_filter_kernel always follows for whatever that one queues.  Static string. */
+ * index ("seed_join_kernel" — behind its "seed_select_kernel" —, "seed_fast_kernel<hash>", "seed_fast_kernel<lean>"
+ * or "seed_filter_kernel"); the generic seed_filter_kernel always follows for whatever those queue.  Static string. */
 const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
 
 /* ---- measurement ---- */
 /* With timing on, every kernel launch is bracketed by HIP events on the stream
  * it is launched on; fem_dev_kernel_time reports their sum and count since
- * the last reset.  kernel: 0 = seed/filter kernel (fast form, k=12 step=3),
+ * the last reset.  kernel: 0 = seed/filter kernel (fast form, k=12 step=3; on a dense
+ * index the join kernel, whose selection kernel is 8),
  * 1 = verify kernel, 2 = seed/filter kernel (generic form: the reads the fast
  * form queued, or every read when the fast form does not apply); of
  * fem_dev_fetch_records: 3 = ordering of the mappings, 4 = traceback + MD,
  * 5 = compaction (one entry per call, several kernels each);
- * 6 = per-read mapping counts + counters after verification; of fem_dev_fetch_sam: 7 = the SAM text kernels. */
+ * 6 = per-read mapping counts + counters after verification; of fem_dev_fetch_sam: 7 = the SAM text kernels;
+ * 8 = seed selection kernel of the dense-index path (it runs beside the previous batch's kernel 0: its event time is
+ * what it takes there, not what it would take alone). */
 int fem_dev_set_timing(fem_dev *h, int on);
 int fem_dev_reset_timing(fem_dev *h);
 int fem_dev_kernel_time(fem_dev *h, int kernel, double *ms_total, uint64_t *launches);

@@ -1,6 +1,6 @@
 """The seed kernels the library selects BY ITSELF on naturally dense indexes, against the oracle (no FEM_FORCE_* set).
 
-BASELINE configs C3-C5 (3 Gbp, ~60 entries per 12-mer bucket) run seed_dense_kernel<R>; references between 50 and
+BASELINE configs C3-C5 (3 Gbp, ~60 entries per 12-mer bucket) run seed_select_kernel<R> + seed_join_kernel<R>; references between 50 and
 200 Mbp (1-4 entries per bucket) run the 64-bit hash-join form seed_fast_kernel<R, true>.  Both are compared here bit
 for bit with the oracle on references large enough that the library picks them unprompted
 (reference path: src/filter.c:80-131,146-223).  Needs a GPU: -m gpu.
@@ -38,7 +38,7 @@ def mid():  # 3 x 25 Mbp: 25 M entries in 16.8 M buckets -> seed_fast_kernel<R, 
 
 
 @pytest.fixture(scope="module")
-def dense():  # 3 x 72 Mbp: 72 M entries, 4.3 per bucket -> seed_dense_kernel<R>
+def dense():  # 3 x 72 Mbp: 72 M entries, 4.3 per bucket -> seed_select_kernel<R> + seed_join_kernel<R>
     d = _setup(72, [72_000_000] * 3)
     yield d
     d["dev"].close()
@@ -118,7 +118,7 @@ def test_dense_form_declines_what_its_32_bit_coordinates_cannot_hold():
     try:
         dev.upload_reference(seqs)
         dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
-        assert dev.seed_kernel(e=3) != "seed_dense_kernel"
+        assert dev.seed_kernel(e=3) != "seed_join_kernel"
         b = fo.ReadBatch(reads)
         got = dev.map_batch(b.bases, b.off, e=3)
         assert np.array_equal(got.stats, want.stats) and np.array_equal(got.per_strand()[1], want.cands)

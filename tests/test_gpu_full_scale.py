@@ -1,6 +1,6 @@
 """BASELINE configs C3 and C5 at their FULL reference size against the oracle, bit for bit: 24 x 125 Mbp, 999 999 912
 index entries (the oracle's index built by 16 threads, ~30 s), 100 k reads of 100 bp at e=3 and 50 k reads of 150 bp at
-e=7 through seed_dense_kernel as the library selects it.  (BASELINE's 50 M reads per config go through the same kernels
+e=7 through seed_select_kernel + seed_join_kernel as the library selects them.  (BASELINE's 50 M reads per config go through the same kernels
 in bench.py and, statistically, in tests/test_gpu_properties.py; the oracle maps ~0.5 Mreads/s at this index size.)
 Needs a GPU: -m gpu."""
 import numpy as np
@@ -30,13 +30,13 @@ def test_device_index_is_byte_identical_at_3_gbp(full):
     n, lookup, occ = dev.build_index(12, 3)  # construct_index (src/index.c:57-98) on the device
     assert n == idx.n_occ == 999_999_912
     assert np.array_equal(lookup, idx.lookup) and np.array_equal(occ, idx.occ[:n])
-    assert dev.seed_kernel(e=3) == "seed_dense_kernel" and dev.seed_kernel(e=7) == "seed_dense_kernel"
+    assert dev.seed_kernel(e=3) == "seed_join_kernel" and dev.seed_kernel(e=7) == "seed_join_kernel"
 
 
 @pytest.mark.parametrize("e,a,L,n,seed", [(3, 1, 100, 100_000, 3), (7, 1, 150, 50_000, 5), (5, 2, 125, 20_000, 11)])
 def test_c3_c5_candidates_and_verification_equal_the_oracle(full, e, a, L, n, seed):
     text, off, lens, ref, idx, dev = full
-    if dev.seed_kernel(e=e) != "seed_dense_kernel":
+    if dev.seed_kernel(e=e) != "seed_join_kernel":
         dev.build_index(12, 3, fetch=False)
     bases, offs = host.synth_reads(seed, text, off, lens, n, L, e, threads=16)
     want = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offs), e=e, a=a, threads=16, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
@@ -51,7 +51,7 @@ def test_c3_c5_candidates_and_verification_equal_the_oracle(full, e, a, L, n, se
 def test_c3_records_equal_the_oracle(full):
     # ... and the mapping tail on the device (ordering, traceback, CIGAR, MD) for reads mapped against the 3 Gbp reference
     text, off, lens, ref, idx, dev = full
-    if dev.seed_kernel(e=3) != "seed_dense_kernel":
+    if dev.seed_kernel(e=3) != "seed_join_kernel":
         dev.build_index(12, 3, fetch=False)
     n = 40_000
     bases, offs = host.synth_reads(33, text, off, lens, n, 100, 3, threads=16)
@@ -73,7 +73,7 @@ def test_diagonals_around_the_second_probe_boundaries(full):
     # coordinate, in three sequences, on both strands, among ordinary reads (so that the lists are long and the probe runs).
     from tests import util
     text, off, lens, ref, idx, dev = full
-    if dev.seed_kernel(e=3) != "seed_dense_kernel":
+    if dev.seed_kernel(e=3) != "seed_join_kernel":
         dev.build_index(12, 3, fetch=False)
     gap = 2048  # femk::kDenseGap: goff[s] = gap + s * (len + gap)
     special = []

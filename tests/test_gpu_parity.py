@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
                                         "tiny-buffers+hash", "tiny-buffers+dense"])
 def dev(request):
     # The library picks the seed kernel by itself: seed_fast_kernel<R, false> (lists in lanes) for sparse
-    # indexes, <R, true> (64-bit hash join) for denser ones, seed_dense_kernel<R> (32-bit coordinates, bitmap join) for
+    # indexes, <R, true> (64-bit hash join) for denser ones, seed_select_kernel<R> + seed_join_kernel<R> (11-mer frequency pairs, 32-bit coordinates, bitmap join) for
     # long lists, and the generic kernel for whatever those queue.  The environment hooks (read by fem_dev_open)
     # force the other forms so that every fixture runs through all four.
     import os

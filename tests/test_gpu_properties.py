@@ -146,7 +146,7 @@ def hg19_sized(dev):
     dev.upload_reference([text[int(o):int(o) + int(l)] for o, l in zip(off, lens)])
     n_occ, _, _ = dev.build_index(12, 3, fetch=False)
     assert n_occ == 999_999_912  # index entries of the 3 Gbp / 24-sequence reference
-    assert dev.seed_kernel(e=3) == "seed_dense_kernel"
+    assert dev.seed_kernel(e=3) == "seed_join_kernel"
     return text, off, lens
 
 
@@ -162,7 +162,7 @@ def test_c3_statistics_match_the_survey_probe(dev, hg19_sized):
 def test_c5_statistics_match_the_survey_probe(dev, hg19_sized):
     # BASELINE config C5; probe: same reference, 100 k reads of 150 bp, e=7: P/N = 2 814, C/N = 1.002, 99.86 % mapped
     text, off, lens = hg19_sized
-    assert dev.seed_kernel(e=7) == "seed_dense_kernel"
+    assert dev.seed_kernel(e=7) == "seed_join_kernel"
     p_n, c_n, mapped = _stats(dev, text, off, lens, 5, 400_000, 150, 7)
     assert abs(p_n - 2814) < 1.5, p_n
     assert abs(c_n - 1.002) < 0.002, c_n
