@@ -10,19 +10,25 @@ One step = one batch of `--batch` (2.5 M) synthetic reads through the DEVICE PIP
     the caller's batch in ordinary host memory --fem_dev_map_batch_submit: packed to 2 bits per base into pinned
     staging by the library's host threads, H2D, expanded--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
 with three batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
-`value` is that rate; `pipeline_by_workload[*].zero_copy_ascii_mreads` is the same pipeline fed from batches that
-already sit in pinned staging as characters (the parser's zero-copy form; bound by the PCIe link at C2).  The kernels
-alone, replayed on a batch already resident in HBM (what round 1 reported), are `config.kernel_only_mreads`; the
-end-to-end command line (FASTQ -> SAM) is `e2e_cli`.  Before its W warm-up steps a workload runs as many further untimed
-steps as it takes for the process to have seen 12 batches (`config.priming_steps`; the HIP runtime grows its command
-pools over the first ~10 batches, which at 2.5 ms per step was a third of a 10-step measurement).
+`value`, `ms_per_step` and `roofline` all come from the SAME workload, the headline one: C3 (100 bp, e=3, 3 Gbp
+reference: the HBM-resident configuration SURVEY.md 8d calls bandwidth-relevant; 20 steps x 2.5 M = BASELINE's 50 M
+reads).  `value` is the first timed run of exactly K steps; `spread` has min / median / max over that run and
+`--reps - 1` further ones.  C2 (5 Mbp: the index is cache-resident, the pipeline host- and link-balanced) and C5 (150 bp,
+e=7) are measured next to it at N = 1 (`pipeline_by_workload`, `roofline_by_workload`).
+
+`roofline` is the dominant kernel of the headline workload — seed_join_kernel — with ITS algorithmic bytes (8 P: the
+occurrence entries of the selected seeds) over ITS mean launch time inside the timed pipeline (HIP events on its stream;
+it runs beside the next batch's seed_select_kernel there).  `roofline_step` is the figure nothing hides in: all
+algorithmic bytes of a step (SURVEY.md 8d's formula) over the driver-visible ms_per_step.  `roofline_by_kernel` has
+seed_select_kernel with its own bytes (N L + 16 S N) over its time when it has the chip to itself.
+`config.kernel_only_mreads`: the kernels alone on batches already resident in HBM, four slots in rotation (so that,
+as in the pipeline, one batch's selection runs beside the previous batch's join).  `e2e_cli`: FASTQ -> SAM.
 
 Workloads (BASELINE.json `configs`):
-    c2   5 Mbp reference, 100 bp reads, e=3        the configuration the metric is quoted on: `value`, all N
-    c3   24 x 125 Mbp reference, 100 bp, e=3       HBM-resident index; N = 1 runs it too (20 steps x 2.5 M = BASELINE's 50 M)
-    c5   same reference, 150 bp, e=7               N = 1 runs it too (20 steps x 2.5 M = BASELINE's 50 M)
-`roofline` is the dominant kernel of c3 when c3 ran (the bandwidth-relevant configuration), else of c2;
-`roofline_by_workload` has all of them.  Rank 0 prints ONE JSON line.
+    c3   24 x 125 Mbp reference, 100 bp, e=3       the headline: `value`, all N
+    c2   5 Mbp reference, 100 bp reads, e=3        N = 1 runs it too
+    c5   same reference as c3, 150 bp, e=7         N = 1 runs it too (20 steps x 2.5 M = BASELINE's 50 M)
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -96,7 +102,7 @@ class Rank:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads):
+def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads, reps=1):
     """Pipeline measurement + resident-kernel replay of one workload on this rank's device.  `data` = (text, off, lens)."""
     import numpy as np
     from fem_amd import host
@@ -125,12 +131,15 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             # fem_dev_map_batch_submit (include/fem_hip.h): the caller's batch is packed to two bits per base into the slot's
             # pinned staging by the library's host threads, sent, expanded on the device; everything behind it asynchronous
             dev.stage_reads(batches[s][0], batches[s][1], slot=s)
-        else:
+        elif form[0] == "acquire_commit":
             # zero-copy form: the batch already sits in the slot's pinned staging as characters (a parser wrote it there)
             dev.commit_stage(batch, L, slot=s, uniform=True)
+        # ("resident": the slot's batch is in HBM already, nothing is sent)
         dev.map_staged(e=e, a=a, k=k, step=step, slot=s)
 
     def retire(i):
+        if form[0] == "resident":
+            return dev.fetch_stats(slot=i % N_SLOTS)  # nothing but the counters comes back
         r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
         d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
         return r.stats
@@ -158,22 +167,28 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     pipeline(max(warmup, 1))
     h2d_bytes, sent_packed = dev.stage_info(0)
     stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
-    dev.reset_timing()
-    fence()
-    t_start = time.perf_counter()
-    job, last_stats = pipeline(steps)
-    if rk.world > 1:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
-        stats_dev.copy_(torch.from_numpy(job.astype(np.int64)))
-        dist.all_reduce(stats_dev)
-        job = stats_dev.cpu().numpy().astype(np.uint64)
-    fence()
-    elapsed = time.perf_counter() - t_start
+    runs = []  # (elapsed seconds, kernel times) of every timed repetition of exactly `steps` steps; the first is `value`
+    job = last_stats = None
+    for rep in range(max(1, reps)):
+        dev.reset_timing()
+        fence()
+        t_start = time.perf_counter()
+        job_r, last_r = pipeline(steps)
+        if rk.world > 1:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
+            stats_dev.copy_(torch.from_numpy(job_r.astype(np.int64)))
+            dist.all_reduce(stats_dev)
+            job_r = stats_dev.cpu().numpy().astype(np.uint64)
+        fence()
+        elapsed = time.perf_counter() - t_start
+        if rk.world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        runs.append((elapsed, {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}))
+        if rep == 0:
+            job, last_stats = job_r, last_r
     dev.set_timing(False)
-    if rk.world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    kt = {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}
+    elapsed, kt = runs[0]
 
     # the zero-copy form, for comparison (the staging buffers held the packed batches until now)
     form[0] = "acquire_commit"
@@ -190,51 +205,93 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     zero_copy = batch * n_z / (time.perf_counter() - tz) / 1e6
     h2d_zero_copy = dev.stage_info(0)[0]
 
-    # the kernels alone on a batch already resident in HBM (slot 0 as staged by the last pipeline step that used it)
-    n_rep = 3
-    dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
-    dev.fetch_stats(slot=0)  # (from here on nothing but the counters comes back: no result arrays behind the kernels)
-    dev.reset_timing()
+    # the kernels alone on batches already resident in HBM (every slot as staged by the pipeline steps above), the four
+    # slots in rotation: as in the pipeline, a batch's seed selection runs beside the previous batch's join
+    form[0] = "resident"
+    n_rep = max(8, min(steps, 12))
+    pipeline(N_SLOTS)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(n_rep):
+    pipeline(n_rep)
+    torch.cuda.synchronize()
+    kernel_only = batch * n_rep / (time.perf_counter() - t1) / 1e6
+    # ... and one batch at a time (nothing beside anything): every kernel's time when it has the chip to itself
+    dev.set_timing(True)
+    dev.reset_timing()
+    for _ in range(3):
         dev.map_staged(e=e, a=a, k=k, step=step, slot=0)
         dev.fetch_stats(slot=0)
     torch.cuda.synchronize()
-    kernel_only = batch * n_rep / (time.perf_counter() - t1) / 1e6
+    alone = {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}
+    dev.set_timing(False)
 
     seed_name = dev.seed_kernel(e=e, a=a, k=k, step=step)
-    per_launch = {}
-    for name, (ms, n) in kt.items():
-        per_launch[seed_name.split("<")[0] if name == "seed" else name] = (ms / max(n, 1), n / steps)
+
+    def per_launch_of(times):
+        out = {}
+        for name, (ms, n) in times.items():
+            if n:
+                out[seed_name.split("<")[0] if name == "seed" else name] = (ms / n, n)
+        return out
+
+    per_launch = {n_: (v[0], v[1] / steps) for n_, v in per_launch_of(kt).items()}
+    alone_ms = {n_: v[0] for n_, v in per_launch_of(alone).items()}
     # algorithmic bytes: B = N*L + 16*(L-k+1)*N + 8*P + (L+2e)*C + 16*M, from the path's own counters
     N, P, Cn, M = batch, int(last_stats[2]), int(last_stats[3]), int(last_stats[4])
     S = L - k + 1
-    seed_bytes = N * L + 16 * S * N + 8 * P      # read bases + one 8-byte lookup pair per seed and strand + occurrences
+    select_bytes = N * L + 16 * S * N            # read bases + one 8-byte lookup pair per seed and strand
+    join_bytes = 8 * P                           # occurrence entries of the selected seeds
+    seed_bytes = select_bytes + join_bytes
     verify_bytes = (L + 2 * e) * Cn + 16 * M     # reference window per verification + result record
-    dominant = max(per_launch, key=lambda n_: per_launch[n_][0] * per_launch[n_][1])
+    split = "seed_select_kernel" in per_launch   # dense index: the seed path is two kernels
+    bytes_of = {"seed_select_kernel": select_bytes, "seed_join_kernel": join_bytes if split else seed_bytes,
+                "seed_fast_kernel": seed_bytes, "seed_filter_kernel": seed_bytes, "verify_kernel": verify_bytes}
+    cand = [n_ for n_ in per_launch if n_ in bytes_of and n_ != "seed_select_kernel"]
+    dominant = max(cand, key=lambda n_: per_launch[n_][0] * per_launch[n_][1])
     dom_ms, dom_launches = per_launch[dominant]
-    dom_bytes = (verify_bytes if dominant == "verify_kernel" else seed_bytes) / max(dom_launches, 1.0)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
-            "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)}
-    # HBM-side bytes of that kernel: NOT measured in this run.  They come from the committed rocprofv3 --pmc passes
-    # of this same command (profiles/r02_<wl>_hbm_traffic.json: FETCH_SIZE + WRITE_SIZE), scaled to this batch size.
-    tpath = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % key)
+
+    def roof_of(name, ms, nbytes, what):
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4), "time_is": what}
+
+    roof = roof_of(dominant, dom_ms, bytes_of[dominant] / max(dom_launches, 1.0),
+                   "mean launch duration inside the timed pipeline (HIP events on the kernel's stream)")
+    roof["bytes_are"] = ("8 P: the occurrence entries of the selected seeds (SURVEY.md 8d's third term)" if split and dominant == "seed_join_kernel"
+                         else "SURVEY.md 8d's terms for this kernel")
+    by_kernel = {dominant: roof}
+    for n_ in per_launch:
+        if n_ in bytes_of and n_ != dominant and n_ in alone_ms and n_ != "seed_filter_kernel":
+            by_kernel[n_] = roof_of(n_, alone_ms[n_], bytes_of[n_], "launch duration with the chip to itself (resident replay, one batch at a time)")
+    ms_step = elapsed * 1e3 / steps
+    step_roof = roof_of("whole step: every kernel of one batch", ms_step * rk.world, (seed_bytes + verify_bytes) * rk.world,
+                        "driver-visible ms_per_step (copies, gaps, fill and drain included)")
+    step_roof["achieved"] = round((seed_bytes + verify_bytes) / (ms_step * 1e-3) / 1e9, 2)  # per GPU
+    step_roof["frac"] = round(step_roof["achieved"] / HBM_PEAK_GBS, 5)
+    step_roof["algorithmic_bytes_per_launch"] = int(seed_bytes + verify_bytes)
+    step_roof["avg_launch_ms"] = round(ms_step, 4)
+    # HBM-side bytes of the dominant kernel: NOT measured in this run.  They come from the committed rocprofv3 --pmc passes
+    # of this same command (profiles/r03_<wl>_hbm_traffic.json: FETCH_SIZE + WRITE_SIZE, corrected by the calibration of
+    # profiles/r03_fetch_calibration.json for this kernel's access pattern), scaled to this batch size.
+    tpath = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % key)
     if os.path.exists(tpath):
         try:
             prof = json.load(open(tpath))
             for kname, ctr in prof["kernels"].items():
-                if dominant in kname and "FETCH_SIZE" in ctr and ctr["FETCH_SIZE"]["mean_per_launch"] > 1e3:
-                    kib = ctr["FETCH_SIZE"]["mean_per_launch"] + ctr.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
-                    roof["traffic"] = int(kib * 1024 * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
-                    roof["traffic_source"] = "committed profile profiles/r02_%s_hbm_traffic.json, rescaled (not measured in this run)" % key
+                if dominant in kname and "hbm_bytes_per_launch" in ctr:
+                    roof["traffic"] = int(ctr["hbm_bytes_per_launch"] * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
+                    roof["traffic_source"] = ("committed profile profiles/r03_%s_hbm_traffic.json (FETCH_SIZE x %.2f + WRITE_SIZE: "
+                                              "calibrated on this kernel's access pattern), rescaled (not measured in this run)"
+                                              % (key, ctr.get("fetch_factor", 1.0)))
         except Exception as ex:  # a malformed profile file must not break the measurement
             log("could not read %s: %s" % (tpath, ex))
-    value = rk.world * batch * steps / elapsed / 1e6
+    values = [rk.world * batch * steps / r[0] / 1e6 for r in runs]
+    value = values[0]
     return {
-        "workload": w["name"], "value": round(value, 3), "ms_per_step": round(elapsed * 1e3 / steps, 3), "steps": steps,
+        "workload": w["name"], "value": round(value, 3), "ms_per_step": round(ms_step, 3), "steps": steps,
+        "spread": {"reps": len(values), "min": round(min(values), 3), "median": round(sorted(values)[len(values) // 2], 3),
+                   "max": round(max(values), 3), "values": [round(v, 3) for v in values]},
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
         "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_bytes[0],
@@ -246,7 +303,8 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "algorithmic_bytes_per_step_per_gpu": seed_bytes + verify_bytes,
         "kernel_ms_per_launch": {n_: round(v[0], 4) for n_, v in per_launch.items()},
         "kernel_launches_per_step": {n_: round(v[1], 2) for n_, v in per_launch.items()},
-        "roofline": roof,
+        "kernel_ms_alone": {n_: round(v, 4) for n_, v in alone_ms.items()},
+        "roofline": roof, "roofline_step": step_roof, "roofline_by_kernel": by_kernel,
     }
 
 
@@ -336,14 +394,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="the workload `value` is measured on")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="the workload `value` is measured on")
+    ap.add_argument("--reps", type=int, default=3, help="timed runs of exactly --steps steps of the headline workload (value = the first; spread = all)")
     ap.add_argument("--batch", type=int, default=2_500_000, help="reads per step and GPU")
     ap.add_argument("--extra", default="auto", help="comma list of further workloads measured on rank 0 when N = 1 "
-                                                    "(auto = c3,c5 next to c2; none)")
+                                                    "(auto = c5,c2 next to c3; none)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
-    ap.add_argument("--cpu-sample-c3", type=int, default=400_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
-                                                                       "the oracle's 3 Gbp index takes ~30 s to build)")
+    ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
+                                                                         "the oracle's 3 Gbp index takes ~30 s to build)")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -389,18 +448,30 @@ def main():
 
     extras = []
     if rk.world == 1 and args.extra != "none":
-        extras = [x for x in (["c3", "c5"] if args.extra == "auto" else args.extra.split(",")) if x in WORKLOADS and x != args.workload]
-        if args.extra == "auto" and args.workload != "c2":
+        extras = [x for x in (["c5", "c2"] if args.extra == "auto" else args.extra.split(",")) if x in WORKLOADS and x != args.workload]
+        if args.extra == "auto" and args.workload != "c3":
             extras = []
 
     results, data_cache = {}, {}
     dev = None
     bw = {}
+    cpu_c3 = [None]
+
+    def cpu_c3_now():
+        """The headline configuration on the host cores, while the 3 Gbp reference is at hand (host text + device)."""
+        w3 = WORKLOADS["c3"]
+        ref_key3 = (3, tuple(w3["seq_lens"]))
+        if cpu_c3[0] is None and not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0 and ref_key3 in data_cache:
+            cpu_c3[0] = cpu_baseline(w3, data_cache[ref_key3][:3], args.cpu_sample_c3, dev, threads, label="C3")
+            cpu_c3[0].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota,
+                             device_pipeline_over_cpu=round(results["c3"]["value"] / max(cpu_c3[0]["value"], 1e-9), 1))
+
     for key in [args.workload] + extras:
         w = WORKLOADS[key]
         ref_key = (w["seed"] if key == "c2" else 3, tuple(w["seq_lens"]))  # c3 and c5 share one reference (seed 3)
         t0 = time.time()
         if ref_key not in data_cache:
+            cpu_c3_now()
             data_cache.clear()
             if dev is not None:
                 dev.close()
@@ -415,11 +486,13 @@ def main():
                 bw = {"device_copy_gbs": round(dev.copy_bandwidth(1 << 30, 10), 1), "pinned_h2d_gbs": round(dev.h2d_bandwidth(1 << 28, 8), 1)}
         text, off, lens, n_occ = data_cache[ref_key]
         steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, N_SLOTS + 1)  # (every slot warm)
-        res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads)
+        res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads,
+                           reps=args.reps if key == args.workload else 1)
         res["index_entries"] = n_occ
         results[key] = res
         log("rank %d %s: pipeline %.1f Mreads/s, kernels only %.1f, %s" % (rk.rank, key, res["value"], res["kernel_only_mreads"], res["kernel_ms_per_launch"]))
 
+    cpu_c3_now()
     if rk.rank != 0:
         if rk.world > 1:
             dist.barrier()
@@ -428,30 +501,29 @@ def main():
 
     head = results[args.workload]
     stage_threads = int(os.environ.get("FEM_STAGE_THREADS", "12"))
-    roof_key = "c3" if "c3" in results else args.workload
     out = {
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
         "value": head["value"], "unit": "Mreads/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic",
-        "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline")},
+        "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic", "spread": head["spread"],
+        "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline", "roofline_step",
+                                                                         "roofline_by_kernel", "spread")},
                        value_is="device pipeline: caller-owned batch in host memory -> fem_dev_map_batch_submit (2-bit packing into pinned "
                                 "staging on %d host threads, H2D, expansion) -> kernels -> D2H of fem_batch_result, %d batches in "
                                 "flight, a different batch per slot" % (stage_threads, DEPTH),
                        parallelism="reads sharded x%d, index replicated" % rk.world, bandwidths=bw),
-        "roofline": dict(results[roof_key]["roofline"], workload=roof_key),
-        "roofline_by_workload": {k_: v_["roofline"] for k_, v_ in results.items()},
+        "roofline": dict(head["roofline"], workload=args.workload),
+        "roofline_step": dict(head["roofline_step"], workload=args.workload),
+        "roofline_by_kernel": head["roofline_by_kernel"],
+        "roofline_by_workload": {k_: {"dominant_kernel": v_["roofline"], "step": v_["roofline_step"]} for k_, v_ in results.items()},
         "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
-                                                           "reads_per_step_per_gpu", "kernel_ms_per_launch", "counters_last_step_per_gpu",
+                                                           "reads_per_step_per_gpu", "kernel_ms_per_launch", "kernel_ms_alone", "counters_last_step_per_gpu",
                                                            "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step",
                                                            "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps")}
                                  for k_, v_ in results.items()},
     }
-    if not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0:
-        # the bandwidth-relevant configuration on the host cores too (the device still holds the 3 Gbp reference)
-        w3 = WORKLOADS["c3"]
-        out["cpu_baseline_c3"] = cpu_baseline(w3, data_cache[(3, tuple(w3["seq_lens"]))][:3], args.cpu_sample_c3, dev, threads, label="C3")
-        out["cpu_baseline_c3"].update(device_pipeline_over_cpu=round(results["c3"]["value"] / max(out["cpu_baseline_c3"]["value"], 1e-9), 1))
+    if cpu_c3[0] is not None:
+        out["cpu_baseline"] = cpu_c3[0]
     c2_data = None
     if (not args.no_cpu or not args.no_e2e) and rk.world == 1:
         w2 = WORKLOADS["c2"]
@@ -465,8 +537,9 @@ def main():
             dev.build_index(12, 3, fetch=False)
             c2_data = t2
     if not args.no_cpu and rk.world == 1:
-        out["cpu_baseline"] = cpu_baseline(WORKLOADS["c2"], c2_data, args.cpu_sample, dev, threads)
-        out["cpu_baseline"].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota)
+        key_cb = "cpu_baseline_c2" if "cpu_baseline" in out else "cpu_baseline"
+        out[key_cb] = cpu_baseline(WORKLOADS["c2"], c2_data, args.cpu_sample, dev, threads)
+        out[key_cb].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota)
     dev.close()
     if not args.no_e2e and rk.world == 1 and args.e2e_reads > 0:
         try:
