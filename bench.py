@@ -308,6 +308,48 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     }
 
 
+def profile_replay(key, dev, data, n, batch, torch, threads):
+    """What `rocprofv3 --kernel-trace` should see when the kernel times of the bench line are checked: the four slots'
+    batches staged once, then nothing but kernels (and the 40-byte counter copies) for n steps."""
+    from fem_amd import host
+    w = WORKLOADS[key]
+    L, e = w["L"], w["e"]
+    text, off, lens = data
+    for s in range(N_SLOTS):
+        b, o = host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=s * batch, threads=threads)
+        dev.stage_reads(b, o, slot=s)
+        dev.map_staged(e=e, a=1, k=12, step=3, slot=s)
+    for s in range(N_SLOTS):
+        dev.fetch_stats(slot=s)
+
+    def replay(m):
+        for i in range(m):
+            if i >= DEPTH:
+                dev.fetch_stats(slot=(i - DEPTH) % N_SLOTS)
+            dev.map_staged(e=e, a=1, k=12, step=3, slot=i % N_SLOTS)
+        for i in range(max(0, m - DEPTH), m):
+            dev.fetch_stats(slot=i % N_SLOTS)
+
+    replay(2 * N_SLOTS)  # warm-up launches: `warmup_launches_per_kernel` of every kernel's trace rows
+    torch.cuda.synchronize()
+    dev.set_timing(True)
+    dev.reset_timing()
+    t0 = time.perf_counter()
+    replay(n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev.set_timing(False)
+    seed_name = dev.seed_kernel(e=e, a=1, k=12, step=3).split("<")[0]
+    times = {}
+    for name, kid in KERNEL_IDS.items():
+        ms, cnt = dev.kernel_time(kid)
+        if cnt:
+            times[seed_name if name == "seed" else name] = {"launches": int(cnt), "mean_ms": round(ms / cnt, 4)}
+    return {"mode": "resident replay, slots in rotation, %d batches in flight" % DEPTH, "workload": key, "steps": n,
+            "reads_per_launch": batch, "warmup_launches_per_kernel": 3 * N_SLOTS, "mreads_per_s": round(batch * n / dt / 1e6, 2),
+            "event_times": times}
+
+
 def cpu_baseline(w, data, n_sample, dev, threads, label="C2"):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of the
     same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
@@ -404,6 +446,9 @@ def main():
     ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
                                                                          "the oracle's 3 Gbp index takes ~30 s to build)")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
+    ap.add_argument("--profile-replay", type=int, default=0, help="profiling aid: only the resident replay of --workload (kernels on batches "
+                                                                     "already in HBM, slots in rotation, no copies in flight), this many steps; "
+                                                                     "prints the HIP-event means of exactly those launches")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
@@ -486,6 +531,10 @@ def main():
                 bw = {"device_copy_gbs": round(dev.copy_bandwidth(1 << 30, 10), 1), "pinned_h2d_gbs": round(dev.h2d_bandwidth(1 << 28, 8), 1)}
         text, off, lens, n_occ = data_cache[ref_key]
         steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, N_SLOTS + 1)  # (every slot warm)
+        if args.profile_replay > 0:
+            print(json.dumps(profile_replay(key, dev, (text, off, lens), args.profile_replay, args.batch, torch, gen_threads)), flush=True)
+            dev.close()
+            return
         res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads,
                            reps=args.reps if key == args.workload else 1)
         res["index_entries"] = n_occ

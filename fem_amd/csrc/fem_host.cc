@@ -681,6 +681,9 @@ int fem_seqfile_read(fem_seqfile *f, uint64_t max_seqs, fem_seqset *out) {
     f->fast_ok = false;
     fast_view_abandon(f, 0);
   }
+  // From here on this reader's byte stream holds inflated bytes the window reader knows nothing of (it inflates from the
+  // file itself): a compressed source stays with the sequential reader once it has been read this way.
+  if (f->gz || f->zmap) f->fast_ok = false;
   if (f->map && max_seqs == 0 && f->last_char == 0 && f->in->tell() == 0 && read_fasta_parallel(f, out)) {
     f->in->seek_mem(f->map_len);
     return 0;
@@ -740,6 +743,7 @@ int fem_seqfile_read_bytes(fem_seqfile *f, uint64_t approx_bytes, int n_threads,
     fast_view_abandon(f, pos0);
   }
   // ---- sequential, kseq-exact ----
+  if (f->gz || f->zmap) f->fast_ok = false;  // (see fem_seqfile_read: the window reader would skip what this one buffers)
   std::vector<ParsedChunk> parts(1);
   int rc = 0;
   while (approx_bytes == 0 || f->in->tell() - pos0 < approx_bytes) {

@@ -381,3 +381,59 @@ def test_bgzf_input_is_inflated_block_parallel(tmp_path):
         host.read_planned_batches(str(flip), 100_000, threads=2)
     with pytest.raises(ValueError):
         host.read_sequences(str(flip))
+
+
+@pytest.mark.parametrize("kind", ["gzip", "bgzf", "plain"])
+def test_sequential_reads_then_batches_on_one_handle(tmp_path, kind):
+    # fem_seqfile_read(f, 10) followed by fem_seqfile_read_bytes / fem_seqfile_plan on the SAME handle: the sequential
+    # reader buffers inflated bytes (1 MB per gzread, or one BGZF block) the window reader knows nothing of, so a
+    # compressed source must stay with the sequential reader from then on — no record may be lost (ADVICE round 2:
+    # read(10) + a read_bytes loop returned 10 of 5000 records on .fq.gz)
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    n = 5000
+    recs = [b"@q%d\n" % i + util.rand_seq(rng, 100) + b"\n+\n" + b"I" * 100 + b"\n" for i in range(n)]
+    text = b"".join(recs)
+    p = tmp_path / ("mix.fq" + {"gzip": ".gz", "bgzf": ".bgz", "plain": ""}[kind])
+    if kind == "gzip":
+        with gzip.open(str(p), "wb", compresslevel=1) as f:
+            f.write(text)
+    elif kind == "bgzf":
+        p.write_bytes(_bgzf(text))
+    else:
+        p.write_bytes(text)
+    L = host.lib()
+    for second in ("read_bytes", "plan"):
+        f = L.fem_seqfile_open(str(p).encode())
+        assert f
+        names = []
+        try:
+            s = host.SeqSet()
+            assert L.fem_seqfile_read(f, 10, C.byref(s)) == 0
+            first = host.Sequences(s)
+            L.fem_seqset_free(C.byref(s))
+            names += [first.name(i) for i in range(first.n)]
+            assert first.n == 10
+            while True:
+                if second == "read_bytes":
+                    s = host.SeqSet()
+                    assert L.fem_seqfile_read_bytes(f, 60_000, 4, C.byref(s)) == 0
+                    part = host.Sequences(s)
+                    L.fem_seqset_free(C.byref(s))
+                    if part.n == 0:
+                        break
+                    names += [part.name(i) for i in range(part.n)]
+                else:
+                    plan, shape = C.c_void_p(), host.BatchShape()
+                    assert L.fem_seqfile_plan(f, 60_000, 4, C.byref(plan), C.byref(shape)) == 0
+                    if shape.n_reads == 0:
+                        L.fem_batch_plan_free(plan)
+                        break
+                    k, nb = int(shape.n_reads), int(shape.n_bases)
+                    bases, off = np.zeros(nb + 64, np.uint8), np.zeros(k + 1, np.uint64)
+                    quals, nm, nmo = np.zeros(nb + 1, np.uint8), np.zeros(int(shape.n_name_bytes) + 1, np.uint8), np.zeros(k + 1, np.uint64)
+                    assert L.fem_seqfile_fill(f, plan, 4, bases.ctypes.data, off.ctypes.data, quals.ctypes.data, nm.ctypes.data, nmo.ctypes.data) == 0
+                    names += [nm[int(nmo[i]):int(nmo[i + 1])].tobytes().decode() for i in range(k)]
+        finally:
+            L.fem_seqfile_close(f)
+        assert names == ["q%d" % i for i in range(n)], (kind, second, len(names))
