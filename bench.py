@@ -100,6 +100,9 @@ class Rank:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # FEM_BENCH_FORCE_DIST=1: a process group even for one rank, so that the RCCL reduction of the counters (the path's
+        # one exchange) runs on a one-GPU box too (tests/test_gpu_bench.py)
+        self.dist = self.world > 1 or os.environ.get("FEM_BENCH_FORCE_DIST") == "1"
 
 
 def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads, reps=1):
@@ -118,7 +121,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     log("rank %d %s: %d x %d reads generated in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
 
     def fence():
-        if rk.world > 1:
+        if rk.dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,13 +177,13 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         fence()
         t_start = time.perf_counter()
         job_r, last_r = pipeline(steps)
-        if rk.world > 1:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
+        if rk.dist:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
             stats_dev.copy_(torch.from_numpy(job_r.astype(np.int64)))
             dist.all_reduce(stats_dev)
             job_r = stats_dev.cpu().numpy().astype(np.uint64)
         fence()
         elapsed = time.perf_counter() - t_start
-        if rk.world > 1:
+        if rk.dist:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -474,8 +477,9 @@ def main():
     backend = os.environ.get("FEM_BENCH_BACKEND", "nccl")
     local_rank = 0 if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else rk.local_rank
     torch.cuda.set_device(local_rank)
-    if rk.world > 1:
+    if rk.dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rk.rank, world_size=rk.world, device_id=torch.device("cuda", local_rank))
         else:
@@ -543,7 +547,7 @@ def main():
 
     cpu_c3_now()
     if rk.rank != 0:
-        if rk.world > 1:
+        if rk.dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -595,8 +599,9 @@ def main():
             out["e2e_cli"] = e2e_cli(WORKLOADS["c2"], c2_data, args.e2e_reads, threads)
         except Exception as ex:
             out["e2e_cli"] = {"error": repr(ex)}
+    out["config"]["counter_reduction"] = ("torch.distributed all_reduce, backend %s, %d rank(s)" % (backend, rk.world)) if rk.dist else "single process: none"
     print(json.dumps(out), flush=True)
-    if rk.world > 1:
+    if rk.dist:
         dist.barrier()
         dist.destroy_process_group()
 

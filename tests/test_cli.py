@@ -166,6 +166,23 @@ def test_allreduce_stats_over_two_handles():
 
 
 @pytest.mark.gpu
+def test_allreduce_stats_over_one_handle_runs_rccl():
+    # fem_dev_allreduce_stats with a single handle: the communicator is created (ncclCommInitAll over one device) and the
+    # reduction runs over RCCL on a one-GPU box; the second and third call reuse the communicator
+    import ctypes as C
+    from fem_amd import Device
+    from fem_amd.device import load_hip
+    a = Device(0)
+    L = load_hip()
+    hs = (C.c_void_p * 1)(a._h)
+    for rep in range(3):
+        st = np.array([[7, 8, 9, 2 ** 41 + rep, 11]], dtype=np.uint64)
+        assert L.fem_dev_allreduce_stats(hs, 1, st.ctypes.data) == 0
+        assert st[0].tolist() == [7, 8, 9, 2 ** 41 + rep, 11]
+    a.close()
+
+
+@pytest.mark.gpu
 def test_map_regrows_its_staging_for_unusual_records(tmp_path):
     # very long read names and short reads: a FASTQ window holds far more name bytes than the staging buffers were sized
     # for (fem_main.cc: kRegrow), with the text rendered on the device and on the host

@@ -18,6 +18,9 @@ def test_oracle_reproduces_the_fixture(name):
         assert np.array_equal(want[key], got[key]), key
     if name == "c1_seed1":
         assert int(want["stats"][0]) == 1000 and 700 < int(want["stats"][1]) < 950  # config 1: most reads map
+    if name == "repeat_rich":  # what SURVEY 8(c)(2) asks the repeat fixture to reach
+        assert int(want["max_records_per_read"][0]) > 64 and int(want["reads_over_64_records"][0]) > 50
+        assert int(want["strands_with_full_groups"][0]) > 100 and (want["in_text"] == ord("N")).sum() > 100
 
 
 @pytest.mark.gpu

@@ -48,6 +48,25 @@ def test_counters_are_consistent_with_the_result_arrays(dev, c2):
     assert int(r.stats[1]) > 0.8 * n  # reads come from the reference with <= e edits: most of them map
 
 
+def test_c2_workload_array_for_array_against_the_oracle(dev, c2):
+    # the first 200 k reads of the C2 workload (the bench's generator, seed 2): candidates, edit distances, end offsets
+    # and counters of the device path — seed_fast_kernel<lean>, as the library selects it — equal the oracle's
+    from oracle import fem_oracle as fo
+    text, off, lens, bases, offs, n = c2
+    m = 200_000
+    assert dev.seed_kernel(e=3) == "seed_fast_kernel<lean>"
+    ref = fo.Reference([text[:5_000_000].tobytes()])
+    idx = fo.OracleIndex(ref)
+    sub_b, sub_o = bases[:int(offs[m]) + 8], offs[:m + 1]
+    want = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(sub_b, sub_o), e=3, a=1, threads=16, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    got = dev.map_batch(sub_b, sub_o, e=3, slot=2)
+    o, cand, ed, end = got.per_strand()
+    assert np.array_equal(got.stats, want.stats), (got.stats, want.stats)
+    assert np.array_equal(o, want.cand_off) and np.array_equal(cand, want.cands)
+    assert np.array_equal(ed, want.v_ed) and np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF])
+    assert 0.84 * m < int(want.stats[1]) < 0.88 * m  # (the probe of the reference binary: 86 % of such reads map)
+
+
 def test_sharding_and_repetition_do_not_change_results(dev, c2):
     text, off, lens, bases, offs, n = c2
     whole = dev.map_batch(bases, offs, e=3)
