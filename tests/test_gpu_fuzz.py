@@ -1,4 +1,4 @@
-"""A bounded slice of tests/fuzz_gpu.py under `pytest -m gpu`: fixed seeds, fixed trial counts (115 batches, about a minute), so
+"""A bounded slice of tests/fuzz_gpu.py under `pytest -m gpu`: fixed seeds, fixed trial counts (580 batches, about a minute), so
 that the driver's GPU run exercises the randomised differential comparison too — device path against the oracle on
 repeat-rich, sparse, mid-density and dense (216 Mbp: seed_select_kernel + seed_join_kernel) references, e in 0..7, a in {1, 2}, read lengths 30..300 (equal or mixed), damaged
 reads, lower case, N rates; candidates, edit distances, end offsets, counters, the tail's records and the device's SAM
@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,kinds,trials", [(101, ("repeat",), 40), (202, ("sparse",), 40), (303, ("mid",), 25), (404, ("dense",), 10)])
+@pytest.mark.parametrize("seed,kinds,trials", [(101, ("repeat",), 200), (202, ("sparse",), 200), (303, ("mid",), 120), (404, ("dense",), 60)])
 def test_fuzz_slice(seed, kinds, trials):
     from tests import fuzz_gpu
     lines = []
