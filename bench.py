@@ -112,11 +112,15 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     w = WORKLOADS[key]
     L, e, a, k, step = w["L"], w["e"], 1, 12, 3
     text, off, lens = data
-    # a different batch for every slot, in ordinary (pageable) host memory: what a caller of the C ABI owns
+    # a different batch for every slot, in ordinary (pageable) host memory: what a caller of the C ABI owns.  The job is
+    # world x N_SLOTS batches of read indices; this rank maps its contiguous range of them (fem_amd/shard.py)
+    from fem_amd.shard import reduce_stats, shard_range
     t0 = time.time()
     batches = []
+    lo, hi = shard_range(rk.rank, rk.world, rk.world * N_SLOTS * batch)
+    assert hi - lo == N_SLOTS * batch
     for s in range(N_SLOTS):
-        b, o = host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=(rk.rank * N_SLOTS + s) * batch, threads=threads)
+        b, o = host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=lo + s * batch, threads=threads)
         batches.append((b, o))
     log("rank %d %s: %d x %d reads generated in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
 
@@ -169,7 +173,6 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         pipeline(priming)
     pipeline(max(warmup, 1))
     h2d_bytes, sent_packed = dev.stage_info(0)
-    stats_dev = torch.zeros(5, dtype=torch.int64, device=red_dev)
     runs = []  # (elapsed seconds, kernel times) of every timed repetition of exactly `steps` steps; the first is `value`
     job = last_stats = None
     for rep in range(max(1, reps)):
@@ -178,9 +181,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         t_start = time.perf_counter()
         job_r, last_r = pipeline(steps)
         if rk.dist:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
-            stats_dev.copy_(torch.from_numpy(job_r.astype(np.int64)))
-            dist.all_reduce(stats_dev)
-            job_r = stats_dev.cpu().numpy().astype(np.uint64)
+            job_r = reduce_stats(job_r, device=red_dev)
         fence()
         elapsed = time.perf_counter() - t_start
         if rk.dist:
