@@ -131,9 +131,11 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
 
     d2h_bytes = [0]
     form = ["stage_reads"]
+    host_s = [0.0, 0.0]  # seconds this rank's thread spent in the staging call (packing, enqueueing) / waiting in the fetch
 
     def submit(i):
         s = i % N_SLOTS
+        t_in = time.perf_counter()
         if form[0] == "stage_reads":
             # fem_dev_map_batch_submit (include/fem_hip.h): the caller's batch is packed to two bits per base into the slot's
             # pinned staging by the library's host threads, sent, expanded on the device; everything behind it asynchronous
@@ -143,11 +145,14 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             dev.commit_stage(batch, L, slot=s, uniform=True)
         # ("resident": the slot's batch is in HBM already, nothing is sent)
         dev.map_staged(e=e, a=a, k=k, step=step, slot=s)
+        host_s[0] += time.perf_counter() - t_in
 
     def retire(i):
         if form[0] == "resident":
             return dev.fetch_stats(slot=i % N_SLOTS)  # nothing but the counters comes back
+        t_in = time.perf_counter()
         r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
+        host_s[1] += time.perf_counter() - t_in
         d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
         return r.stats
 
@@ -175,9 +180,11 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     h2d_bytes, sent_packed = dev.stage_info(0)
     runs = []  # (elapsed seconds, kernel times) of every timed repetition of exactly `steps` steps; the first is `value`
     job = last_stats = None
+    host_first = None
     for rep in range(max(1, reps)):
         dev.reset_timing()
         fence()
+        host_s[0] = host_s[1] = 0.0
         t_start = time.perf_counter()
         job_r, last_r = pipeline(steps)
         if rk.dist:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
@@ -191,6 +198,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         runs.append((elapsed, {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}))
         if rep == 0:
             job, last_stats = job_r, last_r
+            host_first = (host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps)
     dev.set_timing(False)
     elapsed, kt = runs[0]
 
@@ -301,6 +309,12 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_bytes[0],
         "zero_copy_ascii_mreads": round(zero_copy, 3), "zero_copy_h2d_bytes_per_step": int(h2d_zero_copy),
         "priming_steps": priming,
+        # what this rank's host thread does per step: the staging call (2-bit packing of the batch on the library's threads,
+        # enqueueing the copies and kernels) and the wait inside the fetch (device not done yet, or results on their way);
+        # packing reads batch x L bytes of host memory and writes a quarter of that
+        "host_ms_per_step": {"stage_call": round(host_first[0], 3), "fetch_wait": round(host_first[1], 3),
+                             "stage_threads": int(os.environ.get("FEM_STAGE_THREADS", "12")),
+                             "host_read_gb_per_s_while_packing": round(batch * L / max(host_first[0], 1e-6) / 1e6, 1)},
         "counters": {"reads": int(job[0]), "mapped_reads": int(job[1]), "pre_filter": int(job[2]),
                      "candidates": int(job[3]), "mappings": int(job[4])},
         "counters_last_step_per_gpu": [int(x) for x in last_stats],
@@ -573,7 +587,7 @@ def main():
         "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
                                                            "reads_per_step_per_gpu", "kernel_ms_per_launch", "kernel_ms_alone", "counters_last_step_per_gpu",
                                                            "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step",
-                                                           "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps")}
+                                                           "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps", "host_ms_per_step", "spread")}
                                  for k_, v_ in results.items()},
     }
     if cpu_c3[0] is not None:
