@@ -874,27 +874,39 @@ int refresh_dense(fem_dev *h) {
     while (sq + 1u < h->n_seq && goff[sq + 1u] <= first) ++sq;
     blkseq[b] = sq;
   }
+  // These tables are optional (4 bytes per occurrence: 4 GB at 3 Gbp): a failed allocation declines the dense form —
+  // the 64-bit hash-join form of seed_fast_kernel runs without them — instead of failing the upload.
   uint32_t *d_bad = nullptr;
-  HIP_TRY(h, hipMalloc((void **)&h->d_goff, goff.size() * sizeof(uint32_t)));
-  HIP_TRY(h, hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)));
-  HIP_TRY(h, hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)));
-  HIP_TRY(h, hipMalloc((void **)&d_bad, sizeof(uint32_t)));
-  HIP_TRY(h, hipMemset(d_bad, 0, sizeof(uint32_t)));
-  HIP_TRY(h, hipMemcpy(h->d_goff, goff.data(), goff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIP_TRY(h, hipMemcpy(h->d_blkseq, blkseq.data(), blkseq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  auto decline = [&]() {
+    for (void *q : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)d_bad})
+      if (q) (void)hipFree(q);
+    h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr;
+    (void)hipGetLastError();  // (clears the out-of-memory error)
+    return FEM_OK;
+  };
+  if (hipMalloc((void **)&h->d_goff, goff.size() * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&h->d_freq11, (size_t)femk::kX11 * 4u * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&d_bad, sizeof(uint32_t)) != hipSuccess)
+    return decline();
+  if (hipMemset(d_bad, 0, sizeof(uint32_t)) != hipSuccess ||
+      hipMemcpy(h->d_goff, goff.data(), goff.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_blkseq, blkseq.data(), blkseq.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)decline();
+    return fail(h, FEM_ERR_HIP, "dense tables: copy to the device failed");
+  }
   hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq,
                      h->d_occ32, d_bad);
-  HIP_TRY(h, hipGetLastError());
   uint32_t bad = 0;
-  HIP_TRY(h, hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost));
-  (void)hipFree(d_bad);
-  if (bad) {  // the index names sequences the reference does not have: leave that to the 64-bit path's checks
-    (void)hipFree(h->d_occ32);
-    h->d_occ32 = nullptr;
-    return FEM_OK;
+  if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)decline();
+    return fail(h, FEM_ERR_HIP, "dense tables: building the 32-bit occurrence table failed");
   }
+  if (bad) return decline();  // the index names sequences the reference does not have: leave that to the 64-bit path's checks
+  (void)hipFree(d_bad);
+  d_bad = nullptr;
   // byte frequencies per 11-mer for seed_select_kernel (fem_seed_select.hip.h)
-  HIP_TRY(h, hipMalloc((void **)&h->d_freq11, (size_t)femk::kX11 * 4u * sizeof(uint32_t)));
   hipLaunchKernelGGL(femk::freq11_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, h->d_freq11);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());
@@ -1306,8 +1318,8 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
   for (unsigned t = 0; t < n_thr; ++t) max_len = std::max(max_len, t_max[t]), min_len = std::min(min_len, t_min[t]);
   // ---- reads of one length: two bits per base cross the link instead of eight ----
-  const char *np = getenv("FEM_NO_PACK");
-  if (n && min_len == max_len && max_len > 0 && n_bases < 0xFFFFFFF0ull && !(np && np[0] == '1')) {
+  static const bool no_pack = [] { const char *np = getenv("FEM_NO_PACK"); return np && np[0] == '1'; }();  // (read once, not per batch)
+  if (n && min_len == max_len && max_len > 0 && n_bases < 0xFFFFFFF0ull && !no_pack) {
     const uint32_t len = max_len, bpr = (len + 3u) / 4u;
     const uint64_t code_bytes = (n * bpr + 7u) & ~7ull;
     const uint64_t exc_cap = (n_bases + 64 - std::min<uint64_t>(code_bytes, n_bases + 64)) / 5u;  // what is left of the staging buffer
@@ -1650,7 +1662,7 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   if (rc) return fail(h, rc, err);
   if (h->timing) {
     for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;
-    h->t_ms[7] += ms_text, h->t_n[7] += 1;
+    if (wait) h->t_ms[7] += ms_text, h->t_n[7] += 1;  // (without the wait no elapsed time is read: nothing to count)
   }
   out->text = text.text, out->len = text.len, out->n_asserted = text.n_asserted;
   out->n_reads = t.n_reads, out->n_records = t.n_records;

@@ -446,7 +446,8 @@ int map_main(int argc, char **argv) {
       if (!it.t && !it.b) break;
       if (it.b) {  // text rendered on the device: one stretch of the library's pinned memory
         const int wrc = fem_dev_sam_wait(devs[(size_t)it.b->gpu], it.b->slot);  // the copy of the text to the host has arrived
-        if (wrc && !exit_code.exchange(EXIT_FAILURE)) dev_fail(devs[(size_t)it.b->gpu], "SAM text", wrc);
+        // (this thread must not read the handle's error string, which the GPU's worker thread may be writing: the code says enough)
+        if (wrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] SAM text failed: %s\n", fem_strerror(wrc));
         double t0 = real_time();
         bool ok = wrc != 0 || it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
         if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
