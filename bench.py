@@ -9,7 +9,7 @@ it is already under torch.distributed.run (RANK / WORLD_SIZE in the environment)
 One step = one batch of `--batch` (2.5 M) synthetic reads through the DEVICE PIPELINE of libfemhip.so:
     the caller's batch in ordinary host memory --fem_dev_map_batch_submit: packed to 2 bits per base into pinned
     staging by the library's host threads, H2D, expanded--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
-with three batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
+with four batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
 `value`, `ms_per_step` and `roofline` all come from the SAME workload, the headline one: C3 (100 bp, e=3, 3 Gbp
 reference: the HBM-resident configuration SURVEY.md 8d calls bandwidth-relevant; 20 steps x 2.5 M = BASELINE's 50 M
 reads).  `value` is the first timed run of exactly K steps; `spread` has min / median / max over that run and
@@ -44,7 +44,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (a device copy reaches ~6.3 TB/s)
-N_SLOTS, DEPTH = 4, 3  # batch slots of the library, batches in flight
+N_SLOTS = 4  # batch slots of the library
+# batches in flight: all four slots (a dense index has the device work on two batches at once — the selection of one beside
+# the join of the previous — so three in flight left the host one batch short now and then: 225-250 against 248-258 Mreads/s)
+DEPTH = int(os.environ.get("FEM_BENCH_DEPTH", "4"))
 PRIME_TO = 12          # untimed batches a workload has seen before its timed steps (warm-up included), at least
 
 WORKLOADS = {
