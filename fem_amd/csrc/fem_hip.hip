@@ -705,13 +705,9 @@ int launch_batch(fem_dev *h, Slot &s) {
         if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
         uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         if (overlap) per_cu = 1;  // (3.3 ms per 2.5 M reads of C3 with one block per CU as with five: sectors per second, not waves)
-        static const int sel_cap = getenv("FEM_SELECT_BLOCKS_PER_CU") ? atoi(getenv("FEM_SELECT_BLOCKS_PER_CU")) : 0;
-        if (sel_cap > 0) per_cu = std::min<uint64_t>(per_cu, (uint64_t)sel_cap);
         select_lds = lds_bytes, select_threads = 64u * wpb;
         if (overlap && h->have_select_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_select_done, 0));
-        uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
-        static const int sel_grid = getenv("FEM_SELECT_GRID") ? atoi(getenv("FEM_SELECT_GRID")) : 0;
-        if (sel_grid > 0) grid = std::min<uint32_t>(grid, (uint32_t)sel_grid);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
         rc = timed(8, s.stream, [&] { launch_select(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
         if (rc) return rc;
@@ -735,11 +731,7 @@ int launch_batch(fem_dev *h, Slot &s) {
           const uint32_t vj = (kernel_regs(R, true) + 7u) & ~7u, vs = (kernel_regs(R, false) + 7u) & ~7u;
           const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
           while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lds_bytes + select_lds > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
-          static const bool dbg = getenv("FEM_DEBUG") != nullptr;
-          if (dbg) fprintf(stderr, "[femhip] overlap: join regs %u select regs %u, join lds %u select lds %u -> %llu join blocks per CU\n", vj, vs, lds_bytes, select_lds, (unsigned long long)per_cu);
         }
-        static const int join_cap = getenv("FEM_JOIN_BLOCKS_PER_CU") ? atoi(getenv("FEM_JOIN_BLOCKS_PER_CU")) : 0;
-        if (join_cap > 0) per_cu = std::min<uint64_t>(per_cu, (uint64_t)join_cap);
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
         rc = timed(0, s.stream, [&] { launch_join(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
