@@ -31,6 +31,12 @@ namespace femk {
 #define FEM_JOIN_SLOTS_HI 32768u
 #endif
 constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
+// Chunks whose LDS steps are issued together at R >= 7 (see join_read): one — with the 80 registers of six waves per SIMD
+// five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134)
+#ifndef FEM_JOIN_BATCH_HI
+#define FEM_JOIN_BATCH_HI 1
+#endif
+
 constexpr uint32_t join_bitmap_words(int R) { return join_slots(R) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
 
 __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
@@ -234,43 +240,13 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
         val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
         if (long_lists) hv[R - 1] = hv[R - 1] <= max_u ? hv[R - 1] : kDenseSent;
-        // ---- insert: all of the unit's atomics back to back ----
-        uint32_t hit[R], hhit[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) hit[t] = insert(val[t]), hhit[t] = 0;
-        if (long_lists) {
-#pragma unroll
-          for (int t = 0; t < R; ++t) hhit[t] = insert(hv[t]);
-        }
-        // a slot that took a second value (every true hit does): chunk by chunk, only where some lane saw one
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-          if (__builtin_amdgcn_ballot_w64(hit[t] != 0u)) mark(val[t], hit[t]);
-        }
-        if (long_lists) {
-#pragma unroll
-          for (int t = 0; t < R; ++t) {
-            if (__builtin_amdgcn_ballot_w64(hhit[t] != 0u)) mark(hv[t], hhit[t]);
-          }
-        }
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 2
-        {
-          uint32_t hh = 0;
-          for (int t = 0; t < R; ++t) hh |= hit[t];
-          if (hh == 0x12345u) n_flag = 1;
-          continue;
-        }
-#endif
-        wave_sync_lds();
-        // ---- flag: a neighbouring slot is present.  All window reads first, then the flagged values are compacted
-        //      into the group's array ----
-        uint32_t x[R], hx[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) x[t] = window(val[t]), hx[t] = 0;
-        if (long_lists) {
-#pragma unroll
-          for (int t = 0; t < R; ++t) hx[t] = window(hv[t]);
-        }
+        // ---- insert, then flag (a neighbouring slot is present: the flagged values are compacted into the group's array).
+        //      In batches of kBatch chunks: all of a batch's atomics back to back, its marks, later all of a batch's window
+        //      reads before the first is used.  At R <= 6 a batch is the whole unit; above, one chunk — what a batch holds
+        //      in registers (at R = 5 batches of 1, 2, 3 or 5 chunks run within 3 % of each other: the kernel is bound by
+        //      instruction issue, not by the LDS round trips) (hit bits, window words) decides whether the kernel fits the 80 registers of six waves per SIMD,
+        //      i.e. whether five of its blocks or four sit on a CU beside seed_select_kernel ----
+        constexpr int kBatch = R <= 6 ? R : FEM_JOIN_BATCH_HI;
         auto flag_chunk = [&](uint32_t v, uint32_t xw) {
           const bool near = (xw & 5u) != 0u && v < kDenseVLimit;
           const uint64_t m = __builtin_amdgcn_ballot_w64(near);
@@ -279,12 +255,41 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
           if (near) flg_g[pos] = v;
           n_flag += (uint32_t)__popcll(m);
         };
+        auto insert_all = [&](uint32_t (&vals)[R]) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) flag_chunk(val[t], x[t]);
-        if (long_lists) {
+          for (int t0 = 0; t0 < R; t0 += kBatch) {
+            uint32_t hit[kBatch];
 #pragma unroll
-          for (int t = 0; t < R; ++t) flag_chunk(hv[t], hx[t]);
-        }
+            for (int q = 0; q < kBatch; ++q)
+              if (t0 + q < R) hit[q] = insert(vals[t0 + q]);
+            // a slot that took a second value (every true hit does): chunk by chunk, only where some lane saw one
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+              if (t0 + q < R) {
+                if (__builtin_amdgcn_ballot_w64(hit[q] != 0u)) mark(vals[t0 + q], hit[q]);
+              }
+          }
+        };
+        auto flag_all = [&](uint32_t (&vals)[R]) {
+#pragma unroll
+          for (int t0 = 0; t0 < R; t0 += kBatch) {
+            uint32_t x[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+              if (t0 + q < R) x[q] = window(vals[t0 + q]);
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+              if (t0 + q < R) flag_chunk(vals[t0 + q], x[q]);
+          }
+        };
+        insert_all(val);
+        if (long_lists) insert_all(hv);
+#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 2
+        continue;
+#endif
+        wave_sync_lds();
+        flag_all(val);
+        if (long_lists) flag_all(hv);
         wave_sync_lds();
         {  // leave the bitmap clean: every lane clears its 16-byte pieces (the guard word sits behind them)
           uint4 *b4 = (uint4 *)bitmap;
@@ -435,8 +440,9 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
 #define FEM_JOIN_WAVES_LO 7
 #endif
 #ifndef FEM_JOIN_WAVES_HI
-#define FEM_JOIN_WAVES_HI 5
+#define FEM_JOIN_WAVES_HI 6
 #endif
+
 constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_WAVES_HI; }
 // Registers: six blocks of this kernel (R <= 6) share a CU with one block of the next batch's seed_select_kernel (80
 // registers): 6 x 72 + 80 = 512 per lane and SIMD.  (amdgpu_num_vgpr is not honoured by this compiler; the budget follows
