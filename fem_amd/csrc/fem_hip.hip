@@ -371,7 +371,8 @@ femk::SeedLayout make_layout_fast(const fem_params &p, uint32_t max_len, bool ha
 
 // LDS of one wave of seed_select_kernel (fem_seed_select.hip.h): the block's read offsets, the sub-block's two 2-bit
 // streams, one frequency byte per seed, strand and phase group, the per-read words.  The reads of a block are worked
-// on `nb` at a time, as many as a budget of 2 KB of frequency bytes holds (the kernel runs beside seed_join_kernel, whose
+// on `nb` at a time, as many as a budget of 3 KB of 16-bit frequencies holds (a block of four waves then stays within the
+// 16 KB that six blocks of the join leave of a CU's LDS) (the kernel runs beside seed_join_kernel, whose
 // bitmaps want the LDS).
 femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   femk::SeedLayout l{};
@@ -379,8 +380,8 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
   // a phase group's DP takes at most kSelMaxCols columns: groups of more than kSelMaxCols - 1 + 4 R seeds go to the generic kernel
   const uint32_t g_max = std::min<uint32_t>((l.smax + 2u) / 3u, femk::kSelMaxCols - 1u + 4u * R);
-  l.gstride = ((g_max + 3u) & ~3u) + 4u;
-  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 2048u / (6u * l.gstride)));
+  l.gstride = ((g_max + 3u) & ~3u) + 4u;  // (entries of 16 bits)
+  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 3100u / (6u * 2u * l.gstride)));
   l.strm_words = (l.nb * max_len + 15u) / 16u + 2u;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) {
@@ -391,7 +392,7 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   l.rb = take((femk::kReadBlock + 2u) * 8u);
   l.rinfo = take(4u * femk::kReadBlock * 4u);
   l.strm = take(2u * l.strm_words * 4u);
-  l.fq = take(l.nb * 6u * l.gstride + 64u);
+  l.fq = take(l.nb * 6u * l.gstride * 2u + 256u);  // (+ what an idle lane of the last group reads past its array)
   l.wave_bytes = o;
   return l;
 }
@@ -730,7 +731,8 @@ int launch_batch(fem_dev *h, Slot &s) {
           // handed out in eights), LDS (160 KB) and wave slots (8 per SIMD) of both kernels together
           const uint32_t vj = (kernel_regs(R, true) + 7u) & ~7u, vs = (kernel_regs(R, false) + 7u) & ~7u;
           const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
-          while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lds_bytes + select_lds > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
+          const uint32_t lj = (lds_bytes + 511u) & ~511u, ls = (select_lds + 511u) & ~511u;  // (LDS is handed out in pieces of 512 bytes)
+          while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lj + ls > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
         }
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);

@@ -15,7 +15,7 @@
 //     smallest value: one wave min/max instead of sort + merge.  Anything else takes the exact general path
 //     (dense_merge_group below).
 //
-// Reads the two kernels cannot finish (a list over 128 entries or a bucket of 255 and more, more than 64 flagged values in
+// Reads the two kernels cannot finish (a list over 128 entries or a bucket of 65 535 and more, more than 64 flagged values in
 // a group, a DP wider than 64 columns, a == 0) are queued for the generic seed_filter_kernel; results are identical
 // either way.
 #pragma once

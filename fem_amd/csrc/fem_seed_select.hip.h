@@ -13,12 +13,14 @@
 //     j reads ONE dword of it — X = the seed's last eleven bases when j is even, its first eleven when j is odd — and
 //     has the frequency of seed j on the forward strand and of its reverse complement (seed S-1-j of the reverse
 //     strand).  89 four-byte lane-loads in 45 sectors per 100-base read instead of 178 eight-byte ones in 178 sectors.
-//     lookup[h] itself is fetched for the 6 R selected seeds only.  A frequency of 255 or more sends the read to the
-//     generic kernel (never on BASELINE's references: their buckets hold 60 +- 8 entries).
+//     lookup[h] itself is fetched for the 6 R selected seeds only.  A byte that reads 255 ("255 or more": never on
+//     BASELINE's references, whose buckets hold 60 +- 8 entries; a real genome's repeats) has the lane fetch the exact
+//     frequency from the lookup table; the DP works on 16-bit frequencies, and only a bucket of 65 535 entries or more
+//     sends the read to the generic kernel.
 //   * ONE LANE PER PHASE GROUP.  The DP table of a group is R rows by C - 1 <= 64 columns.  A lane walks it column by
-//     column with the R running row values in registers; the frequencies it needs for a column are byte b of R
-//     consecutive dwords of the group's byte array (seed index = column + 4 (row - 1)), so four columns cost one LDS
-//     read.  Six cells' worth of vector instructions per cell, 64 groups (ten reads) at a time, against one DPP
+//     column with the R running row values in registers; the frequencies it needs for a column are R 16-bit LDS reads
+//     off one address (seed index = column + 4 (row - 1)).  Five vector instructions per cell, 64 groups (ten reads)
+//     at a time, against one DPP
 //     prefix-min chain per row and group before.  Take bits are shifted into per-row masks; the traceback, the
 //     frequency sort (a sorting network on frequency << 14 | traceback order << 10 | start: stable by construction)
 //     and the lookup of the selected seeds' list bases stay in the lane.
@@ -77,39 +79,34 @@ __device__ __forceinline__ uint32_t rc_hash(uint32_t hf, uint32_t nm) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The seed-selection DP of one phase group in one lane (src/filter.c:3-28).  F = the group's frequencies, one byte per
+// The seed-selection DP of one phase group in one lane (src/filter.c:3-28).  F = the group's frequencies, 16 bits per
 // seed; ncols = C - 1 of this lane's group (0: idle lane), maxcols = the largest in the wave.  Column c (0-based)
 // of row r (0-based) uses seed c + 4 r.  take[r] receives the take bits: column c at bit iters - 1 - c.
 // ---------------------------------------------------------------------------------------------------------
 template <int R, bool WIDE>
-__device__ __forceinline__ void select_dp(const uint8_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&tlo)[R],
+__device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&tlo)[R],
                                           uint32_t (&thi)[R], uint32_t &m_last, uint32_t &iters) {
-  uint32_t M[R], W[R];
+  uint32_t M[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) M[r] = inf, tlo[r] = 0, thi[r] = 0, W[r] = *(const uint32_t *)(F + 4 * r);
-  const uint32_t n_grp = (maxcols + 3u) >> 2;
-  for (uint32_t cg = 0; cg < n_grp; ++cg) {
-    const uint32_t w_next = *(const uint32_t *)(F + 4u * (cg + (uint32_t)R));
+  for (int r = 0; r < R; ++r) M[r] = inf, tlo[r] = 0, thi[r] = 0;
+  for (uint32_t c = 0; c < maxcols; ++c) {
+    uint32_t f[R];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const bool in = 4u * cg + (uint32_t)b < ncols;
-      uint32_t up = 0;  // M[0][c] = 0
+    for (int r = 0; r < R; ++r) f[r] = F[c + 4u * (uint32_t)r];  // (one address, R immediate offsets)
+    const bool in = c < ncols;
+    uint32_t up = 0;  // M[0][c] = 0
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t v = up + __builtin_amdgcn_ubfe(W[r], 8u * (uint32_t)b, 8u);  // uint32 wrap as in the reference
-        const bool take = in && v < M[r];  // strict: ties go horizontal (src/filter.c:20); M[r][0] = inf (src/filter.c:9)
-        M[r] = take ? v : M[r];
-        up = M[r];
-        if (WIDE) thi[r] = (thi[r] << 1) | (tlo[r] >> 31);
-        tlo[r] = (tlo[r] << 1) | (uint32_t)take;
-      }
+    for (int r = 0; r < R; ++r) {
+      const uint32_t v = up + f[r];      // uint32 wrap as in the reference
+      const bool take = in && v < M[r];  // strict: ties go horizontal (src/filter.c:20); M[r][0] = inf (src/filter.c:9)
+      M[r] = take ? v : M[r];
+      up = M[r];
+      if (WIDE) thi[r] = (thi[r] << 1) | (tlo[r] >> 31);
+      tlo[r] = (tlo[r] << 1) | (uint32_t)take;
     }
-#pragma unroll
-    for (int r = 0; r + 1 < R; ++r) W[r] = W[r + 1];
-    W[R - 1] = w_next;
   }
   m_last = M[R - 1];
-  iters = 4u * n_grp;
+  iters = maxcols;
 }
 
 #ifndef FEM_SELECT_WAVES
@@ -128,7 +125,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
   uint64_t *boff = (uint64_t *)(wbase + p.lay.rb);    // offsets of the block's reads (kReadBlock + 1)
   uint32_t *fw = (uint32_t *)(wbase + p.lay.strm);    // the sub-block's bases, 2 bits each (N as A), 16 per big-endian word
   uint32_t *nw = fw + p.lay.strm_words;               // ... and its N marks (3 = not one of ACGT)
-  uint8_t *fq = wbase + p.lay.fq;                     // [read][strand][phase][gstride] frequencies, one byte per seed
+  uint16_t *fq = (uint16_t *)(wbase + p.lay.fq);      // [read][strand][phase][gstride] frequencies, 16 bits per seed
   uint32_t *r_base = (uint32_t *)(wbase + p.lay.rinfo), *r_len = r_base + kReadBlock, *r_flag = r_len + kReadBlock,
            *r_pre = r_flag + kReadBlock;              // per read of the sub-block
   constexpr uint32_t kOk0 = 1u, kOk1 = 2u, kShape = 4u, kSlow = 8u;
@@ -267,23 +264,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
             uint32_t i, j, S;
             if (place(w0 + (uint32_t)(u * kWave) + ln, i, j, S)) {
               const uint32_t sh = (j & 1u) * 16u;
-              const uint32_t f_fwd = (d[u] >> sh) & 255u;
+              uint32_t f_fwd = (d[u] >> sh) & 255u;
               uint32_t f_rev = (d[u] >> (sh + 8u)) & 255u;
-              if (has_n) {
+              bool rev_own = false;
+              uint32_t hf = 0, nm = 0;
+              if (has_n || f_fwd == 255u || f_rev == 255u) {
                 const uint32_t pos = r_base[i] + j;
-                const uint32_t nm = stream_window(nw, pos) >> 8;
-                if (nm != 0u) {  // the reverse strand counts N as A after complementing: its own hash
-                  const uint32_t hr = rc_hash(stream_window(fw, pos) >> 8, nm);
-                  const uint32_t df = p.lookup[hr + 1u] - p.lookup[hr];
-                  f_rev = df < 255u ? df : 255u;
-                }
+                hf = stream_window(fw, pos) >> 8;
+                if (has_n) nm = stream_window(nw, pos) >> 8;
+                rev_own = nm != 0u;  // the reverse strand counts N as A after complementing: its own hash
+              }
+              if (f_fwd == 255u) f_fwd = p.lookup[hf + 1u] - p.lookup[hf];  // "255 or more": the exact count
+              if (rev_own || f_rev == 255u) {
+                const uint32_t hr = rc_hash(hf, nm);
+                f_rev = p.lookup[hr + 1u] - p.lookup[hr];
               }
               const uint32_t jr = S - 1u - j;
               const uint32_t gi = __umulhi(j, 0x55555556u), gr = __umulhi(jr, 0x55555556u);  // / 3
-              uint8_t *row = fq + (size_t)i * 6u * gstride;
-              row[(j - 3u * gi) * gstride + gi] = (uint8_t)f_fwd;
-              row[(3u + jr - 3u * gr) * gstride + gr] = (uint8_t)f_rev;
-              if (f_fwd == 255u || f_rev == 255u) atomicOr(&r_flag[i], kSlow);
+              uint16_t *row = fq + (size_t)i * 6u * gstride;
+              row[(j - 3u * gi) * gstride + gi] = (uint16_t)(f_fwd < 0xFFFFu ? f_fwd : 0xFFFFu);
+              row[(3u + jr - 3u * gr) * gstride + gr] = (uint16_t)(f_rev < 0xFFFFu ? f_rev : 0xFFFFu);
+              if (f_fwd >= 0xFFFFu || f_rev >= 0xFFFFu) atomicOr(&r_flag[i], kSlow);  // (16 bits do not hold it: generic kernel)
             }
           }
         }
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         const bool valid = read_ok && ((fl >> strand) & 1u);
         const uint32_t ncols = valid ? (S - si) / 3u - (uint32_t)(R * kLg) + 1u : 0u;
         const uint32_t maxcols = wave_max_u32(ncols);
-        const uint8_t *F = fq + ((size_t)i_c * 6u + u) * gstride;
+        const uint16_t *F = fq + ((size_t)i_c * 6u + u) * gstride;
         uint32_t key[R];  // frequency << 14 | traceback order << 10 | start, per selected seed
 #pragma unroll
         for (int t = 0; t < R; ++t) key[t] = (uint32_t)t << 10;  // a seed that was never taken is all zero (see below)
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
               } else {
                 col -= __builtin_ctzll(seg);
                 const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
-                key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + 3u * idx);
+                key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + 3u * idx);  // (65 534 << 14 fits)
               }
             }
           }
