@@ -1312,7 +1312,10 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
   for (unsigned t = 0; t < n_thr; ++t) max_len = std::max(max_len, t_max[t]), min_len = std::min(min_len, t_min[t]);
   // ---- reads of one length: two bits per base cross the link instead of eight ----
-  static const bool no_pack = [] { const char *np = getenv("FEM_NO_PACK"); return np && np[0] == '1'; }();  // (read once, not per batch)
+  // (test hook, read per batch on purpose: tests/test_gpu_packed.py switches it between two batches of one handle; one
+  // getenv per batch of >= 10^4 reads is not measurable)
+  const char *np = getenv("FEM_NO_PACK");
+  const bool no_pack = np && np[0] == '1';
   if (n && min_len == max_len && max_len > 0 && n_bases < 0xFFFFFFF0ull && !no_pack) {
     const uint32_t len = max_len, bpr = (len + 3u) / 4u;
     const uint64_t code_bytes = (n * bpr + 7u) & ~7ull;
