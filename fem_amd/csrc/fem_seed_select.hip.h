@@ -2,7 +2,7 @@
 // hash_all_seeds_in_sequence + the frequency lookups + generate_optimal_prefix_qgram_for_group_seeding + the stable
 // qsort of the selected seeds (reference src/utils.h:83-117, src/index.h:22-28, src/filter.c:3-43,146-204), for both
 // strands of every read.  Its output — per read and (strand, phase group) the R selected seeds in run order as
-// (lookup[h], start | frequency << 16) — is what seed_join_kernel (fem_seed_dense.hip.h) walks the lists of.
+// (lookup[h], start | frequency << 16) — is what seed_join_kernel (fem_seed_join.hip.h) walks the lists of.
 //
 // Why a kernel of its own: inside the wave-per-read kernel this front end used 6..60 of the 64 lanes and 178 random
 // 8-byte table reads per read, each of which moves a 64-byte sector across the fabric.  Here the work is laid out so
@@ -20,8 +20,7 @@
 //   * ONE LANE PER PHASE GROUP.  The DP table of a group is R rows by C - 1 <= 64 columns.  A lane walks it column by
 //     column with the R running row values in registers; the frequencies it needs for a column are R 16-bit LDS reads
 //     off one address (seed index = column + 4 (row - 1)).  Five vector instructions per cell, 64 groups (ten reads)
-//     at a time, against one DPP
-//     prefix-min chain per row and group before.  Take bits are shifted into per-row masks; the traceback, the
+//     at a time, against one DPP prefix-min chain per row and group before.  Take bits are shifted into per-row masks; the traceback, the
 //     frequency sort (a sorting network on frequency << 14 | traceback order << 10 | start: stable by construction)
 //     and the lookup of the selected seeds' list bases stay in the lane.
 #pragma once
