@@ -203,7 +203,7 @@ struct fem_dev {
   // reference
   uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
-  uint8_t *d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint8_t *d_planes = nullptr;  // femk::plane_window
   uint8_t *d_ref_raw = nullptr;  // the characters as uploaded (the traceback and MD compare and print them)
   uint64_t ref_bytes = 0;
   uint64_t *d_seq_off = nullptr;
@@ -673,7 +673,7 @@ int launch_batch(fem_dev *h, Slot &s) {
     if (!overlap && h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
     femk::VerifyParams vp{};
     vp.bases = s.bases(), vp.read_off = s.d_off;
-    vp.plane[0] = h->d_plane[0], vp.plane[1] = h->d_plane[1], vp.plane[2] = h->d_plane[2], vp.seq_off = h->d_seq_off;
+    vp.planes = h->d_planes, vp.seq_off = h->d_seq_off;
     vp.cand = s.d_cand, vp.cand_meta = s.d_meta;
     vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
     vp.ed = s.d_ed, vp.end = s.d_end;
@@ -1089,8 +1089,7 @@ int fem_dev_close(fem_dev *h) {
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
-                  (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_plane[0], (void *)h->d_plane[1],
-                  (void *)h->d_plane[2], (void *)h->d_plane[3], (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
+                  (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_planes, (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
                   (void *)h->d_freq11})
     if (p) (void)hipFree(p);
   delete h;
@@ -1133,11 +1132,10 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     h->seq_off[i] = total;
     total += seq_len[i];
   }
-  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_plane[0],
-                  (void *)h->d_plane[1], (void *)h->d_plane[2], (void *)h->d_plane[3]})
+  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_planes})
     if (p) (void)hipFree(p);
   h->d_ref = nullptr, h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
-  h->d_plane[0] = h->d_plane[1] = h->d_plane[2] = h->d_plane[3] = nullptr;
+  h->d_planes = nullptr;
   // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
   HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 128));
   HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 128));
@@ -1157,12 +1155,9 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
   }
   {  // bit planes of the codes, 64 bases of slack (code 4) included
     const uint64_t n_pb = (total + 64 + 7) / 8;
-    for (int q = 0; q < 4; ++q) {
-      HIP_TRY(h, hipMalloc((void **)&h->d_plane[q], n_pb + 16));
-      HIP_TRY(h, hipMemset(h->d_plane[q], 0, n_pb + 16));
-    }
-    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, h->d_ref_raw, n_pb,
-                       h->d_plane[0], h->d_plane[1], h->d_plane[2], h->d_plane[3]);
+    HIP_TRY(h, hipMalloc((void **)&h->d_planes, femk::plane_bytes(n_pb)));
+    HIP_TRY(h, hipMemset(h->d_planes, 0, femk::plane_bytes(n_pb)));
+    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, h->d_ref_raw, n_pb, h->d_planes);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipDeviceSynchronize());
   }
@@ -1527,7 +1522,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   femt::TailInput in{};
   in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
-  for (int q = 0; q < 4; ++q) in.plane[q] = h->d_plane[q];
+  in.planes = h->d_planes;
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
   femt::TailOutput t{};
@@ -1643,7 +1638,7 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   femt::TailInput in{};
   in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
-  for (int q = 0; q < 4; ++q) in.plane[q] = h->d_plane[q];
+  in.planes = h->d_planes;
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
   femt::TailOutput t{};

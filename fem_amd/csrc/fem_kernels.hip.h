@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fem_planes.hip.h"
 
 namespace femk {
 
@@ -1050,7 +1051,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
 struct VerifyParams {
   const uint8_t *bases;       // 16 bytes of padding in front of the batch's characters, 64 behind
   const uint64_t *read_off;
-  const uint8_t *plane[3];    // bit planes of the base codes 0..4, all sequences concatenated (see verify_kernel)
+  const uint8_t *planes;      // bit planes of the base codes 0..4, all sequences concatenated (plane_window; see verify_kernel)
   const uint64_t *seq_off;
   const uint64_t *cand;
   const uint32_t *cand_meta;
@@ -1065,6 +1066,10 @@ __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p) {
   uint4 w;
   __builtin_memcpy(&w, p, 16);
   return w;
+}
+
+__device__ __forceinline__ uint4 plane_window(const uint8_t *planes, int q, uint64_t at) {  // fem_planes.hip.h
+  return load_u128_unaligned(plane_addr(planes, q, at));
 }
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
   uint32_t w;
@@ -1158,7 +1163,7 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
     const int n_steps = (L + 15) >> 4;
     // the reverse strand's chunk comes from the far end; the last, partial one may start in front of the read
     auto text_chunk = [&](int col) { return load_u128_unaligned(strand == 0 ? rd + col : rd + (L - 16 - col)); };
-    auto plane_chunk = [&](int q, int col) { return load_u128_unaligned(p.plane[q] + ((pat + (uint32_t)col) >> 3)); };
+    auto plane_chunk = [&](int q, int col) { return plane_window(p.planes, q, (pat + (uint32_t)col) >> 3); };
     uint4 P0 = make_uint4(0, 0, 0, 0), P1 = P0, P2 = P0, P0n = P0, P1n = P0, P2n = P0;
     if (n_steps > 0) {
       P0n = plane_chunk(0, 0), P1n = plane_chunk(1, 0), P2n = plane_chunk(2, 0);
@@ -1269,20 +1274,24 @@ __global__ void __launch_bounds__(256) count_mappings_kernel(CountParams p) {
 // bit q of code(text[i]) -> bit i of plane q (q = 0..2); plane 3: the character as uploaded is none of "ACGTN" (lower
 // case, IUPAC codes: it then equals no read character the device traceback compares it with).  One thread per byte of
 // the planes (eight bases).
-__global__ void ref_planes_kernel(const uint8_t *codes, const uint8_t *raw, uint64_t n_bytes, uint8_t *p0, uint8_t *p1,
-                                  uint8_t *p2, uint8_t *p3) {
+__global__ void ref_planes_kernel(const uint8_t *codes, const uint8_t *raw, uint64_t n_bytes, uint8_t *planes) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += stride) {
     uint64_t w, r;
     __builtin_memcpy(&w, codes + 8 * b, 8);
     __builtin_memcpy(&r, raw + 8 * b, 8);
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    uint32_t o[4] = {0, 0, 0, 0};
     for (int k = 0; k < 8; ++k) {
       const uint32_t c = (uint32_t)(w >> (8 * k)) & 0xFFu, ch = (uint32_t)(r >> (8 * k)) & 0xFFu;
-      o0 |= (c & 1u) << k, o1 |= ((c >> 1) & 1u) << k, o2 |= ((c >> 2) & 1u) << k;
-      o3 |= (uint32_t)(ch != ((0x4E54474341ull >> (8u * c)) & 0xFFu)) << k;  // "ACGTN"[code]
+      o[0] |= (c & 1u) << k, o[1] |= ((c >> 1) & 1u) << k, o[2] |= ((c >> 2) & 1u) << k;
+      o[3] |= (uint32_t)(ch != ((0x4E54474341ull >> (8u * c)) & 0xFFu)) << k;  // "ACGTN"[code]
     }
-    p0[b] = (uint8_t)o0, p1[b] = (uint8_t)o1, p2[b] = (uint8_t)o2, p3[b] = (uint8_t)o3;
+    // byte b of a plane sits in group b / 16 and, as that group's look-ahead, behind the sixteen bytes of group b / 16 - 1
+    const uint64_t g = b >> 4, r16 = b & 15u;
+    for (int q = 0; q < 4; ++q) {
+      planes[g * kPlaneGroup + (uint32_t)q * 32u + r16] = (uint8_t)o[q];
+      if (g) planes[(g - 1) * kPlaneGroup + (uint32_t)q * 32u + 16u + r16] = (uint8_t)o[q];
+    }
   }
 }
 

@@ -1,6 +1,7 @@
 // fem_tail.hip — device mapping tail: kernels + the host-side driver behind fem_dev_fetch_records.
 // See fem_tail.hip.h for what is computed and the reference lines it follows.
 #include "fem_tail.hip.h"
+#include "fem_planes.hip.h"
 
 #include <cstring>  // before rocprim: its headers use memcpy unqualified
 
@@ -35,7 +36,7 @@ struct Params {
   uint32_t n_reads;
   const uint8_t *ref_raw;
   uint64_t ref_bytes;
-  const uint8_t *plane[4];
+  const uint8_t *planes;
   const uint64_t *seq_off;
   const uint64_t *cand;
   const uint8_t *ed;
@@ -62,7 +63,7 @@ struct Params {
   const uint32_t *ovf_queue;  // overflow pass: the records to redo, staged at index * cap
   uint32_t *ovf_out;          // first pass: where overflowing records are queued
   uint32_t *rec_list;         // records trace_ident_kernel left to the walking kernels (ctl[3] of them); nullptr = all
-  uint32_t *src_slot;         // per record: 0 = first-pass staging, else 1 + index in the overflow staging
+  uint32_t *src_slot;         // per record: 0 = first-pass staging, kSlotDiagonal | L = `L M` (MD in the first-pass staging), else 1 + index in the overflow staging
   uint32_t *n_ops, *n_md;
   uint16_t *flag;
   uint32_t *tid, *pos0;
@@ -548,116 +549,126 @@ __global__ void __launch_bounds__(64) trace_kernel(Params p) {
 // waves per CU here, and the walk is a chain of dependent LDS reads that only more waves can hide: a low plane of
 // P0 words and, where needed, a high plane of P1 words; column c of lane l sits at [c * lanes + l] of each.
 // ---------------------------------------------------------------------------------------------------------
-// Traceback, pass zero: records with edit distance 0.  generate_alignment first compares the read with the reference
-// at its end position character by character (src/align.c:285-300) and, with no mismatch, emits `L M` without any
-// recurrence.  A zero-edit record (a quarter to a third of the records of the BASELINE workloads) almost always is
-// such a match — unless a reference character is lower case / IUPAC or the read has a non-canonical character, which
-// Myers (on codes) takes for equal and the character comparison does not.  One lane per record, no LDS: read
-// characters sixteen at a time (decoded to code-bit masks), the reference from its bit planes, compared on the one
-// diagonal.  Every other record (ed > 0, or a zero-edit record that is no character-exact match) is appended to
-// rec_list for the walking kernels.
+// Traceback, pass zero: records whose alignment is the end position's diagonal — no recurrence, no walk.
+//  * Edit distance 0: generate_alignment first compares the read with the reference at its end position character by
+//    character (src/align.c:285-300) and, with no mismatch, emits `L M`.
+//  * Edit distance ed > 0 with exactly ed mismatching columns on that diagonal (every record of a read whose errors
+//    are substitutions: most of a real sequencer's).  The walk of src/align.c:340-479 then never leaves the diagonal:
+//    ed is the least cost of any path into (L-1, end), so no path reaches a cell (t, j) of the diagonal for less than
+//    the mismatches before it (it would continue down the diagonal for less than ed), D[t][j] is that count, D0 — "the
+//    diagonal step costs nothing" — is set exactly in the columns that match, and the walk tests match, then
+//    mismatch, before it looks at HP.  It emits M runs only (the 'S' pseudo-run of mismatches at the read's end folds
+//    into the M run behind it; L > ed keeps that run from being the only one): CIGAR `L M`, start = end - L + 1, MD
+//    from the mismatching columns.  tests/test_traceback_model.py checks that claim on the matrix model.
+// Both need character equality to be code equality: no reference character of the window outside "ACGTN" (plane[3]),
+// no non-canonical read character on the forward strand (the reverse strand's complement table turns them into N).
+// One lane per record, no LDS: read characters sixteen at a time (decoded to code-bit masks), the reference from its
+// bit planes, compared on the one diagonal; MD written as the columns go by (a record that turns out to have more
+// mismatches than ed is walked later and its MD written again).  Every other record is appended to rec_list for the
+// walking kernels.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lsb_mask4(uint32_t bytes01) {  // bytes of 0/1 -> their four bits, byte 0 in bit 0
   return ((bytes01 & 0x01010101u) * 0x01020408u) >> 24;
 }
+__device__ __forceinline__ uint32_t md_number(uint8_t *md, uint32_t at, uint32_t v) {  // decimal of v < 10000 -> md[at ...]
+  const uint32_t digits = v >= 1000u ? 4u : v >= 100u ? 3u : v >= 10u ? 2u : 1u;
+  for (uint32_t k = digits; k-- > 0; v /= 10u) md[at + k] = (uint8_t)('0' + v % 10u);
+  return at + digits;
+}
+constexpr uint32_t kSlotDiagonal = 0x80000000u;
 constexpr uint32_t kIdentChunk = 1024;  // records one block classifies at a time (four per thread)
 __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
-  __shared__ uint32_t lst[kIdentChunk], walk[kIdentChunk];
-  __shared__ uint32_t cnt, n_walk, walk_base;
+  __shared__ uint32_t walk[kIdentChunk];
+  __shared__ uint32_t n_walk, walk_base;
   const int sh = 2 * p.e;
-  // Records for the walking kernels gather in LDS and go out with ONE atomic on the list's cursor per chunk (one per
-  // wave cost 1.3 ms per 8.6 M records: same-address atomics complete at ~10 ns each).
-  auto flush_walk = [&]() {
+  for (uint32_t base = blockIdx.x * kIdentChunk; base < p.n_records; base += gridDim.x * kIdentChunk) {
+    __syncthreads();
+    if (threadIdx.x == 0) n_walk = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t k = 0; k < kIdentChunk / 256u; ++k) {
+      const uint32_t rec = base + k * 256u + threadIdx.x;
+      if (rec >= p.n_records) continue;
+      bool done = false;
+      const uint32_t misc = p.s_misc[rec];
+      const uint32_t read = p.s_read[rec];
+      const uint64_t cand = p.s_cand[rec];
+      const int end = (int16_t)(misc & 0xFFFFu);
+      const uint32_t ed = (misc >> 16) & 0xFFu;
+      const uint32_t dir = (misc >> 24) & 1u;
+      const uint64_t off = p.read_off[read];
+      const int L = (int)(p.read_off[read + 1] - off);
+      const uint8_t *fwd = p.bases + off;
+      const uint32_t tid = (uint32_t)(cand >> 32);
+      const int start = end - L + 1;
+      const uint32_t digits = L >= 1000 ? 4u : L >= 100 ? 3u : L >= 10 ? 2u : 1u;
+      // MD: at most ed reference characters and ed + 1 numbers
+      if (start >= 0 && start <= sh && L > (int)ed && L < 10000 && p.ops_cap >= 1u && (ed + 1u) * digits + ed <= p.md_cap) {
+        const uint64_t ref0 = p.seq_off[tid] + (uint32_t)cand + (uint32_t)start;  // compared with text[0]
+        const uint32_t complement = dir ? 0x03030303u : 0u;
+        const uint32_t bit0 = (uint32_t)ref0 & 7u;
+        uint8_t *md = p.t_md + (size_t)rec * p.md_cap;
+        uint32_t odd_ref = 0, odd_text = 0, n_mm = 0, n_md = 0;
+        int last = -1;  // the column of the last mismatch
+        uint4 W0{}, W1{}, W2{}, W3{};
+        for (int col = 0; col < L; col += 16) {
+          const int sub = (col >> 4) % 7;  // 7 (bit offset) + 16 * 7 <= 128: one load per plane covers seven steps
+          if (sub == 0) {
+            const uint64_t at = (ref0 + (uint32_t)col) >> 3;
+            W0 = load_u128_unaligned(femk::plane_addr(p.planes, 0, at)), W1 = load_u128_unaligned(femk::plane_addr(p.planes, 1, at));
+            W2 = load_u128_unaligned(femk::plane_addr(p.planes, 2, at)), W3 = load_u128_unaligned(femk::plane_addr(p.planes, 3, at));
+          }
+          const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
+          const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
+                                 dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
+          const int ncol = L - col < 16 ? L - col : 16;
+          uint32_t m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t cw, nw, odd;
+            decode4(w[q], complement, cw, nw, odd);
+            const int nb = ncol - 4 * q;
+            odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
+            m0 |= lsb_mask4(cw) << (4 * q), m1 |= lsb_mask4(cw >> 1) << (4 * q), m2 |= lsb_mask4(nw) << (4 * q);
+          }
+          const uint32_t wbit = bit0 + 16u * (uint32_t)sub;  // (ref0 + 112 k) & 7 == ref0 & 7
+          const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);
+          odd_ref |= bits_at(W3, wbit) & colmask;
+          const uint32_t b0 = bits_at(W0, wbit), b1 = bits_at(W1, wbit), b2 = bits_at(W2, wbit);
+          uint32_t diff = ((b0 ^ m0) | (b1 ^ m1) | (b2 ^ m2)) & colmask;
+          while (diff) {  // generate_MD_tag over an M run (src/align.c:515-529): the matches counted, the reference's character
+            const uint32_t i = (uint32_t)__builtin_ctz(diff);
+            const int at = col + (int)i;
+            diff &= diff - 1u;
+            if (++n_mm > ed) break;
+            if (at - last > 1) n_md = md_number(md, n_md, (uint32_t)(at - last - 1));
+            // the character from its code (it is one of "ACGTN", or odd_ref sends the record to the walk): no load
+            const uint32_t code = ((b0 >> i) & 1u) | (((b1 >> i) & 1u) << 1);
+            md[n_md++] = (uint8_t)((b2 >> i) & 1u ? 'N' : 0x54474341u >> (8u * code));
+            last = at;
+          }
+          if (n_mm > ed) break;
+        }
+        if (n_mm == ed && odd_ref == 0u && !(dir == 0 && odd_text)) {
+          if (L - 1 - last > 0) n_md = md_number(md, n_md, (uint32_t)(L - 1 - last));
+          const uint32_t rank = rec - p.rec_begin[read];
+          p.flag[rec] = (uint16_t)((dir ? 16u : 0u) | (rank ? 256u : 0u));
+          p.tid[rec] = tid;
+          p.pos0[rec] = (uint32_t)start + (uint32_t)cand;
+          p.nm[rec] = (uint8_t)ed;
+          p.n_ops[rec] = 1u, p.n_md[rec] = n_md;
+          p.src_slot[rec] = kSlotDiagonal | (uint32_t)L;  // CIGAR `L M`: compact_kernel writes it from this word
+          done = true;
+        }
+      }
+      if (!done) walk[atomicAdd(&n_walk, 1u)] = rec;
+    }
+    // Records for the walking kernels gather in LDS and go out with ONE atomic on the list's cursor per chunk (one per
+    // wave cost 1.3 ms per 8.6 M records: same-address atomics complete at ~10 ns each).
     __syncthreads();
     if (threadIdx.x == 0) walk_base = n_walk ? atomicAdd(&p.ctl[3], n_walk) : 0u;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_walk; i += 256u) p.rec_list[walk_base + i] = walk[i];
-    __syncthreads();
-    if (threadIdx.x == 0) n_walk = 0;
-    __syncthreads();
-  };
-  for (uint32_t base = blockIdx.x * kIdentChunk; base < p.n_records; base += gridDim.x * kIdentChunk) {
-    __syncthreads();
-    if (threadIdx.x == 0) cnt = 0, n_walk = 0;
-    __syncthreads();
-    // ---- classify: zero-edit records into the block's list (so that the comparison below runs on full waves),
-    //      the others into the walking kernels' list ----
-#pragma unroll
-    for (uint32_t k = 0; k < kIdentChunk / 256u; ++k) {
-      const uint32_t rec = base + k * 256u + threadIdx.x;
-      if (rec < p.n_records) {
-        if (((p.s_misc[rec] >> 16) & 0xFFu) == 0u) lst[atomicAdd(&cnt, 1u)] = rec;
-        else walk[atomicAdd(&n_walk, 1u)] = rec;
-      }
-    }
-    flush_walk();
-    const uint32_t n_zero = cnt;
-    for (uint32_t i0 = 0; i0 < n_zero; i0 += 256u) {
-      const uint32_t i = i0 + threadIdx.x;
-      const bool active = i < n_zero;
-      const uint32_t rec = active ? lst[i] : 0u;
-      bool done = false;
-      if (active) {
-        const uint32_t misc = p.s_misc[rec];
-        const uint32_t read = p.s_read[rec];
-        const uint64_t cand = p.s_cand[rec];
-        const int end = (int16_t)(misc & 0xFFFFu);
-        const uint32_t dir = (misc >> 24) & 1u;
-        const uint64_t off = p.read_off[read];
-        const int L = (int)(p.read_off[read + 1] - off);
-        const uint8_t *fwd = p.bases + off;
-        const uint32_t tid = (uint32_t)(cand >> 32);
-        const int start = end - L + 1;
-        const uint32_t digits = L >= 1000 ? 4u : L >= 100 ? 3u : L >= 10 ? 2u : 1u;
-        if (start >= 0 && start <= sh && L >= 1 && L < 10000 && p.ops_cap >= 1u && digits <= p.md_cap) {
-          const uint64_t ref0 = p.seq_off[tid] + (uint32_t)cand + (uint32_t)start;  // compared with text[0]
-          const uint32_t complement = dir ? 0x03030303u : 0u;
-          const uint32_t bit0 = (uint32_t)ref0 & 7u;
-          uint32_t diff = 0, odd_text = 0;
-          uint4 W0{}, W1{}, W2{}, W3{};
-          for (int col = 0; col < L; col += 16) {
-            const int sub = (col >> 4) % 7;  // 7 (bit offset) + 16 * 7 <= 128: one load per plane covers seven steps
-            if (sub == 0) {
-              const uint64_t at = (ref0 + (uint32_t)col) >> 3;
-              W0 = load_u128_unaligned(p.plane[0] + at), W1 = load_u128_unaligned(p.plane[1] + at);
-              W2 = load_u128_unaligned(p.plane[2] + at), W3 = load_u128_unaligned(p.plane[3] + at);
-            }
-            const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
-            const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
-                                   dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
-            const int ncol = L - col < 16 ? L - col : 16;
-            uint32_t m0 = 0, m1 = 0, m2 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              uint32_t cw, nw, odd;
-              decode4(w[k], complement, cw, nw, odd);
-              const int nb = ncol - 4 * k;
-              odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
-              m0 |= lsb_mask4(cw) << (4 * k), m1 |= lsb_mask4(cw >> 1) << (4 * k), m2 |= lsb_mask4(nw) << (4 * k);
-            }
-            const uint32_t wbit = bit0 + 16u * (uint32_t)sub;  // (ref0 + 112 k) & 7 == ref0 & 7
-            const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);
-            diff |= ((bits_at(W0, wbit) ^ m0) | (bits_at(W1, wbit) ^ m1) | (bits_at(W2, wbit) ^ m2) | bits_at(W3, wbit)) & colmask;
-          }
-          if (diff == 0u && !(dir == 0 && odd_text)) {
-            const uint32_t rank = rec - p.rec_begin[read];
-            p.t_ops[(size_t)rec * p.ops_cap] = ((uint32_t)L << 4);  // L M
-            uint8_t *md = p.t_md + (size_t)rec * p.md_cap;
-            uint32_t v = (uint32_t)L;
-            for (uint32_t k = digits; k-- > 0; v /= 10u) md[k] = (uint8_t)('0' + v % 10u);
-            p.flag[rec] = (uint16_t)((dir ? 16u : 0u) | (rank ? 256u : 0u));
-            p.tid[rec] = tid;
-            p.pos0[rec] = (uint32_t)start + (uint32_t)cand;
-            p.nm[rec] = 0;
-            p.n_ops[rec] = 1u, p.n_md[rec] = digits;
-            p.src_slot[rec] = 0u;
-            done = true;
-          }
-        }
-      }
-      if (active && !done) walk[atomicAdd(&n_walk, 1u)] = rec;  // (at most n_zero <= kIdentChunk of them)
-    }
-    flush_walk();
   }
 }
 
@@ -718,7 +729,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
     // in front).  Loads are issued one step (text) / one stretch (planes) ahead of their use.
     const uint32_t complement = dir ? 0x03030303u : 0u;
     auto text_chunk = [&](int c) { return load_u128_unaligned(dir == 0 ? fwd + c : fwd + (L - 16 - c)); };
-    auto plane_chunk = [&](int q, int c) { return load_u128_unaligned(p.plane[q] + ((pat_abs + (uint32_t)c) >> 3)); };
+    auto plane_chunk = [&](int q, int c) { return load_u128_unaligned(femk::plane_addr(p.planes, q, (pat_abs + (uint32_t)c) >> 3)); };
     const uint32_t pat_bit = (uint32_t)pat_abs & 7u;
     const int n_steps = (L + 15) >> 4;
     uint32_t vp = 0, vn = 0, ident = 1u, odd_text = 0;
@@ -945,11 +956,16 @@ struct CompactParams {
 __global__ void __launch_bounds__(256) compact_kernel(CompactParams p) {
   const uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x;
   if (rec >= p.n_records) return;
-  const uint32_t slot = p.src_slot[rec];
-  const uint32_t *ops = slot ? p.o_ops + (size_t)(slot - 1u) * p.o_ops_cap : p.t_ops + (size_t)rec * p.ops_cap;
-  const uint8_t *md = slot ? p.o_md + (size_t)(slot - 1u) * p.o_md_cap : p.t_md + (size_t)rec * p.md_cap;
+  uint32_t slot = p.src_slot[rec];
   const uint32_t no = p.n_ops[rec], nm = p.n_md[rec], co = p.cigar_off[rec], mo = p.md_off[rec];
-  for (uint32_t i = 0; i < no; ++i) p.cigar[co + i] = ops[i];
+  if (slot & kSlotDiagonal) {  // trace_ident_kernel's records: one M run over the whole read
+    p.cigar[co] = (slot & ~kSlotDiagonal) << 4;
+    slot = 0;
+  } else {
+    const uint32_t *ops = slot ? p.o_ops + (size_t)(slot - 1u) * p.o_ops_cap : p.t_ops + (size_t)rec * p.ops_cap;
+    for (uint32_t i = 0; i < no; ++i) p.cigar[co + i] = ops[i];
+  }
+  const uint8_t *md = slot ? p.o_md + (size_t)(slot - 1u) * p.o_md_cap : p.t_md + (size_t)rec * p.md_cap;
   for (uint32_t i = 0; i < nm; ++i) p.md[mo + i] = md[i];
 }
 
@@ -1284,7 +1300,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   Params p{};
   p.bases = in.bases, p.read_off = in.read_off, p.n_reads = n;
   p.ref_raw = in.ref_raw, p.ref_bytes = in.ref_bytes, p.seq_off = in.seq_off;
-  for (int q = 0; q < 4; ++q) p.plane[q] = in.plane[q];
+  p.planes = in.planes;
   p.cand = in.cand, p.ed = in.ed, p.end = in.end, p.cand_begin = in.cand_begin, p.cand_count = in.cand_count;
   p.e = in.e, p.n_records = nr;
   p.rec_begin = m.rec_begin.as<uint32_t>();

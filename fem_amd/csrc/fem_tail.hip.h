@@ -19,7 +19,7 @@ struct TailInput {  // device pointers unless noted
   uint32_t max_len;            // host: longest read of the batch
   const uint8_t *ref_raw;      // raw reference characters (case kept: the traceback compares characters, src/align.c:355)
   uint64_t ref_bytes;          // host: bytes in ref_raw, its slack included
-  const uint8_t *plane[4];     // bit planes over the reference: code bits 0..2, and "character is none of ACGTN"
+  const uint8_t *planes;       // bit planes over the reference (femk::plane_window): code bits 0..2, and "character is none of ACGTN"
   const uint64_t *seq_off;
   const uint64_t *cand;        // per candidate slot
   const uint8_t *ed;           // 0xFF = rejected

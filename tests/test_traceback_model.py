@@ -186,7 +186,7 @@ def cigar_str(cigar):
 @pytest.mark.parametrize("e", [1, 2, 3, 5, 7])
 def test_model_walk_equals_the_oracle_traceback(e):
     rng = np.random.default_rng(900 + e)
-    n = n_indel = n_folded = 0
+    n = n_indel = n_folded = n_diagonal = 0
     for trial in range(700):
         L = int(rng.integers(30, 161))
         ref = util.rand_seq(rng, L + 4 * e + 8)
@@ -226,7 +226,14 @@ def test_model_walk_equals_the_oracle_traceback(e):
             n_folded += 1
         n += 1
         n_indel += any(op != "M" for op, _ in m_cig)
-    assert n > 500 and n_indel > 60, (n, n_indel, n_folded)
+        # what trace_ident_kernel relies on (fem_amd/csrc/fem_tail.hip): ed mismatching columns on the end position's
+        # diagonal, characters standing for their codes -> the walk stays on that diagonal and emits `L M`
+        d0 = end - L + 1
+        canonical = all(c in b"ACGTN" for c in read) and all(c in b"ACGTN" for c in ref[d0:d0 + L]) if d0 >= 0 else False
+        if canonical and L > ed and sum(code(ref[d0 + i]) != code(read[i]) for i in range(L)) == ed:
+            assert m_cig == [("M", L)] and m_start == d0, (e, trial, ref, read, ed, end, m_cig)
+            n_diagonal += 1
+    assert n > 500 and n_indel > 60 and n_diagonal > 150, (n, n_indel, n_folded, n_diagonal)
 
 
 def test_model_walk_equals_the_oracle_on_the_repeat_fixture_records():
