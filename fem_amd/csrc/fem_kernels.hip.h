@@ -1107,12 +1107,13 @@ __device__ __forceinline__ void decode4(uint32_t chars, uint32_t complement, uin
   code = (c ^ complement) & ~(nflag * 3u);  // complement = 0x03030303 on the reverse strand (3 - code); N stays N
 }
 
-// 32 bits of a 128-bit little-endian bit string starting at bit `at` (at + 32 <= 128)
-__device__ __forceinline__ uint32_t bits_at(const uint4 &w, uint32_t at) {
-  const uint32_t k = at >> 5;
-  const uint32_t lo = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
-  const uint32_t hi = k == 0 ? w.y : k == 1 ? w.z : w.w;  // unused when k == 3 (then at & 31 == 0 is required)
-  return __builtin_amdgcn_alignbit(hi, lo, at & 31u);
+// The plane windows are consumed sixteen bits at a time: the 32 bits at bit `off` (< 32) of the window's head, and the
+// window moving on by sixteen bits — four v_alignbit per plane and step.  (Indexing the window's words by the step made
+// the compiler keep the windows in scratch memory: six scratch loads per step in the verify kernel.)
+__device__ __forceinline__ uint32_t window_head(const uint4 &w, uint32_t off) { return __builtin_amdgcn_alignbit(w.y, w.x, off); }
+__device__ __forceinline__ void window_advance16(uint4 &w) {
+  w.x = __builtin_amdgcn_alignbit(w.y, w.x, 16u), w.y = __builtin_amdgcn_alignbit(w.z, w.y, 16u);
+  w.z = __builtin_amdgcn_alignbit(w.w, w.z, 16u), w.w >>= 16;
 }
 
 // One column (src/align.c:118-133).  B0..B2: the step's plane windows; m0..m2: the read base's code bits as masks;
@@ -1185,10 +1186,11 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
           const int nc = col + 16 * kStepsPerPlaneLoad;
           P0n = plane_chunk(0, nc), P1n = plane_chunk(1, nc), P2n = plane_chunk(2, nc);
         }
+      } else {
+        window_advance16(P0), window_advance16(P1), window_advance16(P2);
       }
-      // window of this step: pattern[col .. col + 16 + 2e), bit j <-> pattern[col + j]
-      const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat + 96 k) & 7 == pat & 7
-      const uint32_t b0 = bits_at(P0, wbit), b1 = bits_at(P1, wbit), b2 = bits_at(P2, wbit);
+      // window of this step: pattern[col .. col + 16 + 2e), bit j <-> pattern[col + j]; (pat + 96 k) & 7 == pat & 7
+      const uint32_t b0 = window_head(P0, pat_bit), b1 = window_head(P1, pat_bit), b2 = window_head(P2, pat_bit);
       uint32_t cw[4], nw[4];
       {
         const uint32_t w0 = strand ? __builtin_bswap32(r.w) : r.x, w1 = strand ? __builtin_bswap32(r.z) : r.y;

@@ -277,12 +277,13 @@ __device__ __forceinline__ void decode4(uint32_t chars, uint32_t complement, uin
   const uint32_t ze = chars ^ expect, zn = chars ^ 0x4E4E4E4Eu;
   odd = (((ze & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | ze) & (((zn & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zn) & 0x80808080u;
 }
-// 32 bits of a 128-bit little-endian bit string starting at bit `at` (at <= 96)
-__device__ __forceinline__ uint32_t bits_at(const uint4 &w, uint32_t at) {
-  const uint32_t k = at >> 5;
-  const uint32_t lo = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
-  const uint32_t hi = k == 0 ? w.y : k == 1 ? w.z : w.w;
-  return __builtin_amdgcn_alignbit(hi, lo, at & 31u);
+// The plane windows are consumed sixteen bits at a time: the 32 bits at bit `off` (< 32) of the window's head, and the
+// window moving on by sixteen bits — four v_alignbit per plane and step.  (Indexing the window's words by the step made
+// the compiler keep the windows in scratch memory: six scratch loads per step in the verify kernel.)
+__device__ __forceinline__ uint32_t window_head(const uint4 &w, uint32_t off) { return __builtin_amdgcn_alignbit(w.y, w.x, off); }
+__device__ __forceinline__ void window_advance16(uint4 &w) {
+  w.x = __builtin_amdgcn_alignbit(w.y, w.x, 16u), w.y = __builtin_amdgcn_alignbit(w.z, w.y, 16u);
+  w.z = __builtin_amdgcn_alignbit(w.w, w.z, 16u), w.w >>= 16;
 }
 constexpr int kStepsPerPlaneLoad = 6;  // 7 (bit offset) + 16 * 5 + 16 + 2 * 7 (band) bits <= 128
 
@@ -617,6 +618,8 @@ __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
             const uint64_t at = (ref0 + (uint32_t)col) >> 3;
             W0 = load_u128_unaligned(femk::plane_addr(p.planes, 0, at)), W1 = load_u128_unaligned(femk::plane_addr(p.planes, 1, at));
             W2 = load_u128_unaligned(femk::plane_addr(p.planes, 2, at)), W3 = load_u128_unaligned(femk::plane_addr(p.planes, 3, at));
+          } else {
+            window_advance16(W0), window_advance16(W1), window_advance16(W2), window_advance16(W3);
           }
           const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
           const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
@@ -631,10 +634,9 @@ __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
             odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
             m0 |= lsb_mask4(cw) << (4 * q), m1 |= lsb_mask4(cw >> 1) << (4 * q), m2 |= lsb_mask4(nw) << (4 * q);
           }
-          const uint32_t wbit = bit0 + 16u * (uint32_t)sub;  // (ref0 + 112 k) & 7 == ref0 & 7
-          const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);
-          odd_ref |= bits_at(W3, wbit) & colmask;
-          const uint32_t b0 = bits_at(W0, wbit), b1 = bits_at(W1, wbit), b2 = bits_at(W2, wbit);
+          const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);  // ((ref0 + 112 k) & 7 == ref0 & 7)
+          odd_ref |= window_head(W3, bit0) & colmask;
+          const uint32_t b0 = window_head(W0, bit0), b1 = window_head(W1, bit0), b2 = window_head(W2, bit0);
           uint32_t diff = ((b0 ^ m0) | (b1 ^ m1) | (b2 ^ m2)) & colmask;
           while (diff) {  // generate_MD_tag over an M run (src/align.c:515-529): the matches counted, the reference's character
             const uint32_t i = (uint32_t)__builtin_ctz(diff);
@@ -732,7 +734,8 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
     auto plane_chunk = [&](int q, int c) { return load_u128_unaligned(femk::plane_addr(p.planes, q, (pat_abs + (uint32_t)c) >> 3)); };
     const uint32_t pat_bit = (uint32_t)pat_abs & 7u;
     const int n_steps = (L + 15) >> 4;
-    uint32_t vp = 0, vn = 0, ident = 1u, odd_text = 0;
+    uint32_t vp = 0, vn = 0, odd_text = 0, dm = 0;
+    int last_bad = -1;  // the last column whose characters differ on the end position's diagonal (-1: the read is identical there)
     uint4 rw = make_uint4(0, 0, 0, 0), W0 = rw, W1 = rw, W2 = rw, W3 = rw, W0n = rw, W1n = rw, W2n = rw, W3n = rw;
     if (n_steps > 0) {
       rw = text_chunk(0);
@@ -749,7 +752,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       vn = x & hp;
       vp = hn | ~(x | hp);
       const uint32_t same = eq & ~__builtin_amdgcn_ubfe(bw, q, (uint32_t)W);  // the characters themselves are equal
-      ident &= same >> start;
+      dm |= __builtin_amdgcn_ubfe(same, (uint32_t)start, 1u) << q;  // this step's columns that are equal on the end position's diagonal
       // What the walk asks of a cell is one of four things: match (D0 and equal characters), mismatch (not D0),
       // insertion (D0, unequal, HP), deletion (D0, unequal, not HP) — two bits per diagonal, as planes
       // P = match | deletion and Q = match | insertion (so: D0 = P | Q, equal characters = P & Q, HP where it matters = Q).
@@ -764,10 +767,12 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
           const int nc = col + 16 * kStepsPerPlaneLoad;
           W0n = plane_chunk(0, nc), W1n = plane_chunk(1, nc), W2n = plane_chunk(2, nc), W3n = plane_chunk(3, nc);
         }
+      } else {
+        window_advance16(W0), window_advance16(W1), window_advance16(W2), window_advance16(W3);
       }
       if (step + 1 < n_steps) rw = text_chunk(col + 16);
-      const uint32_t wbit = pat_bit + 16u * (uint32_t)sub;  // (pat_abs + 96 k) & 7 == pat_abs & 7
-      const uint32_t b0 = bits_at(W0, wbit), b1 = bits_at(W1, wbit), b2 = bits_at(W2, wbit), bw = bits_at(W3, wbit);
+      // ((pat_abs + 96 k) & 7 == pat_abs & 7)
+      const uint32_t b0 = window_head(W0, pat_bit), b1 = window_head(W1, pat_bit), b2 = window_head(W2, pat_bit), bw = window_head(W3, pat_bit);
       odd_ref |= bw;
       const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
                              dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
@@ -795,6 +800,9 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
           column((uint32_t)col, (uint32_t)q, b0, b1, b2, bw, 0u - (cb & 1u), 0u - ((cb >> 1) & 1u), 0u - (nb & 1u));
         }
       }
+      const uint32_t bad = ~dm & (ncol == 16 ? 0xFFFFu : (1u << ncol) - 1u);
+      if (bad) last_bad = col + 31 - (int)__builtin_clz(bad);
+      dm = 0;
     }
     if (dir == 0 && odd_text) punt = true;  // a read character outside "ACGTN": character equality is not code equality
 
@@ -824,14 +832,19 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
     };
     bool broken = false;
     uint32_t lead = 0;  // leading read bases the walk never visited: exact matches when no odd reference character is near
-    if (!punt && (ident & 1u)) {  // src/align.c:294-300
+    if (!punt && last_bad < 0) {  // src/align.c:294-300
       push_op(kOpM, (uint32_t)L);
       push_number((uint32_t)L);
     } else if (!punt) {
       // ---- walk back (src/align.c:340-440); pe == t + bit throughout ----
       int bit = start, t = L - 1, n_err = 0;
       uint32_t cur_op = kOpS, cur_n = 1;
-      {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
+      // Behind the last column that differs on the end position's diagonal the walk only matches (equal characters
+      // set D0, and match is the first thing it tests): it starts at that column with the M run already counted.
+      const uint32_t trail = (uint32_t)(L - 1 - last_bad);
+      if (trail) {
+        t = last_bad, cur_op = kOpM, cur_n = trail;
+      } else {  // the first step replaces the initial pseudo-run (src/align.c:345-368)
         const HistT h = hist.get((uint32_t)t) >> bit;
         const bool pp = (uint32_t)h & 1u, qq = (uint32_t)(h >> W) & 1u;
         const bool d = pp || qq, same = pp && qq, horiz = qq;
@@ -897,7 +910,9 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
               i = lead < n ? lead : n;
               run += i, rp += (int)i, tp += i;
             }
-            for (; i < n; ++i, ++rp, ++tp) {
+            // the rightmost run ends in `trail` matches the walk never visited either (k == 0: it is that run)
+            const uint32_t n_walked = k == 0 && trail ? (n > trail ? n - trail : 0u) : n;
+            for (; i < n_walked; ++i, ++rp, ++tp) {
               const HistT hd = hist.get(tp) >> diag;
               if ((uint32_t)hd & (uint32_t)(hd >> W) & 1u) {  // equal characters = P & Q
                 ++run;
@@ -906,6 +921,7 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
                 push_md(pattern[rp]);
               }
             }
+            if (i < n) run += n - i, rp += (int)(n - i), tp += n - i;
           } else if (op == kOpI) {
             tp += n;
           } else {
