@@ -9,7 +9,7 @@
 // values of the unit's multiset lie in [v, v+e], so a bitmap over slots of 8 positions finds the few values that can
 // have a partner and the filter is evaluated exactly on those — but is built to retire as few instructions as that
 // idea allows (the round-2 join ran the vector, scalar and LDS ports at 73 / 74 / 58 % at once):
-//   * ONE bit per slot, 32 Ki slots (64 Ki at R >= 7): slot and bit of a value are two shifts, and the three slots a
+//   * ONE bit per slot, 32 Ki slots (FEM_JOIN_SLOTS_HI: 64 Ki at R >= 7 was slower): slot and bit of a value are two shifts, and the three slots a
 //     within-e partner can sit in come out of one two-word read + v_alignbit.  A value is flagged when a neighbouring
 //     slot is present.  A slot hit TWICE is seen by its second value only (the returning atomic); that lane then sets
 //     both neighbours' bits, which flags the slot's first value like any other neighbour would (and, harmlessly,
@@ -119,9 +119,6 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     const uint32_t *w = bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits);
     return __builtin_amdgcn_alignbit(w[1], w[0], qm & 31u);
   };
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 0
-  if (s_alo != 0x12345u) return true;
-#endif
   prefetch(0);
   uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
   uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
@@ -232,10 +229,6 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
           }
         }
       }
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 1
-      if (val[0] + val[R - 1] == 0x12345u) n_flag = 1;  // (keeps the loads alive)
-      any_u = false;
-#endif
       if (any_u) {
         // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
         val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
@@ -284,9 +277,6 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         };
         insert_all(val);
         if (long_lists) insert_all(hv);
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 2
-        continue;
-#endif
         wave_sync_lds();
         flag_all(val);
         if (long_lists) flag_all(hv);
@@ -300,10 +290,6 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         if (n_flag > kFlagCap) return false;
       }
     }
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 3
-    if (n_flag == 0x12345u) cmin = 0;
-    continue;
-#endif
     if (kSecondProbe && n_flag > kProbeMin) {
       // ---- second probe: most of the flagged values are chance flags — values whose slot or a neighbouring one was
       //      also hit by a value 2^kPeriodBits k positions away.  The flagged values alone go through the (clean again)
@@ -344,10 +330,6 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       n_flag = c0 + (uint32_t)__popcll(m1);
       wave_sync_lds();
     }
-#if defined(FEM_JOIN_ABLATE) && FEM_JOIN_ABLATE == 4
-    if (n_flag == 0x12345u) cmin = 0;
-    continue;
-#endif
     if (n_flag > (uint32_t)p.a) {
       // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
       const bool have = ln < n_flag;
