@@ -66,6 +66,37 @@ def test_records_equal_oracle(dev, e, L, repeat):
         assert np.any((want.cig & 0xF) == 1) and np.any((want.cig & 0xF) == 2), "fixture must contain I and D"
 
 
+@pytest.mark.parametrize("e,L", [(3, 100), (7, 150), (2, 64)])
+def test_substitution_only_reads_and_the_diagonal_shortcut(dev, e, L):
+    # trace_ident_kernel finishes a record whose ed edits are all mismatches on the end position's diagonal without the
+    # recurrence (CIGAR `L M`, MD from the mismatching columns): reads with 0..e substitutions, some at the first and
+    # last base, some adjacent, some an N in the read or over an N / lower-case base of the reference, both strands
+    rng = np.random.default_rng(9100 + e)
+    s0 = bytearray(util.rand_seq(rng, 120_000))
+    s0[40_000:40_030] = b"N" * 30
+    s0[70_000:70_400] = bytes(s0[70_000:70_400]).lower()
+    seqs = [bytes(s0), util.rand_seq(rng, 60_000)]
+    nxt = {65: 67, 67: 71, 71: 84, 84: 65}
+    reads = []
+    for i in range(400):
+        sq = seqs[i % 2]
+        where = (39_990, 69_990, 70_100)[i % 3] + int(rng.integers(0, 60)) if i % 7 == 0 and sq is seqs[0] else int(rng.integers(0, len(sq) - L))
+        r = bytearray(sq[where:where + L].upper())
+        k = int(rng.integers(0, e + 1))
+        at = set(int(x) for x in rng.integers(0, L, k))
+        if i % 5 == 0 and k:
+            at = set(list(at)[:max(0, k - 2)]) | ({0, L - 1} if i % 10 == 0 else {L // 2, L // 2 + 1})
+        for x in sorted(at)[:e]:
+            r[x] = 78 if i % 13 == 0 else nxt.get(r[x], 65)
+        r = bytes(r)
+        reads.append(fo.revcomp(r) if i % 2 else r)
+    want, got = run_both(dev, seqs, reads, e)
+    assert want.stats[4] > 300
+    n_ops = np.diff(want.cig_off.astype(np.int64))
+    assert (n_ops == 1).sum() > 250 and (want.r_nm[n_ops == 1] > 0).sum() > 100, "fixture must hold mismatch-only records"
+    assert_same_records(want, got)
+
+
 def test_thousands_of_mappings_per_read(dev):
     # one unit ~1500 times: reads with far more mappings than the ordering kernel keeps in LDS, several radix levels
     rng = np.random.default_rng(77)
