@@ -198,6 +198,10 @@ struct fem_dev {
   // dense indexes: occurrence table in 32-bit global coordinates + its sequence tables (fem_seed_dense.hip.h)
   uint32_t *d_occ32 = nullptr, *d_goff = nullptr, *d_blkseq = nullptr;
   uint32_t *d_freq11 = nullptr;  // saturated byte frequencies per 11-mer (fem_seed_select.hip.h), 64 MiB
+  // banks of sequences, each with 32-bit coordinates of its own (fem_seed_dense.hip.h); 1 = the whole reference in one
+  uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
+  uint32_t *d_bank_lo = nullptr;  // [n_banks - 1][n_buckets]: where each further bank's part of a bucket's list starts
+  uint64_t bank_limit = 0;        // FEM_TEST_BANK_BASES: coordinates per bank (tests: banks on small references); 0 = kDenseLimit
   int select_occ_blocks = 0, join_occ_blocks = 0;
   uint64_t select_occ_key = ~0ull, join_occ_key = ~0ull;
   // reference
@@ -399,7 +403,7 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
 
 // LDS of one wave of seed_join_kernel: the strands' candidates, flagged values per phase group, scatter, the block's
 // begin/count entries, the sequence table, the join's bitmap
-femk::SeedLayout make_layout_join(const fem_params &p) {
+femk::SeedLayout make_layout_join(const fem_params &p, bool banked) {
   femk::SeedLayout l{};
   const uint32_t R = (uint32_t)(p.e + 1 + p.a);
   uint32_t o = 0;
@@ -413,26 +417,36 @@ femk::SeedLayout make_layout_join(const fem_params &p) {
   l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
   l.F = take(femk::join_bitmap_words((int)R) * 4u);
+  if (banked) l.gq = take(2u * 128u * 8u);  // a strand's candidates of bank after bank (seed_join_body<R, true>)
   l.wave_bytes = o;
   l.picked = 0;  // the block's sequence table: set by the launcher (behind the waves' regions)
   return l;
 }
 
+// (`banked`: the reference's sequences lie in more than one coordinate space, fem_seed_dense.hip.h)
 template <int R>
-void launch_select_r(dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL((femk::seed_select_kernel<R>), grid, block, lds, st, sp);
+void launch_select_r(bool banked, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  if (banked)
+    hipLaunchKernelGGL((femk::seed_select_kernel<R, true>), grid, block, lds, st, sp);
+  else
+    hipLaunchKernelGGL((femk::seed_select_kernel<R>), grid, block, lds, st, sp);
 }
 template <int R>
-int select_blocks_per_cu_r(int block, uint32_t lds) {
+int select_blocks_per_cu_r(bool banked, int block, uint32_t lds) {
   int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_select_kernel<R>, block, lds) == hipSuccess ? nb : 0;
+  const hipError_t e = banked ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_select_kernel<R, true>, block, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, femk::seed_select_kernel<R>, block, lds);
+  return e == hipSuccess ? nb : 0;
 }
 typedef void (*JoinKernel)(femk::SeedParams);
-JoinKernel join_kernel(int R) {
-  static const JoinKernel k[femk::kMaxR] = {femk::seed_join_kernel_r1, femk::seed_join_kernel_r2, femk::seed_join_kernel_r3, femk::seed_join_kernel_r4,
-                                            femk::seed_join_kernel_r5, femk::seed_join_kernel_r6, femk::seed_join_kernel_r7, femk::seed_join_kernel_r8,
-                                            femk::seed_join_kernel_r9, femk::seed_join_kernel_r10};
-  return k[std::min(std::max(R, 1), femk::kMaxR) - 1];
+JoinKernel join_kernel(int R, bool banked = false) {
+  static const JoinKernel k[2][femk::kMaxR] = {
+      {femk::seed_join_kernel_r1, femk::seed_join_kernel_r2, femk::seed_join_kernel_r3, femk::seed_join_kernel_r4, femk::seed_join_kernel_r5,
+       femk::seed_join_kernel_r6, femk::seed_join_kernel_r7, femk::seed_join_kernel_r8, femk::seed_join_kernel_r9, femk::seed_join_kernel_r10},
+      {femk::seed_join_banked_kernel_r1, femk::seed_join_banked_kernel_r2, femk::seed_join_banked_kernel_r3, femk::seed_join_banked_kernel_r4,
+       femk::seed_join_banked_kernel_r5, femk::seed_join_banked_kernel_r6, femk::seed_join_banked_kernel_r7, femk::seed_join_banked_kernel_r8,
+       femk::seed_join_banked_kernel_r9, femk::seed_join_banked_kernel_r10}};
+  return k[banked ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR) - 1];
 }
 
 #define FEM_DENSE_SWITCH(R, CALL)      \
@@ -449,39 +463,40 @@ JoinKernel join_kernel(int R) {
     default: CALL(10); break;          \
   }
 template <int R>
-uint32_t kernel_regs_r(bool join) {
+uint32_t kernel_regs_r(bool join, bool banked) {
   hipFuncAttributes a{};
-  const void *f = join ? (const void *)join_kernel(R) : (const void *)femk::seed_select_kernel<R>;
+  const void *f = join ? (const void *)join_kernel(R, banked)
+                       : banked ? (const void *)femk::seed_select_kernel<R, true> : (const void *)femk::seed_select_kernel<R>;
   return hipFuncGetAttributes(&a, f) == hipSuccess && a.numRegs > 0 ? (uint32_t)a.numRegs : 128u;
 }
 // vector registers per lane of seed_join_kernel<R> / seed_select_kernel<R>
-uint32_t kernel_regs(int R, bool join) {
-  static uint32_t cache[2][femk::kMaxR + 1] = {};
-  uint32_t &c = cache[join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
+uint32_t kernel_regs(int R, bool join, bool banked = false) {
+  static uint32_t cache[2][2][femk::kMaxR + 1] = {};
+  uint32_t &c = cache[banked ? 1 : 0][join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
   if (c) return c;
-#define FEM_CALL(r) c = kernel_regs_r<r>(join)
+#define FEM_CALL(r) c = kernel_regs_r<r>(join, banked)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
   return c;
 }
-int select_blocks_per_cu(int R, int block, uint32_t lds) {
+int select_blocks_per_cu(int R, bool banked, int block, uint32_t lds) {
   int nb = 0;
-#define FEM_CALL(r) nb = select_blocks_per_cu_r<r>(block, lds)
+#define FEM_CALL(r) nb = select_blocks_per_cu_r<r>(banked, block, lds)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
   return nb;
 }
-void launch_select(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-#define FEM_CALL(r) launch_select_r<r>(grid, block, lds, st, sp)
+void launch_select(int R, bool banked, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+#define FEM_CALL(r) launch_select_r<r>(banked, grid, block, lds, st, sp)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
 }
-int join_blocks_per_cu(int R, int block, uint32_t lds) {
+int join_blocks_per_cu(int R, bool banked, int block, uint32_t lds) {
   int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, join_kernel(R), block, lds) == hipSuccess ? nb : 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, join_kernel(R, banked), block, lds) == hipSuccess ? nb : 0;
 }
-void launch_join(int R, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL(join_kernel(R), grid, block, lds, st, sp);
+void launch_join(int R, bool banked, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL(join_kernel(R, banked), grid, block, lds, st, sp);
 }
 
 template <int R>
@@ -688,12 +703,16 @@ int launch_batch(fem_dev *h, Slot &s) {
       // dense index: seed selection for blocks of reads (fem_seed_select.hip.h), then the bitmap join on 32-bit
       // coordinates, a wave per read (fem_seed_dense.hip.h)
       const uint32_t max_len = std::max<uint32_t>(s.max_len, (uint32_t)p.k);
-      const size_t want_sel = (size_t)s.n_reads * 6u * (size_t)R;
+      const bool banked = h->n_banks > 1;
+      const size_t want_sel = (size_t)s.n_reads * 6u * (size_t)R * h->n_banks;
       if ((rc = dev_realloc(h, &s.d_sel, &s.sel_cap, want_sel))) return rc;
       if ((rc = dev_realloc(h, &s.d_sel_hdr, &s.sel_hdr_cap, (size_t)s.n_reads))) return rc;
       femk::SeedParams fp = sp;
       fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
       fp.freq11 = h->d_freq11, fp.sel = s.d_sel, fp.sel_hdr = s.d_sel_hdr;
+      fp.n_banks = h->n_banks, fp.bank_lo = h->d_bank_lo, fp.n_buckets = (uint32_t)(h->n_lookup - 1);
+      fp.blk_stride = (femk::kDenseRemap >> femk::kDenseBlkShift) + 1u;
+      for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) fp.bank_first[b] = h->bank_first[b];
       fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
       const uint64_t blocks_of_reads = (s.n_reads + femk::kReadBlock - 1) / femk::kReadBlock;
       uint32_t select_lds = 0, select_threads = 256;
@@ -702,15 +721,15 @@ int launch_batch(fem_dev *h, Slot &s) {
         if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
         const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
         const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
-        const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
-        if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
+        const uint64_t key = ((uint64_t)banked << 48) | ((uint64_t)R << 40) | lds_bytes;
+        if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, banked, (int)(64u * wpb), lds_bytes);
         uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         if (overlap) per_cu = 1;  // (3.3 ms per 2.5 M reads of C3 with one block per CU as with five: sectors per second, not waves)
         select_lds = lds_bytes, select_threads = 64u * wpb;
         if (overlap && h->have_select_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_select_done, 0));
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
-        rc = timed(8, s.stream, [&] { launch_select(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+        rc = timed(8, s.stream, [&] { launch_select(R, banked, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
         if (rc) return rc;
         if (overlap) {
           HIP_TRY(h, hipEventRecord(h->ev_select_done, s.stream));
@@ -719,24 +738,24 @@ int launch_batch(fem_dev *h, Slot &s) {
         }
       }
       {
-        fp.lay = make_layout_join(p);
+        fp.lay = make_layout_join(p, banked);
         const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / fp.lay.wave_bytes));
         fp.lay.picked = wpb * fp.lay.wave_bytes;
         const uint32_t lds_bytes = wpb * fp.lay.wave_bytes + 64u * 8u;
-        const uint64_t key = ((uint64_t)R << 40) | lds_bytes;
-        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, (int)(64u * wpb), lds_bytes);
+        const uint64_t key = ((uint64_t)banked << 48) | ((uint64_t)R << 40) | lds_bytes;
+        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, banked, (int)(64u * wpb), lds_bytes);
         uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         if (overlap) {
           // leave one block of the next batch's seed_select_kernel room on every CU: registers (512 per lane and SIMD,
           // handed out in eights), LDS (160 KB) and wave slots (8 per SIMD) of both kernels together
-          const uint32_t vj = (kernel_regs(R, true) + 7u) & ~7u, vs = (kernel_regs(R, false) + 7u) & ~7u;
+          const uint32_t vj = (kernel_regs(R, true, banked) + 7u) & ~7u, vs = (kernel_regs(R, false, banked) + 7u) & ~7u;
           const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
           const uint32_t lj = (lds_bytes + 511u) & ~511u, ls = (select_lds + 511u) & ~511u;  // (LDS is handed out in pieces of 512 bytes)
           while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lj + ls > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
         }
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
-        rc = timed(0, s.stream, [&] { launch_join(R, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+        rc = timed(0, s.stream, [&] { launch_join(R, banked, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
         if (rc) return rc;
       }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the two queued
@@ -846,35 +865,48 @@ int refresh_summary(fem_dev *h) {
 // form of seed_fast_kernel runs instead) when the coordinates do not fit 32 bits.
 constexpr double kDenseMinAvgBucket = 4.0;
 int refresh_dense(fem_dev *h) {
-  for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11})
+  for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)h->d_bank_lo})
     if (p) (void)hipFree(p);
-  h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr;
+  h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr, h->d_bank_lo = nullptr;
+  h->n_banks = 1;
   if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
   const uint64_t n_buckets = h->n_lookup - 1;
   if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
   if (h->n_seq > femk::kDenseMaxSeq) return FEM_OK;
+  // Coordinates: goff[seq] + pos, a gap between sequences; where the next sequence would pass the 32-bit limit a new BANK
+  // starts with coordinates of its own (fem_seed_dense.hip.h) — up to kDenseMaxBanks of them, else the 64-bit join
+  const uint64_t limit = h->bank_limit ? std::min<uint64_t>(h->bank_limit, femk::kDenseLimit) : femk::kDenseLimit;
   std::vector<uint32_t> goff(h->n_seq + 1);
+  uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
   uint64_t at = femk::kDenseGap;
   for (uint32_t i = 0; i < h->n_seq; ++i) {
+    if (at + (uint64_t)h->seq_len[i] + femk::kDenseGap > limit && at != femk::kDenseGap) {
+      if (n_banks == femk::kDenseMaxBanks) return FEM_OK;
+      bank_first[n_banks++] = i;
+      at = femk::kDenseGap;
+    }
     goff[i] = (uint32_t)at;
     at += (uint64_t)h->seq_len[i] + femk::kDenseGap;
-    if (at > femk::kDenseLimit) return FEM_OK;  // does not fit 32 bits: 64-bit join
+    if (at > femk::kDenseLimit) return FEM_OK;  // one sequence beyond 32 bits: 64-bit join
   }
   goff[h->n_seq] = (uint32_t)at;
+  for (uint32_t b = n_banks; b <= femk::kDenseMaxBanks; ++b) bank_first[b] = h->n_seq;
   const uint32_t n_blk = (femk::kDenseRemap >> femk::kDenseBlkShift) + 1u;
-  std::vector<uint32_t> blkseq(n_blk, 0);
-  for (uint32_t b = 0, sq = 0; b < n_blk; ++b) {
-    const uint64_t first = (uint64_t)b << femk::kDenseBlkShift;
-    while (sq + 1u < h->n_seq && goff[sq + 1u] <= first) ++sq;
-    blkseq[b] = sq;
-  }
+  std::vector<uint32_t> blkseq((size_t)n_blk * n_banks, 0);  // per bank: the last of its sequences starting at or before each 2^20 block
+  for (uint32_t bank = 0; bank < n_banks; ++bank)
+    for (uint32_t b = 0, sq = bank_first[bank]; b < n_blk; ++b) {
+      const uint64_t first = (uint64_t)b << femk::kDenseBlkShift;
+      while (sq + 1u < bank_first[bank + 1] && goff[sq + 1u] <= first) ++sq;
+      blkseq[(size_t)bank * n_blk + b] = sq;
+    }
   // These tables are optional (4 bytes per occurrence: 4 GB at 3 Gbp): a failed allocation declines the dense form —
   // the 64-bit hash-join form of seed_fast_kernel runs without them — instead of failing the upload.
   uint32_t *d_bad = nullptr;
   auto decline = [&]() {
-    for (void *q : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)d_bad})
+    for (void *q : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)h->d_bank_lo, (void *)d_bad})
       if (q) (void)hipFree(q);
-    h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr;
+    h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr, h->d_bank_lo = nullptr;
+    h->n_banks = 1;
     (void)hipGetLastError();  // (clears the out-of-memory error)
     return FEM_OK;
   };
@@ -882,6 +914,7 @@ int refresh_dense(fem_dev *h) {
       hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void **)&h->d_freq11, (size_t)femk::kX11 * 4u * sizeof(uint32_t)) != hipSuccess ||
+      (n_banks > 1 && hipMalloc((void **)&h->d_bank_lo, (size_t)(n_banks - 1) * n_buckets * sizeof(uint32_t)) != hipSuccess) ||
       hipMalloc((void **)&d_bad, sizeof(uint32_t)) != hipSuccess)
     return decline();
   if (hipMemset(d_bad, 0, sizeof(uint32_t)) != hipSuccess ||
@@ -900,6 +933,11 @@ int refresh_dense(fem_dev *h) {
   if (bad) return decline();  // the index names sequences the reference does not have: leave that to the 64-bit path's checks
   (void)hipFree(d_bad);
   d_bad = nullptr;
+  for (uint32_t b = 1; b < n_banks; ++b)  // where bank b's part of every list starts
+    hipLaunchKernelGGL(femk::bank_split_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->d_lookup, (uint32_t)n_buckets, bank_first[b],
+                       h->d_bank_lo + (size_t)(b - 1) * n_buckets);
+  h->n_banks = n_banks;
+  for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) h->bank_first[b] = bank_first[b];
   // byte frequencies per 11-mer for seed_select_kernel (fem_seed_select.hip.h)
   hipLaunchKernelGGL(femk::freq11_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, h->d_freq11);
   HIP_TRY(h, hipGetLastError());
@@ -1055,6 +1093,7 @@ int fem_dev_open(int device, fem_dev **out) {
   h->no_dense = nd && nd[0] == '1';
   const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
   h->tiny_buffers = tb && tb[0] == '1';
+  if (const char *bl = getenv("FEM_TEST_BANK_BASES")) h->bank_limit = strtoull(bl, nullptr, 10);
   *out = h;
   return FEM_OK;
 }
@@ -1090,7 +1129,7 @@ int fem_dev_close(fem_dev *h) {
   if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_planes, (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
-                  (void *)h->d_freq11})
+                  (void *)h->d_freq11, (void *)h->d_bank_lo})
     if (p) (void)hipFree(p);
   delete h;
   return FEM_OK;
@@ -1675,7 +1714,7 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
   const int R = p->e + 1 + p->a;
   const bool use_fast = !h->force_generic && p->k == femk::kK && p->step == femk::kStep && R >= 1 && R <= femk::kMaxR;
   if (!use_fast) return "seed_filter_kernel";
-  if (h->d_occ32 && h->d_freq11) return "seed_join_kernel";
+  if (h->d_occ32 && h->d_freq11) return h->n_banks > 1 ? "seed_join_banked_kernel" : "seed_join_kernel";
   return (h->force_hash || (double)h->n_occ > (double)h->n_lookup) ? "seed_fast_kernel<hash>" : "seed_fast_kernel<lean>";
 }
 

@@ -92,6 +92,14 @@ struct SeedParams {
   const uint32_t *freq11;
   uint2 *sel;
   uint2 *sel_hdr;
+  // References beyond the 32-bit coordinate (fem_seed_dense.hip.h, "banks"): the sequences [bank_first[b], bank_first[b+1])
+  // share one coordinate space; bank_lo[(b - 1) * n_buckets + h] = where bank b's part of bucket h's list starts in the
+  // occurrence tables (b = 1 .. n_banks - 1); blkseq holds blk_stride entries per bank.  n_banks == 1: none of this is read.
+  uint32_t n_banks;
+  uint32_t bank_first[5];
+  const uint32_t *bank_lo;
+  uint32_t n_buckets;
+  uint32_t blk_stride;
   unsigned long long *stats;  // [0] sum of pre-filter counts, [1] sum of candidates
   uint64_t *arena;
   unsigned long long arena_cap;   // entries

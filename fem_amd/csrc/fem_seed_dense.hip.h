@@ -27,6 +27,14 @@ constexpr uint32_t kDenseGap = 2048u;          // positions between two sequence
 constexpr uint32_t kDenseNear = 1024u;         // entries with pos < this are stored remapped (>= the longest read)
 constexpr uint32_t kDenseRemap = 0xF0000000u;  // remapped entry: kDenseRemap | seq << 10 | pos  (seq < 2^18)
 constexpr uint32_t kDenseMaxSeq = 1u << 18;
+// A reference whose sequences do not fit one 32-bit coordinate space is cut into up to kDenseMaxBanks BANKS of consecutive
+// sequences, each with coordinates of its own (goff restarts at kDenseGap).  A bucket's list is sorted by (sequence,
+// position), so it falls into one contiguous part per bank; values of different sequences are never within e of each
+// other, so merge, window filter and de-duplication decompose per bank exactly and the candidates of bank after bank are
+// ascending.  The one rule that looks across banks — the last run keeps values <= max(U) only (src/filter.c:85) —
+// becomes, per unit and bank: keep all of it (U has entries in a higher bank), as usual (this is the highest bank with
+// entries of U), or drop it (only lower banks have them); seed_select_kernel<R, true> writes that into what it hands over.
+// (kDenseMaxBanks, kSelKeepAll: fem_seed_select.hip.h)
 constexpr uint32_t kDenseLimit = 0xEFFFF000u;  // global coordinates stay below this
 constexpr uint32_t kDenseSent = 0xEFFFFFFFu;   // "no entry" in a lane: still above kDenseVLimit after the start is subtracted
 constexpr uint32_t kDenseVLimit = 0xEFFFF800u; // v < this <=> the lane holds a real entry
@@ -58,6 +66,20 @@ __global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32
       v = goff[seq] + pos;
     }
     out[i] = v;
+  }
+}
+
+// out[h] = index in occ of bucket h's first entry whose sequence is >= first_seq (lookup[h + 1] if none): where the
+// bank starting at that sequence begins in the list.  One thread per bucket, binary search (the list ascends).
+__global__ void bank_split_kernel(const uint64_t *occ, const uint32_t *lookup, uint32_t n_buckets, uint32_t first_seq, uint32_t *out) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_buckets; h += stride) {
+    uint32_t lo = lookup[h], hi = lookup[h + 1u];
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if ((uint32_t)(occ[mid] >> 32) < first_seq) lo = mid + 1u; else hi = mid;
+    }
+    out[h] = lo;
   }
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
 // kept0/kept1; false = hand the read to the generic kernel.  `bitmap` is all-zero (but for its guard word) on entry
 // and on exit.
 // ---------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool BANKED = false>
 __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
                           uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */,
                           uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1) {
@@ -130,10 +130,12 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     // ---- the unit's runs as wave-uniform scalars ----
     uint32_t f[R], st[R];
     uint32_t n_g = 0, f_max = 0;
+    // (banks: U has entries in a higher bank — the last run is merged whole, also where this bank holds nothing else)
+    const bool keep_all = BANKED && (nxt_sf[R - 1] & kSelKeepAll) != 0u;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t sf = nxt_sf[t];
-      f[t] = (sf >> 16) & 0xFFu, st[t] = sf & 0xFFFFu;
+      f[t] = (sf >> 16) & 0xFFu, st[t] = sf & (BANKED ? kSelKeepAll - 1u : 0xFFFFu);
       n_g += f[t];
       f_max = f[t] > f_max ? f[t] : f_max;
     }
@@ -143,7 +145,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     if (u + 1u < kUnits) prefetch(u + 1u);
     // fewer than a+1 occurrences: nothing can pass the filter; no list but the last seed's: it is merged only while
     // the list has elements (src/filter.c:85)
-    const bool skip = n_g <= (uint32_t)p.a || n_g == f[R - 1];
+    const bool skip = n_g <= (uint32_t)p.a || (n_g == f[R - 1] && !keep_all);
     uint32_t n_flag = 0;
     uint32_t *flg_g = flg + g * kFlgStride;
     if (!skip) {
@@ -229,6 +231,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
           }
         }
       }
+      if (keep_all) any_u = true, max_u = 0xFFFFFFFFu;
       if (any_u) {
         // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
         val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
@@ -430,7 +433,7 @@ constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_W
 // registers): 6 x 72 + 80 = 512 per lane and SIMD.  (amdgpu_num_vgpr is not honoured by this compiler; the budget follows
 // from the waves per SIMD asked for, and that attribute wants a literal: one kernel per R instead of a template.)
 
-template <int R>
+template <int R, bool BANKED = false>
 __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *smem) {
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
@@ -478,16 +481,101 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
     uint2 hdr = make_uint2(kSelSlow, 0u);
     if (ln < n_blk) hdr = p.sel_hdr[r0 + ln];
     uint2 sel_next = make_uint2(0u, 0u);
-    if (ln < 2u * kSeeds) sel_next = p.sel[(size_t)r0 * (2u * kSeeds) + ln];
+    if (!BANKED && ln < 2u * kSeeds) sel_next = p.sel[(size_t)r0 * (2u * kSeeds) + ln];
     for (uint32_t rb = 0; rb < n_blk; ++rb) {
       const uint32_t read = r0 + rb;
       const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hdr.x, (int)rb);
       const uint32_t status = h0 & 3u, L = h0 >> 8;
       const uint2 sel = sel_next;
-      if (rb + 1u < n_blk && ln < 2u * kSeeds) sel_next = p.sel[(size_t)(read + 1u) * (2u * kSeeds) + ln];
+      if (!BANKED && rb + 1u < n_blk && ln < 2u * kSeeds) sel_next = p.sel[(size_t)(read + 1u) * (2u * kSeeds) + ln];
       if (status == kSelSlow) continue;  // queued by seed_select_kernel
       if (status == kSelNone) {
         if (ln / 2u == rb) blk_entries[ln] = make_uint2(0u, 0u);
+        continue;
+      }
+      if constexpr (BANKED) {
+        // ---- a reference in banks (fem_seed_dense.hip.h): the join once per bank on that bank's parts of the lists; a
+        //      strand's candidates of bank after bank gather in LDS (ascending: banks are runs of sequences) and go out
+        //      together — the 16-bit-lane flag of full groups of eight is a function of the strand's total ----
+        constexpr uint32_t kStash = 2u * (uint32_t)kWave;  // candidates one strand may have over all banks
+        uint64_t *stash = (uint64_t *)(wbase + p.lay.gq);  // [2][kStash]
+        uint32_t acc[2] = {0u, 0u};
+        bool failed = false;
+        for (uint32_t b = 0; b < p.n_banks && !failed; ++b) {
+          uint2 sel_b = make_uint2(0u, 0u);
+          if (ln < 2u * kSeeds) sel_b = p.sel[((size_t)read * p.n_banks + b) * (2u * kSeeds) + ln];
+          uint32_t kept0 = 0, kept1 = 0;
+          if (!join_read<R, true>(p, sel_b.y & 0xFFFFu, sel_b.x, sel_b.y >> 16, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
+            failed = true;
+            break;
+          }
+          const uint32_t sq_lo = p.bank_first[b], sq_hi = p.bank_first[b + 1u];
+#pragma unroll 1
+          for (uint32_t strand = 0; strand < 2u; ++strand) {
+            const uint32_t kept = strand ? kept1 : kept0;
+            if (kept == 0) continue;
+            const uint32_t v = cand_lds[strand * (uint32_t)kWave + ln];
+            uint32_t sq = 0, pos = 0, slen = 0;
+            if (small_ref) {
+              const uint2 tab = seqtab[ln];
+              const bool mine = ln >= sq_lo && ln < sq_hi;  // the bank's sequences
+              for (uint32_t i = 0; i < kept; ++i) {
+                const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
+                const uint32_t s_i = sq_lo + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(mine && tab.x <= vi)) - 1u;
+                const uint32_t g_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.x, (int)s_i);
+                const uint32_t l_i = (uint32_t)__builtin_amdgcn_readlane((int)tab.y, (int)s_i);
+                if (ln == i) sq = s_i, pos = vi - g_i, slen = l_i;
+              }
+            } else if (ln < kept) {
+              sq = p.blkseq[(size_t)b * p.blk_stride + (v >> kDenseBlkShift)];
+              while (sq + 1u < sq_hi && p.goff[sq + 1u] <= v) ++sq;
+              pos = v - p.goff[sq];
+              slen = p.seq_len[sq];
+            }
+            const bool ok = ln < kept && pos >= (uint32_t)p.e && pos + L + (uint32_t)p.e < slen;
+            const uint64_t mo = __ballot(ok);
+            const uint32_t n_ok = (uint32_t)__popcll(mo);
+            if (acc[strand] + n_ok > kStash) {
+              failed = true;
+              break;
+            }
+            if (ok) stash[strand * kStash + acc[strand] + (uint32_t)__popcll(mo & ((1ull << ln) - 1ull))] = (((uint64_t)sq << 32) | pos) - (uint64_t)p.e;
+            acc[strand] += n_ok;
+          }
+        }
+        if (failed) {
+          queue_slow(read);
+          continue;
+        }
+        pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, (int)rb);
+        wave_sync_lds();
+#pragma unroll 1
+        for (uint32_t strand = 0; strand < 2u; ++strand) {
+          const uint32_t n_out = acc[strand];
+          uint32_t base = 0;
+          if (n_out > 0) {
+            if (n_out <= chunk.left) {
+              base = chunk.next;
+              chunk.next += n_out, chunk.left -= n_out;
+            } else {
+              pad_chunk(p, chunk);
+              if (ln == 0) base = atomicAdd(&p.ctr[0], kSlotChunk);
+              base = bcast0(base);
+              chunk.next = base + n_out, chunk.left = kSlotChunk - n_out;
+            }
+            if ((unsigned long long)base + n_out > p.cand_cap) {
+              if (ln == 0) atomicOr(&p.ctr[1], kFlagCandOverflow);
+            } else {
+              for (uint32_t i = ln; i < n_out; i += (uint32_t)kWave) {
+                p.cand[base + i] = stash[strand * kStash + i];
+                p.cand_meta[base + i] = (read * 2u + strand) | (i < (n_out & ~7u) ? kMeta16 : 0u);
+              }
+            }
+          }
+          if (ln == 0) blk_entries[2u * rb + strand] = make_uint2(base, n_out);
+          cand_sum += n_out;
+        }
+        wave_sync_lds();
         continue;
       }
       const uint32_t s_lo = sel.x, s_start = sel.y & 0xFFFFu, s_freq = sel.y >> 16;
@@ -577,6 +665,10 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
   __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) seed_join_kernel_r##R(SeedParams p) {                         \
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R>(p, smem);                                                                                                  \
+  }                                                                                                                              \
+  __global__ void __launch_bounds__(256) seed_join_banked_kernel_r##R(SeedParams p) { /* references in banks: no register budget to keep */ \
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
+    seed_join_body<R, true>(p, smem);                                                                                            \
   }
 FEM_JOIN_KERNEL(1, FEM_JOIN_WAVES_LO)
 FEM_JOIN_KERNEL(2, FEM_JOIN_WAVES_LO)

@@ -28,6 +28,8 @@
 
 namespace femk {
 
+constexpr uint32_t kDenseMaxBanks = 4;       // banks of sequences with coordinates of their own (fem_seed_dense.hip.h)
+constexpr uint32_t kSelKeepAll = 1u << 15;  // in a last run's (start | frequency << 16) word: no truncation at max(U) in this bank
 constexpr uint32_t kSelOk = 0u, kSelNone = 1u, kSelSlow = 2u;  // sel_hdr[read].x & 3: joined / no candidates / generic kernel
 constexpr uint32_t kSelMaxCols = 64u;                          // DP columns a lane's take masks hold
 constexpr uint32_t kSelMaxList = 128u;                         // longest list seed_join_kernel takes (kDenseMaxList)
@@ -115,7 +117,7 @@ __device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uin
 #define FEM_SELECT_UNROLL 4
 #endif
 
-template <int R>
+template <int R, bool BANKED = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SELECT_WAVES, 8))) seed_select_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t ln = lane_id();
@@ -346,24 +348,65 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         // ---- the selected seeds' list bases; hand-over ----
         if (read_ok) {
           const uint32_t base = r_base[i_c];
-          uint2 *out = p.sel + ((size_t)(rd0 + i_c) * 6u + u) * (uint32_t)R;
-          uint32_t lo[R];
+          uint32_t lo[R], hs[R];
           bool too_long = false;
 #pragma unroll
           for (int t = 0; t < R; ++t) {
             const uint32_t f = key[t] >> 14, sidx = key[t] & 1023u;
-            lo[t] = 0;
+            lo[t] = 0, hs[t] = 0;
             if (f != 0u) {
               const uint32_t j = strand ? S - 1u - sidx : sidx;
               const uint32_t hf = stream_window(fw, base + j) >> 8;
               uint32_t h = hf;
               if (strand) h = rc_hash(hf, has_n ? stream_window(nw, base + j) >> 8 : 0u);
-              lo[t] = p.lookup[h];
+              lo[t] = p.lookup[h], hs[t] = h;
             }
             too_long |= f > kSelMaxList;
           }
+          if constexpr (!BANKED) {
+            uint2 *out = p.sel + ((size_t)(rd0 + i_c) * 6u + u) * (uint32_t)R;
 #pragma unroll
-          for (int t = 0; t < R; ++t) out[t] = make_uint2(lo[t], (key[t] & 1023u) | ((key[t] >> 14) << 16));
+            for (int t = 0; t < R; ++t) out[t] = make_uint2(lo[t], (key[t] & 1023u) | ((key[t] >> 14) << 16));
+          } else {
+            // ---- banks (fem_seed_dense.hip.h): every list cut at the banks' boundaries; per bank the part's base and
+            //      length, and for the last run what becomes of "values <= max(U) only" (src/filter.c:85) ----
+            const uint32_t nb = p.n_banks;
+            uint32_t cut[R];  // where the current bank's part of list t starts
+#pragma unroll
+            for (int t = 0; t < R; ++t) cut[t] = lo[t];
+            uint32_t u_banks = 0;  // bit b: some run of U (t < R - 1) has entries in bank b
+            uint32_t part[kDenseMaxBanks][R];
+            for (uint32_t b = 0; b < nb; ++b) {
+#pragma unroll
+              for (int t = 0; t < R; ++t) {
+                const uint32_t f = key[t] >> 14;
+                uint32_t end = lo[t] + f;
+                if (f != 0u && b + 1u < nb) end = p.bank_lo[(size_t)b * p.n_buckets + hs[t]];
+                part[b][t] = f != 0u ? end - cut[t] : 0u;
+                if (t < R - 1 && part[b][t] != 0u) u_banks |= 1u << b;
+              }
+#pragma unroll
+              for (int t = 0; t < R; ++t) cut[t] += part[b][t];
+            }
+#pragma unroll
+            for (int t = 0; t < R; ++t) cut[t] = lo[t];
+            for (uint32_t b = 0; b < nb; ++b) {
+              uint2 *out = p.sel + (((size_t)(rd0 + i_c) * nb + b) * 6u + u) * (uint32_t)R;
+              const bool above = (u_banks >> (b + 1u)) != 0u;                 // U has entries in a higher bank: keep all of the last run
+              const bool gone = !above && !((u_banks >> b) & 1u) && u_banks;  // ... only in lower banks: the last run is dropped here
+#pragma unroll
+              for (int t = 0; t < R; ++t) {
+                uint32_t f_b = part[b][t];
+                uint32_t word = key[t] & 1023u;
+                if (t == R - 1) {
+                  if (gone) f_b = 0;
+                  if (above) word |= kSelKeepAll;
+                }
+                out[t] = make_uint2(cut[t], word | (f_b << 16));
+                cut[t] += part[b][t];
+              }
+            }
+          }
           if (too_long) atomicOr(&r_flag[i_c], kSlow);
         }
       }

@@ -206,8 +206,9 @@ int fem_dev_fetch_sam_nowait(fem_dev *h, int slot, fem_batch_sam *out);
 int fem_dev_sam_wait(fem_dev *h, int slot);
 
 /* Name of the seed + filter kernel fem_dev_map_staged would launch first for these parameters on the resident
- * index ("seed_join_kernel" — behind its "seed_select_kernel" —, "seed_fast_kernel<hash>", "seed_fast_kernel<lean>"
- * or "seed_filter_kernel"); the generic seed_filter_kernel always follows for whatever those queue.  Static string. */
+ * index ("seed_join_kernel" — behind its "seed_select_kernel"; "seed_join_banked_kernel" where the reference's sequences
+ * need more than one 32-bit coordinate space —, "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or
+ * "seed_filter_kernel"); the generic seed_filter_kernel always follows for whatever those queue.  Static string. */
 const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
 
 /* ---- measurement ---- */
