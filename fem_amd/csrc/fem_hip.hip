@@ -417,7 +417,7 @@ femk::SeedLayout make_layout_join(const fem_params &p, bool banked) {
   l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
   l.F = take(femk::join_bitmap_words((int)R) * 4u);
-  if (banked) l.gq = take(2u * 128u * 8u);  // a strand's candidates of bank after bank (seed_join_body<R, true>)
+  if (banked) l.gq = take(2u * 64u * 8u);  // a strand's candidates of bank after bank (seed_join_body<R, true>)
   l.wave_bytes = o;
   l.picked = 0;  // the block's sequence table: set by the launcher (behind the waves' regions)
   return l;

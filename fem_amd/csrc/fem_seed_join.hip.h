@@ -497,7 +497,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
         // ---- a reference in banks (fem_seed_dense.hip.h): the join once per bank on that bank's parts of the lists; a
         //      strand's candidates of bank after bank gather in LDS (ascending: banks are runs of sequences) and go out
         //      together — the 16-bit-lane flag of full groups of eight is a function of the strand's total ----
-        constexpr uint32_t kStash = 2u * (uint32_t)kWave;  // candidates one strand may have over all banks
+        constexpr uint32_t kStash = (uint32_t)kWave;  // candidates one strand may have over all banks (as in one bank: a wave's lanes)
         uint64_t *stash = (uint64_t *)(wbase + p.lay.gq);  // [2][kStash]
         uint32_t acc[2] = {0u, 0u};
         bool failed = false;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R>(p, smem);                                                                                                  \
   }                                                                                                                              \
-  __global__ void __launch_bounds__(256) seed_join_banked_kernel_r##R(SeedParams p) { /* references in banks: no register budget to keep */ \
+  __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_JOIN_WAVES_HI, 8))) seed_join_banked_kernel_r##R(SeedParams p) { /* references in banks */ \
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R, true>(p, smem);                                                                                            \
   }
