@@ -510,6 +510,10 @@ def main():
         cores = max(1, int(os.environ["FEM_BENCH_THREADS"]))
     threads = max(1, cores // (rk.world if os.environ.get("FEM_BENCH_ONE_GPU") == "1" else 1))
     gen_threads = max(1, min(threads, 32))
+    if rk.world > 1 and "FEM_STAGE_THREADS" not in os.environ:
+        # the library packs a batch on 12 threads by default (what a 16-core share feeds); N ranks on one node share the
+        # node's cores: each takes its part of them, so that eight ranks do not put 96 threads on a 16-core quota
+        os.environ["FEM_STAGE_THREADS"] = str(max(2, min(12, cores // rk.world)))
     log("rank %d: %d host threads (affinity mask %d CPUs%s, cgroup quota %s)" %
         (rk.rank, threads, n_aff, ", bound to the GPU's NUMA node" if numa_bound else "", quota))
 
