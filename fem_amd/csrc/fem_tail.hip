@@ -18,7 +18,7 @@ namespace femt {
 namespace {
 
 constexpr uint32_t kOpM = 0, kOpI = 1, kOpD = 2, kOpS = 3;  // S: the traceback's pseudo-run (src/align.c:342), never emitted
-constexpr uint32_t kOpsCap = 16, kMdCap = 96;  // first-pass staging per record; anything longer goes to the overflow pass
+constexpr uint32_t kOpsCap = 16, kMdCap = 32;  // first-pass staging per record; anything longer goes to the overflow pass
 constexpr uint32_t kSortLdsHits = 2048;         // hits of one read the ordering kernel keeps in LDS
 constexpr uint16_t kFlagBroken = 0x8000;
 
@@ -839,6 +839,12 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
       // ---- walk back (src/align.c:340-440); pe == t + bit throughout ----
       int bit = start, t = L - 1, n_err = 0;
       uint32_t cur_op = kOpS, cur_n = 1;
+      // The read positions of the walk's mismatch steps, the leftmost in the low byte: what the MD tag needs to know
+      // about an M run besides its length (every other base of it is a match).  Where that does not say it all — see
+      // use_hist below — the MD loop reads the history instead.
+      uint64_t mm = 0;
+      uint32_t n_mm = 0;
+      bool use_hist = L > 255;  // (a position is kept in eight bits)
       // Behind the last column that differs on the end position's diagonal the walk only matches (equal characters
       // set D0, and match is the first thing it tests): it starts at that column with the M run already counted.
       const uint32_t trail = (uint32_t)(L - 1 - last_bad);
@@ -849,8 +855,8 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
         const bool pp = (uint32_t)h & 1u, qq = (uint32_t)(h >> W) & 1u;
         const bool d = pp || qq, same = pp && qq, horiz = qq;
         if (d && same) --t, cur_op = kOpM;
-        else if (!d) --t, ++n_err;
-        else if (horiz) --t, ++bit, ++n_err, ++start;
+        else if (!d) mm = (uint64_t)(uint32_t)t, n_mm = 1, --t, ++n_err;
+        else if (horiz) --t, ++bit, ++n_err, ++start, use_hist = true;  // a read-end insertion folds into the run that follows
         else broken = true;  // assert(1 == 0)
       }
       while (!broken && !punt && t >= 0 && n_err != ed) {
@@ -868,6 +874,10 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
         const bool is_match = d && same, is_ins = d && !same && horiz, is_del = d && !same && !horiz;  // else: mismatch
         const uint32_t op = is_del ? kOpD : is_ins ? kOpI : kOpM;
         const bool absorbed = cur_op == kOpS && !is_match && !is_del;  // read-end errors pile up in the pseudo-run
+        // the pseudo-run takes an insertion, or ends in a deletion: the run it folds into is not what the walk stepped through
+        use_hist |= cur_op == kOpS && (is_ins || is_del);
+        mm = d ? mm : (mm << 8) | (uint64_t)(uint32_t)t;
+        n_mm += (uint32_t)!d;
         t -= (int)!is_del;
         bit += (int)is_ins - (int)is_del;
         start += (int)is_ins - (int)is_del;
@@ -891,8 +901,43 @@ __global__ void __launch_bounds__(64) trace_fast_kernel(Params p) {
         }
         if (cur_op == kOpS) broken = true; else push_op(cur_op, cur_n);
       }
-      if (!broken && !punt) {
-        // ---- MD over pattern + start (src/align.c:501-544); runs were produced right to left ----
+      // leading bases the walk never visited match on codes; on characters too unless an odd reference character is near
+      use_hist |= (t >= 0 && odd_ref != 0u) || n_mm > 8u;
+      if (!broken && !punt && !use_hist) {
+        // ---- MD (src/align.c:501-544) from the runs (produced right to left) and the mismatch positions: every base of
+        //      an M run the walk stepped through as a match is a match of characters, as are the bases in front of the
+        //      walk's last step (all ed edits found) and behind its first (`trail`) ----
+        uint32_t run = 0, tp = 0;
+        int rp = start;
+        for (uint32_t k = n_ops; k-- > 0 && !punt;) {
+          const uint32_t o = ops[k * nl + ln], op = o & 3u, n = o >> 2;
+          if (op == kOpM) {
+            const uint32_t end = tp + n;
+            while (n_mm && ((uint32_t)mm & 0xFFu) < end) {
+              const uint32_t at = (uint32_t)mm & 0xFFu;
+              mm >>= 8, --n_mm;
+              run += at - tp;
+              if (run) push_number(run), run = 0;
+              rp += (int)(at - tp);
+              push_md(pattern[rp]);
+              ++rp, tp = at + 1u;
+            }
+            run += end - tp, rp += (int)(end - tp), tp = end;
+          } else if (op == kOpI) {
+            tp += n;
+          } else {
+            if (rp < 0) {
+              punt = true;
+              break;
+            }
+            if (run) push_number(run), run = 0;
+            push_md('^');
+            for (uint32_t i = 0; i < n; ++i, ++rp) push_md(pattern[rp]);
+          }
+        }
+        if (run) push_number(run);
+      } else if (!broken && !punt) {
+        // ---- MD over pattern + start, character equality read off the history ----
         uint32_t run = 0, tp = 0;
         int rp = start;
         for (uint32_t k = n_ops; k-- > 0 && !punt;) {
@@ -1276,7 +1321,8 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   const uint32_t fast_per_lane = max_len * hist_bytes + fast_ops * 2u;
   const uint32_t fast_lanes = std::min<uint32_t>(64, (64u * 1024u - 4u) / fast_per_lane);
   const uint32_t fast_lds = ((max_len * hist_bytes * fast_lanes + 3u) & ~3u) + fast_ops * 2u * fast_lanes;
-  const uint32_t ops_cap = tiny ? 1u : kOpsCap, md_cap = tiny ? 2u : kMdCap;
+  // (the staging's rows are read and written one record per lane: the shorter the row, the fewer lines a wave touches)
+  const uint32_t ops_cap = tiny ? 1u : std::max<uint32_t>(8u, fast_ops), md_cap = tiny ? 2u : kMdCap;
   // longest possible walk: every step opens a run; the MD of a run never exceeds two characters per column
   const uint32_t o_ops_cap = 2 * max_len + 2 * (uint32_t)in.e + 8, o_md_cap = 8 * max_len + 128;
 
