@@ -1030,6 +1030,13 @@ __global__ void __launch_bounds__(256) compact_kernel(CompactParams p) {
   for (uint32_t i = 0; i < nm; ++i) p.md[mo + i] = md[i];
 }
 
+struct PairPlus {  // component-wise sum of (run count, MD length) pairs
+  __host__ __device__ rocprim::tuple<uint32_t, uint32_t> operator()(const rocprim::tuple<uint32_t, uint32_t> &a,
+                                                                   const rocprim::tuple<uint32_t, uint32_t> &b) const {
+    return rocprim::make_tuple(rocprim::get<0>(a) + rocprim::get<0>(b), rocprim::get<1>(a) + rocprim::get<1>(b));
+  }
+};
+
 // ---- host-side buffer helpers ----
 struct DevBuf {
   void *p = nullptr;
@@ -1353,8 +1360,11 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   size_t tmp_a = 0, tmp_b = 0;
   TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_a, (const uint32_t *)in.n_map, m.rec_begin.as<uint32_t>(), 0u, (size_t)n,
                                    rocprim::plus<uint32_t>(), stream));
-  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_b, m.n_ops.as<uint32_t>(), m.cigar_off.as<uint32_t>(), 0u, r1,
-                                   rocprim::plus<uint32_t>(), stream));
+  {
+    auto lens = rocprim::make_zip_iterator(rocprim::make_tuple(m.n_ops.as<uint32_t>(), m.n_md.as<uint32_t>()));
+    auto offs = rocprim::make_zip_iterator(rocprim::make_tuple(m.cigar_off.as<uint32_t>(), m.md_off.as<uint32_t>()));
+    TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_b, lens, offs, rocprim::make_tuple(0u, 0u), r1, PairPlus(), stream));
+  }
   size_t tmp_bytes = std::max(tmp_a, tmp_b);
   TAIL_TRY(m.scan_tmp.need(std::max<size_t>(tmp_bytes, 16)));
   tmp_bytes = m.scan_tmp.cap;
@@ -1428,16 +1438,15 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   // ---- compaction: offsets by exclusive scans over n_records + 1 lengths (the last one zero) ----
   TAIL_TRY(hipMemsetAsync(m.n_ops.as<uint32_t>() + nr, 0, 4, stream));
   TAIL_TRY(hipMemsetAsync(m.n_md.as<uint32_t>() + nr, 0, 4, stream));
-  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, m.n_ops.as<uint32_t>(), m.cigar_off.as<uint32_t>(), 0u, r1,
-                                   rocprim::plus<uint32_t>(), stream));
-  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, m.n_md.as<uint32_t>(), m.md_off.as<uint32_t>(), 0u, r1,
-                                   rocprim::plus<uint32_t>(), stream));
-  TAIL_TRY(hipMemcpyAsync(h_ctl + 4, m.cigar_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
-  TAIL_TRY(hipMemcpyAsync(h_ctl + 5, m.md_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
-  TAIL_TRY(hipStreamSynchronize(stream));
-  const uint32_t n_cigar = h_ctl[4], n_md = h_ctl[5];
-  TAIL_TRY(m.cigar.need(std::max<size_t>(n_cigar, 1) * 4));
-  TAIL_TRY(m.md.need(std::max<size_t>(n_md, 1)));
+  {  // both offsets in one pass: a scan over (runs, MD characters) pairs
+    auto lens = rocprim::make_zip_iterator(rocprim::make_tuple(m.n_ops.as<uint32_t>(), m.n_md.as<uint32_t>()));
+    auto offs = rocprim::make_zip_iterator(rocprim::make_tuple(m.cigar_off.as<uint32_t>(), m.md_off.as<uint32_t>()));
+    TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp_bytes, lens, offs, rocprim::make_tuple(0u, 0u), r1, PairPlus(), stream));
+  }
+  // (the compacted arrays are sized by what the stagings can hold, so that no round trip to the host sits between the scan
+  // and the kernel that uses it; the totals come back with everything else)
+  TAIL_TRY(m.cigar.need(std::max<size_t>((size_t)nr * ops_cap + (size_t)n_overflow * o_ops_cap, 1) * 4));
+  TAIL_TRY(m.md.need(std::max<size_t>((size_t)nr * md_cap + (size_t)n_overflow * o_md_cap, 1)));
   if (nr) {
     CompactParams c{};
     c.n_records = nr, c.src_slot = p.src_slot, c.n_ops = p.n_ops, c.n_md = p.n_md;
@@ -1449,6 +1458,8 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     TAIL_TRY(hipGetLastError());
   }
   TAIL_TRY(hipEventRecord(m.ev[3], stream));
+  TAIL_TRY(hipMemcpyAsync(h_ctl + 4, m.cigar_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(h_ctl + 5, m.md_off.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream));
   m.last_n = n, m.last_nr = nr;
   if (!copy_records) {  // the caller renders them on the device (sam())
     TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
@@ -1468,6 +1479,8 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     return FEM_OK;
   }
   // ---- copy back ----
+  TAIL_TRY(hipStreamSynchronize(stream));
+  const uint32_t n_cigar = h_ctl[4], n_md = h_ctl[5];
   TAIL_TRY(m.h_rec_begin.need(((size_t)n + 1) * 4));
   TAIL_TRY(m.h_flag.need(r1 * 2));
   TAIL_TRY(m.h_tid.need(r1 * 4));
