@@ -73,6 +73,9 @@ struct Slot {
   bool text_staged = false;
   uint8_t *d_packed = nullptr;            // packed transfer (fem_dev_stage_reads): 2-bit codes + positions of other characters
   size_t packed_cap = 0;
+  uint32_t *d_exc_bits = nullptr;         // ... bit r: read r has such a character (the device tail reads the others' bases from d_packed)
+  size_t exc_bits_cap = 0;
+  uint32_t packed_bpr = 0;
   // fem_dev_fetch callers get the result arrays sent home behind the kernels, without the host waiting for the batch first:
   // the per-read arrays whole, the per-candidate arrays up to what the slot's previous batch needed (the rest at fetch)
   bool prefetch_results = false, staged_by_copy = false;
@@ -1112,7 +1115,7 @@ int fem_dev_close(fem_dev *h) {
     drain_timing(h, s);
     for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
-                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_sel, (void *)s.d_sel_hdr, (void *)s.d_packed, (void *)s.d_quals, (void *)s.d_names,
+                    (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_sel, (void *)s.d_sel_hdr, (void *)s.d_packed, (void *)s.d_exc_bits, (void *)s.d_quals, (void *)s.d_names,
                     (void *)s.d_name_off})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
@@ -1387,10 +1390,16 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
       HIP_TRY(h, hipMemcpyAsync(s.d_packed, hb, total, hipMemcpyHostToDevice, s.stream));
       const uint32_t grid = (uint32_t)std::min<uint64_t>((n * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
       hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed, n, len, bpr, s.bases());
-      if (n_exc)
-        hipLaunchKernelGGL(femk::scatter_chars_kernel, dim3((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u)), dim3(256),
-                           0, s.stream, (const uint32_t *)(s.d_packed + code_bytes), (const uint8_t *)(s.d_packed + code_bytes + 4u * n_exc), n_exc,
-                           s.bases());
+      if ((rc = dev_realloc(h, &s.d_exc_bits, &s.exc_bits_cap, (size_t)n / 32 + 2))) return rc;
+      HIP_TRY(h, hipMemsetAsync(s.d_exc_bits, 0, ((size_t)n / 32 + 1) * sizeof(uint32_t), s.stream));
+      if (n_exc) {
+        const dim3 g((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u));
+        hipLaunchKernelGGL(femk::scatter_chars_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes),
+                           (const uint8_t *)(s.d_packed + code_bytes + 4u * n_exc), n_exc, s.bases());
+        hipLaunchKernelGGL(femk::mark_exception_reads_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes), n_exc, len,
+                           s.d_exc_bits);
+      }
+      s.packed_bpr = bpr;
       hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
                          s.stream, s.d_off, n, len);
       HIP_TRY(h, hipGetLastError());
@@ -1562,6 +1571,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
   in.planes = h->d_planes;
+  if (s.sent_packed) in.packed = s.d_packed, in.packed_bpr = s.packed_bpr, in.exc_bits = s.d_exc_bits;
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
   femt::TailOutput t{};
@@ -1678,6 +1688,7 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   in.bases = s.bases(), in.read_off = s.d_off, in.n_reads = (uint32_t)s.n_reads, in.max_len = s.max_len;
   in.ref_raw = h->d_ref_raw, in.ref_bytes = h->ref_bytes + 64, in.seq_off = h->d_seq_off;
   in.planes = h->d_planes;
+  if (s.sent_packed) in.packed = s.d_packed, in.packed_bpr = s.packed_bpr, in.exc_bits = s.d_exc_bits;
   in.cand = s.d_cand, in.ed = s.d_ed, in.end = s.d_end, in.cand_begin = s.d_begin, in.cand_count = s.d_count;
   in.n_map = s.d_nmap, in.e = s.params.e, in.n_records = s.stats[4];
   femt::TailOutput t{};

@@ -143,6 +143,15 @@ __global__ void scatter_chars_kernel(const uint32_t *at, const uint8_t *ch, uint
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bases[at[i]] = ch[i];
 }
 
+// bit r of bits[]: read r of a batch of equal-length reads has one of the characters the packed transfer sends separately
+__global__ void mark_exception_reads_kernel(const uint32_t *at, uint64_t n, uint32_t len, uint32_t *bits) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t r = at[i] / len;
+    atomicOr(&bits[r >> 5], 1u << (r & 31u));
+  }
+}
+
 struct Picked {
   uint32_t start, lo, freq, pad;
 };

@@ -37,6 +37,9 @@ struct Params {
   const uint8_t *ref_raw;
   uint64_t ref_bytes;
   const uint8_t *planes;
+  const uint8_t *packed;     // TailInput::packed, packed_bpr, exc_bits
+  uint32_t packed_bpr;
+  const uint32_t *exc_bits;
   const uint64_t *seq_off;
   const uint64_t *cand;
   const uint8_t *ed;
@@ -576,6 +579,23 @@ __device__ __forceinline__ uint32_t md_number(uint8_t *md, uint32_t at, uint32_t
   for (uint32_t k = digits; k-- > 0; v /= 10u) md[at + k] = (uint8_t)('0' + v % 10u);
   return at + digits;
 }
+// ---- the read's bases from the packed form of the batch (two bits per base, low bits first; A C G T = 0 1 2 3) ----
+// bases j0 .. j0 + 15 of the read whose row starts at `row` (j0 >= 0), base j0 in bits 0-1
+__device__ __forceinline__ uint32_t packed16(const uint8_t *row, int j0) {
+  const uint8_t *a = row + (j0 >> 2);
+  return __builtin_amdgcn_alignbit(load_u32_unaligned(a + 4), load_u32_unaligned(a), 2u * ((uint32_t)j0 & 3u));
+}
+__device__ __forceinline__ uint32_t reverse_fields2(uint32_t x) {  // the sixteen 2-bit fields in reverse order
+  x = __builtin_bitreverse32(x);
+  return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+__device__ __forceinline__ uint32_t even_bits16(uint32_t x) {  // bits 0, 2, 4 .. 30 -> bits 0 .. 15
+  x &= 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  return (x | (x >> 8)) & 0xFFFFu;
+}
 constexpr uint32_t kSlotDiagonal = 0x80000000u;
 constexpr uint32_t kIdentChunk = 1024;  // records one block classifies at a time (four per thread)
 __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
@@ -612,6 +632,10 @@ __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
         uint32_t odd_ref = 0, odd_text = 0, n_mm = 0, n_md = 0;
         int last = -1;  // the column of the last mismatch
         uint4 W0{}, W1{}, W2{}, W3{};
+        // a read of A C G T only, in a batch that arrived packed: its code bits come out of the packed words with a
+        // handful of shifts (sixteen characters decoded to the same masks are a quarter of this kernel's instructions)
+        const bool from_packed = p.packed != nullptr && !((p.exc_bits[read >> 5] >> (read & 31u)) & 1u);
+        const uint8_t *row = p.packed + (size_t)read * p.packed_bpr;
         for (int col = 0; col < L; col += 16) {
           const int sub = (col >> 4) % 7;  // 7 (bit offset) + 16 * 7 <= 128: one load per plane covers seven steps
           if (sub == 0) {
@@ -621,18 +645,30 @@ __global__ void __launch_bounds__(256) trace_ident_kernel(Params p) {
           } else {
             window_advance16(W0), window_advance16(W1), window_advance16(W2), window_advance16(W3);
           }
-          const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
-          const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
-                                 dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
           const int ncol = L - col < 16 ? L - col : 16;
           uint32_t m0 = 0, m1 = 0, m2 = 0;
+          if (from_packed) {
+            uint32_t t16;  // text[col .. col + 16), two bits each
+            if (dir == 0) {
+              t16 = packed16(row, col);
+            } else if (ncol == 16) {  // text[col + i] = complement(fwd[L - 1 - col - i])
+              t16 = ~reverse_fields2(packed16(row, L - 16 - col));
+            } else {  // the last, partial step: the read's first ncol bases
+              t16 = ~(reverse_fields2(packed16(row, 0)) >> (2u * (uint32_t)(16 - ncol)));
+            }
+            m0 = even_bits16(t16), m1 = even_bits16(t16 >> 1);
+          } else {
+            const uint4 r = load_u128_unaligned(dir == 0 ? fwd + col : fwd + (L - 16 - col));
+            const uint32_t w[4] = {dir ? __builtin_bswap32(r.w) : r.x, dir ? __builtin_bswap32(r.z) : r.y,
+                                   dir ? __builtin_bswap32(r.y) : r.z, dir ? __builtin_bswap32(r.x) : r.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t cw, nw, odd;
-            decode4(w[q], complement, cw, nw, odd);
-            const int nb = ncol - 4 * q;
-            odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
-            m0 |= lsb_mask4(cw) << (4 * q), m1 |= lsb_mask4(cw >> 1) << (4 * q), m2 |= lsb_mask4(nw) << (4 * q);
+            for (int q = 0; q < 4; ++q) {
+              uint32_t cw, nw, odd;
+              decode4(w[q], complement, cw, nw, odd);
+              const int nb = ncol - 4 * q;
+              odd_text |= nb >= 4 ? odd : nb > 0 ? odd & ((1u << (8 * nb)) - 1u) : 0u;
+              m0 |= lsb_mask4(cw) << (4 * q), m1 |= lsb_mask4(cw >> 1) << (4 * q), m2 |= lsb_mask4(nw) << (4 * q);
+            }
           }
           const uint32_t colmask = ncol == 16 ? 0xFFFFu : ((1u << ncol) - 1u);  // ((ref0 + 112 k) & 7 == ref0 & 7)
           odd_ref |= window_head(W3, bit0) & colmask;
@@ -1373,6 +1409,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   p.bases = in.bases, p.read_off = in.read_off, p.n_reads = n;
   p.ref_raw = in.ref_raw, p.ref_bytes = in.ref_bytes, p.seq_off = in.seq_off;
   p.planes = in.planes;
+  p.packed = in.packed, p.packed_bpr = in.packed_bpr, p.exc_bits = in.exc_bits;
   p.cand = in.cand, p.ed = in.ed, p.end = in.end, p.cand_begin = in.cand_begin, p.cand_count = in.cand_count;
   p.e = in.e, p.n_records = nr;
   p.rec_begin = m.rec_begin.as<uint32_t>();

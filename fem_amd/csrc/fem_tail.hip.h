@@ -19,6 +19,12 @@ struct TailInput {  // device pointers unless noted
   uint32_t max_len;            // host: longest read of the batch
   const uint8_t *ref_raw;      // raw reference characters (case kept: the traceback compares characters, src/align.c:355)
   uint64_t ref_bytes;          // host: bytes in ref_raw, its slack included
+  // the batch as it arrived packed (fem_dev_stage_reads on equal-length reads): two bits per base, four bases per byte,
+  // packed_bpr bytes per read; bit r of exc_bits: read r has a character that is not one of ACGT (kept in `bases` only).
+  // nullptr: the batch came as characters.
+  const uint8_t *packed;
+  uint32_t packed_bpr;
+  const uint32_t *exc_bits;
   const uint8_t *planes;       // bit planes over the reference (femk::plane_window): code bits 0..2, and "character is none of ACGTN"
   const uint64_t *seq_off;
   const uint64_t *cand;        // per candidate slot
