@@ -205,6 +205,7 @@ struct fem_dev {
   uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
   uint32_t *d_bank_lo = nullptr;  // [n_banks - 1][n_buckets]: where each further bank's part of a bucket's list starts
   uint64_t bank_limit = 0;        // FEM_TEST_BANK_BASES: coordinates per bank (tests: banks on small references); 0 = kDenseLimit
+  uint32_t bank_seqs = 0;         // FEM_TEST_BANK_SEQS: sequences per bank (tests); 0 = kDenseMaxSeq
   int select_occ_blocks = 0, join_occ_blocks = 0;
   uint64_t select_occ_key = ~0ull, join_occ_key = ~0ull;
   // reference
@@ -875,15 +876,16 @@ int refresh_dense(fem_dev *h) {
   if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
   const uint64_t n_buckets = h->n_lookup - 1;
   if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
-  if (h->n_seq > femk::kDenseMaxSeq) return FEM_OK;
   // Coordinates: goff[seq] + pos, a gap between sequences; where the next sequence would pass the 32-bit limit a new BANK
   // starts with coordinates of its own (fem_seed_dense.hip.h) — up to kDenseMaxBanks of them, else the 64-bit join
   const uint64_t limit = h->bank_limit ? std::min<uint64_t>(h->bank_limit, femk::kDenseLimit) : femk::kDenseLimit;
+  const uint32_t seq_limit = h->bank_seqs ? std::min<uint32_t>(h->bank_seqs, femk::kDenseMaxSeq) : femk::kDenseMaxSeq;
   std::vector<uint32_t> goff(h->n_seq + 1);
   uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
   uint64_t at = femk::kDenseGap;
   for (uint32_t i = 0; i < h->n_seq; ++i) {
-    if (at + (uint64_t)h->seq_len[i] + femk::kDenseGap > limit && at != femk::kDenseGap) {
+    // (a bank also ends at kDenseMaxSeq sequences: the remapped near-start entries carry the index within the bank)
+    if ((at + (uint64_t)h->seq_len[i] + femk::kDenseGap > limit && at != femk::kDenseGap) || i - bank_first[n_banks - 1] >= seq_limit) {
       if (n_banks == femk::kDenseMaxBanks) return FEM_OK;
       bank_first[n_banks++] = i;
       at = femk::kDenseGap;
@@ -926,7 +928,10 @@ int refresh_dense(fem_dev *h) {
     (void)decline();
     return fail(h, FEM_ERR_HIP, "dense tables: copy to the device failed");
   }
-  hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq,
+  femk::BankFirst bf{};
+  bf.n = n_banks;
+  for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) bf.first[b] = bank_first[b];
+  hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq, bf,
                      h->d_occ32, d_bad);
   uint32_t bad = 0;
   if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1097,6 +1102,7 @@ int fem_dev_open(int device, fem_dev **out) {
   const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
   h->tiny_buffers = tb && tb[0] == '1';
   if (const char *bl = getenv("FEM_TEST_BANK_BASES")) h->bank_limit = strtoull(bl, nullptr, 10);
+  if (const char *bs = getenv("FEM_TEST_BANK_SEQS")) h->bank_seqs = (uint32_t)strtoul(bs, nullptr, 10);
   *out = h;
   return FEM_OK;
 }

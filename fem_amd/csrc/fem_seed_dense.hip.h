@@ -25,7 +25,7 @@ namespace femk {
 
 constexpr uint32_t kDenseGap = 2048u;          // positions between two sequences in the global coordinate (> e + 1)
 constexpr uint32_t kDenseNear = 1024u;         // entries with pos < this are stored remapped (>= the longest read)
-constexpr uint32_t kDenseRemap = 0xF0000000u;  // remapped entry: kDenseRemap | seq << 10 | pos  (seq < 2^18)
+constexpr uint32_t kDenseRemap = 0xF0000000u;  // remapped entry: kDenseRemap | seq << 10 | pos  (seq: index within its bank, < 2^18)
 constexpr uint32_t kDenseMaxSeq = 1u << 18;
 // A reference whose sequences do not fit one 32-bit coordinate space is cut into up to kDenseMaxBanks BANKS of consecutive
 // sequences, each with coordinates of its own (goff restarts at kDenseGap).  A bucket's list is sorted by (sequence,
@@ -50,7 +50,10 @@ constexpr uint32_t dense_flag_cap(int R) { return R >= 7 ? FEM_DENSE_FLAGS_HI : 
 
 // ---- derived tables (built once per index upload) ----
 // occ (uint64 seq << 32 | pos) -> global 32-bit coordinates; *bad is set if an entry names a sequence >= n_seq
-__global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32_t *goff, uint32_t n_seq, uint32_t *out,
+struct BankFirst {
+  uint32_t n, first[5];  // bank b = sequences [first[b], first[b + 1])
+};
+__global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32_t *goff, uint32_t n_seq, BankFirst banks, uint32_t *out,
                                    uint32_t *bad) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -61,7 +64,9 @@ __global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32
       v = kDenseSent;
       *bad = 1u;
     } else if (pos < kDenseNear) {
-      v = kDenseRemap | (seq << 10) | pos;
+      uint32_t rel = seq;  // the sequence's index within its bank (< kDenseMaxSeq: refresh_dense cuts the banks so)
+      for (uint32_t b = 1; b < banks.n; ++b) rel = seq >= banks.first[b] ? seq - banks.first[b] : rel;
+      v = kDenseRemap | (rel << 10) | pos;
     } else {
       v = goff[seq] + pos;
     }

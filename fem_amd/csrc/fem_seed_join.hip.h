@@ -55,7 +55,7 @@ __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
 template <int R, bool BANKED = false>
 __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
                           uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */,
-                          uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1) {
+                          uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1, uint32_t seq_base = 0u /* first sequence of the bank */) {
   const uint32_t ln = lane_id();
   constexpr uint32_t kSlots = join_slots(R);
   constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : 15u;
@@ -185,7 +185,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
             v = raw - start;
             if (raw >= kDenseRemap) {
               const uint32_t sq = (raw - kDenseRemap) >> 10, pos = raw & (kDenseNear - 1u);
-              v = pos >= start ? p.goff[sq] + pos - start : kDenseSent;
+              v = pos >= start ? p.goff[seq_base + sq] + pos - start : kDenseSent;
             }
           }
         };
@@ -505,7 +505,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
           uint2 sel_b = make_uint2(0u, 0u);
           if (ln < 2u * kSeeds) sel_b = p.sel[((size_t)read * p.n_banks + b) * (2u * kSeeds) + ln];
           uint32_t kept0 = 0, kept1 = 0;
-          if (!join_read<R, true>(p, sel_b.y & 0xFFFFu, sel_b.x, sel_b.y >> 16, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
+          if (!join_read<R, true>(p, sel_b.y & 0xFFFFu, sel_b.x, sel_b.y >> 16, bitmap, flg, scatter, cand_lds, kept0, kept1, p.bank_first[b])) {
             failed = true;
             break;
           }

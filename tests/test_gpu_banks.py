@@ -14,15 +14,18 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _device(bank_bases):
+def _device(bank_bases, bank_seqs=None):
     from fem_amd import Device
     os.environ["FEM_FORCE_DENSE"] = "1"
     os.environ["FEM_TEST_BANK_BASES"] = str(bank_bases)
+    if bank_seqs:
+        os.environ["FEM_TEST_BANK_SEQS"] = str(bank_seqs)
     try:
         return Device(0)
     finally:
         os.environ.pop("FEM_FORCE_DENSE")
         os.environ.pop("FEM_TEST_BANK_BASES")
+        os.environ.pop("FEM_TEST_BANK_SEQS", None)
 
 
 def _reference(rng, n_seq, shared):
@@ -86,6 +89,24 @@ def test_banked_reference_equals_oracle(e, a, L, bank_bases, n_seq):
         c = want.cands[int(want.cand_off[i]):int(want.cand_off[i + 1])]
         spans += len(set((c >> np.uint64(32)).tolist())) > 1
     assert spans > 20
+
+
+def test_banks_cut_by_the_number_of_sequences():
+    # a bank also ends at 2^18 sequences (the remapped near-start entries of the 32-bit table carry the sequence's index
+    # within its bank); FEM_TEST_BANK_SEQS = 2 cuts seven sequences into banks of 2 + 2 + 2 + 1.  Reads at every
+    # sequence's first bases take that path.
+    rng = np.random.default_rng(77)
+    seqs = _reference(rng, 7, shared=True)
+    L, e = 100, 3
+    reads = util.make_reads(rng, seqs, 600, L, e, n_rate=0.002)
+    for s in seqs:
+        for at in (0, 1, 2, 5, 30, 200, 900, 1020, 1030):
+            reads += [s[at:at + L], fo.revcomp(s[at:at + L])]
+    dev = _device(10_000_000, bank_seqs=2)
+    try:
+        _compare(dev, seqs, reads, e, 1)
+    finally:
+        dev.close()
 
 
 def test_more_banks_than_the_join_takes_falls_back():
