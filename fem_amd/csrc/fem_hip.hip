@@ -882,10 +882,20 @@ int refresh_dense(fem_dev *h) {
   const uint32_t seq_limit = h->bank_seqs ? std::min<uint32_t>(h->bank_seqs, femk::kDenseMaxSeq) : femk::kDenseMaxSeq;
   std::vector<uint32_t> goff(h->n_seq + 1);
   uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
+  // Where more than one bank is needed they are cut about EQUAL, not the first ones filled to the brim: the join runs once
+  // per bank on that bank's part of every list, and a pass over lists of up to 64 entries costs about half of one over
+  // longer lists (their second chunks).  Filling each bank up to the mean + one sequence never needs more banks.
+  uint64_t cap = limit;
+  {
+    uint64_t total_c = femk::kDenseGap, longest = 0;
+    for (uint32_t i = 0; i < h->n_seq; ++i) total_c += (uint64_t)h->seq_len[i] + femk::kDenseGap, longest = std::max<uint64_t>(longest, h->seq_len[i]);
+    const uint64_t want = (total_c + limit - 1) / limit;
+    if (want > 1) cap = std::min<uint64_t>(limit, (total_c + want - 1) / want + longest + femk::kDenseGap);
+  }
   uint64_t at = femk::kDenseGap;
   for (uint32_t i = 0; i < h->n_seq; ++i) {
     // (a bank also ends at kDenseMaxSeq sequences: the remapped near-start entries carry the index within the bank)
-    if ((at + (uint64_t)h->seq_len[i] + femk::kDenseGap > limit && at != femk::kDenseGap) || i - bank_first[n_banks - 1] >= seq_limit) {
+    if ((at + (uint64_t)h->seq_len[i] + femk::kDenseGap > cap && at != femk::kDenseGap) || i - bank_first[n_banks - 1] >= seq_limit) {
       if (n_banks == femk::kDenseMaxBanks) return FEM_OK;
       bank_first[n_banks++] = i;
       at = femk::kDenseGap;

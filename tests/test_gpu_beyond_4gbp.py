@@ -1,6 +1,6 @@
 """A reference beyond the 32-bit coordinate of the dense-index kernels: 30 x 143.4 Mbp = 4.302 Gbp (1 433 999 910 index
 entries, 85 per bucket).  The library keeps seed_select_kernel + seed_join_kernel by cutting the sequences into two banks
-(28 + 2 sequences, fem_seed_dense.hip.h) instead of falling back to the 64-bit hash-join form; candidates, verification
+(16 + 14 sequences: cut about equal, fem_seed_dense.hip.h) instead of falling back to the 64-bit hash-join form; candidates, verification
 and records against the oracle, bit for bit.  ~35 GB of host memory, ~1.5 minutes.  Needs a GPU: -m gpu."""
 import numpy as np
 import pytest
@@ -39,8 +39,8 @@ def test_two_banks_equal_the_oracle(big, e, a, L, n, seed):
     assert np.array_equal(o, want.cand_off) and np.array_equal(cand, want.cands)
     assert np.array_equal(ed, want.v_ed) and np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF])
     assert want.stats[1] > 0.9 * n
-    in_second = (want.cands >> np.uint64(32)) >= 28  # candidates among the second bank's two sequences
-    assert 0.03 * len(want.cands) < in_second.sum() < 0.15 * len(want.cands)
+    in_second = (want.cands >> np.uint64(32)) >= 16  # candidates among the second bank's fourteen sequences
+    assert 0.35 * len(want.cands) < in_second.sum() < 0.6 * len(want.cands)
     rec = dev.fetch_records()
     assert np.array_equal(rec.rec_begin, want.rec_off) and np.array_equal(rec.tid, want.r_tid) and np.array_equal(rec.pos0, want.r_pos)
     assert np.array_equal(rec.cigar, want.cig) and np.array_equal(rec.md, want.md)
