@@ -58,7 +58,7 @@ WORKLOADS = {
     "c5": dict(seed=5, seq_lens=[125_000_000] * 24, L=150, e=7,
                name="C5: synthetic 150 bp reads, e=7, 24x125 Mbp random reference, k=12 step=3"),
 }
-KERNEL_IDS = {"seed": 0, "verify_kernel": 1, "seed_filter_kernel": 2, "count_mappings_kernel": 6, "seed_select_kernel": 8}
+KERNEL_IDS = {"seed": 0, "verify_kernel": 1, "seed_filter_kernel": 2, "seed_select_kernel": 8}
 
 
 def log(*a):

@@ -39,7 +39,7 @@ constexpr uint32_t kMaxReadLen = 1024;
 constexpr size_t kFrontPad = 16;  // kernels fetch a reverse-strand chunk from up to 15 bytes in front of a read
 constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;
 
-constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 verify, 2 generic seed, 3-5 tail, 6 count, 7 SAM text, 8 seed selection
+constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 verify, 2 generic seed, 3-5 tail, 6 unused (the count kernel of rounds 1-2), 7 SAM text, 8 seed selection
 struct TimedLaunch {
   int kernel;
   hipEvent_t start, stop;
@@ -696,6 +696,8 @@ int launch_batch(fem_dev *h, Slot &s) {
     vp.cand = s.d_cand, vp.cand_meta = s.d_meta;
     vp.ctr = d_ctr, vp.cand_cap = s.cand_cap, vp.e = p.e;
     vp.ed = s.d_ed, vp.end = s.d_end;
+    vp.n_map = s.d_nmap, vp.stats = d_stats;
+    HIP_TRY(h, hipMemsetAsync(s.d_nmap, 0, (size_t)s.n_reads * sizeof(uint32_t), s.stream));
     // grid-stride kernel: exactly the blocks that are resident together, or the ones that start late set the makespan
     if (h->verify_blocks_per_cu == 0) {
       int nb = 0;
@@ -810,14 +812,6 @@ int launch_batch(fem_dev *h, Slot &s) {
       if (rc) return rc;
     }
     rc = timed(1, s.stream, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
-    if (rc) return rc;
-    femk::CountParams cp{};
-    cp.cand_begin = s.d_begin, cp.cand_count = s.d_count, cp.ed = s.d_ed, cp.ctr = d_ctr;
-    cp.n_reads = (uint32_t)s.n_reads, cp.n_map = s.d_nmap, cp.stats = d_stats;
-    rc = timed(6, s.stream, [&] {
-      const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((cp.n_reads + 255u) / 256u, (uint32_t)h->n_cu * 8u));
-      hipLaunchKernelGGL(femk::count_mappings_kernel, dim3(blocks), dim3(256), 0, s.stream, cp);
-    });
     if (rc) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_kernels_done, s.stream));
     h->have_kernels_done = true;

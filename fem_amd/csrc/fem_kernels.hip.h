@@ -1077,6 +1077,10 @@ struct VerifyParams {
   int32_t e;
   uint8_t *ed;
   int16_t *end;
+  // MappingStats (src/map.c:37,48,51): accepted candidates per read (zeroed by the launcher), their sum and the reads
+  // with at least one -> stats[2], stats[3]
+  uint32_t *n_map;
+  unsigned long long *stats;
 };
 
 __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p) {
@@ -1105,8 +1109,10 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 //   * read: 16 characters per load, four loads back to back into the lane's LDS words (they share 64-byte sectors;
 //     one load per step missed the L1 every time), decoded four at a time (SWAR), byte-reversed and complemented on
 //     the reverse strand (prepare_negative_sequence_at, src/sequence_batch.h:90-98).
-// Nothing is accumulated here: count_mappings_kernel derives the per-read counts and the counters afterwards (one
-// returning atomic per accepted candidate used to cost as much as everything else in this kernel together).
+// MappingStats (src/map.c:37,48,51): an accepted candidate adds one to its read's n_map — the lane that finds it at zero
+// counts the read as mapped — and a block adds its sums to the two counters once (round 1's returning atomics on the two
+// COUNTERS, same address for every lane, had cost as much as the rest of the kernel; a separate count_mappings_kernel did
+// it until round 3, 0.07 ms between one batch's join and the next's).
 // ---------------------------------------------------------------------------------------------------------
 struct MyersState {
   uint32_t VP, VN;
@@ -1162,6 +1168,8 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   // (1.26 -> 1.14 ms at C2).  Eight chunks at once cost three waves per SIMD and were slower.
   constexpr int kStageChunks = 4;
   __shared__ uint4 stage[kStageChunks][256];
+  __shared__ uint32_t part[2][4];
+  uint32_t mappings = 0, mapped = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const uint32_t meta = p.cand_meta[i];
     if (meta == kInvalidMeta) {
@@ -1252,34 +1260,13 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
     const bool accepted = !rejected && best <= e;
     p.ed[i] = accepted ? (uint8_t)best : (uint8_t)0xFF;
     p.end[i] = accepted ? (int16_t)endp : (int16_t)0;
+    if (accepted) {  // the read's first accepted candidate (whichever lane's atomic comes first) counts the read as mapped
+      mapped += (uint32_t)(atomicAdd(&p.n_map[read], 1u) == 0u);
+      ++mappings;
+    }
   }
-}
-
-// MappingStats after verification (src/map.c:37,48,51): accepted candidates per read -> n_map, their sum ->
-// "number of mapping", reads with at least one -> "number of mapped read".  One lane per read.
-struct CountParams {
-  const uint32_t *cand_begin, *cand_count;  // 2 * n_reads
-  const uint8_t *ed;
-  const uint32_t *ctr;
-  uint32_t n_reads;
-  uint32_t *n_map;
-  unsigned long long *stats;  // [2] mappings, [3] mapped reads
-};
-
-__global__ void __launch_bounds__(256) count_mappings_kernel(CountParams p) {
-  if (p.ctr[1] != 0) return;
-  // grid-stride with per-thread sums and ONE pair of atomics per block: atomics on a single address complete at
-  // roughly 10 ns each, so one pair per wave of reads would cost more than the rest of the batch's verification
-  __shared__ uint32_t part[2][4];
-  uint32_t mappings = 0, mapped = 0;
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_reads; r += gridDim.x * blockDim.x) {
-    const uint2 b = *(const uint2 *)(p.cand_begin + 2u * r), cnt = *(const uint2 *)(p.cand_count + 2u * r);
-    uint32_t n = 0;
-    for (uint32_t i = b.x; i < b.x + cnt.x; ++i) n += (uint32_t)(p.ed[i] != 0xFFu);
-    for (uint32_t i = b.y; i < b.y + cnt.y; ++i) n += (uint32_t)(p.ed[i] != 0xFFu);
-    p.n_map[r] = n;
-    mappings += n, mapped += (uint32_t)(n > 0);
-  }
+  // one pair of atomics per block (same-address atomics complete at ~10 ns each: a pair per wave had cost more than the
+  // verification itself)
   for (int d = 32; d >= 1; d >>= 1) mappings += __shfl_xor(mappings, d), mapped += __shfl_xor(mapped, d);
   if (lane_id() == 0) part[0][threadIdx.x >> 6] = mappings, part[1][threadIdx.x >> 6] = mapped;
   __syncthreads();

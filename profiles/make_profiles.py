@@ -29,7 +29,7 @@ PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slot
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"],
     ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"],
 ]
-KERNELS = ("seed_select_kernel", "seed_join_kernel", "seed_fast_kernel", "seed_filter_kernel", "verify_kernel", "count_mappings_kernel",
+KERNELS = ("seed_select_kernel", "seed_join_kernel", "seed_fast_kernel", "seed_filter_kernel", "verify_kernel",
            "calib_runs", "calib_gather", "calib_pairs")
 
 
