@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "fem_index_build.hip.h"
+#include "fem_pack.h"
 #include "fem_kernels.hip.h"
 #include "fem_seed_fast.hip.h"
 #include "fem_seed_join.hip.h"
@@ -983,62 +984,41 @@ int check_slot(fem_dev *h, int slot) {
 }
 
 
-// ---- packed read transfer: host side (the device side is unpack_reads_kernel) ----
-// Two bits per base, four bases per byte, low bits first.  Only the characters A C G T are packed; every other byte
-// (lower case, N, anything) becomes code 0 and goes to `exc` as index << 8 | byte, so that the device gets the batch back
-// byte for byte: the seed and verification kernels see codes (src/utils.h:72-73), but the traceback compares characters
-// (src/align.c:289-300, :344-366) and a lower-case read takes the reference's assertion path there.
-// `first_index` is the batch-wide index of src[0].
-inline uint32_t code2(uint8_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }  // A C G T -> 0 1 2 3
-inline bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
-void pack_scalar(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index, std::vector<uint64_t> &exc) {
-  for (uint64_t i = 0; i < n; i += 4) {
-    uint32_t b = 0;
-    for (uint32_t q = 0; q < 4 && i + q < n; ++q) {
-      const uint8_t c = src[i + q];
-      if (is_acgt(c)) b |= code2(c) << (2u * q);
-      else exc.push_back(((first_index + i + q) << 8) | c);
-    }
-    dst[i >> 2] = (uint8_t)b;
+// ---- packed read transfer: host side in fem_pack.h (the device side is unpack_reads_kernel) ----
+using fempack::pack_bases;
+
+// Device side of a packed batch that sits in the slot's pinned staging (codes | uint32 positions | bytes, fem_pack.h):
+// one copy, then the characters are rebuilt in HBM byte for byte and the offset table is generated there.
+int enqueue_packed(fem_dev *h, Slot &s, uint64_t n, uint32_t len, uint64_t n_exc) {
+  const uint32_t bpr = fempack::bytes_per_read(len);
+  const uint64_t code_bytes = fempack::code_bytes(n, len), n_bases = n * (uint64_t)len;
+  const uint64_t total = code_bytes + n_exc * 5u;
+  int rc;
+  if ((rc = dev_realloc(h, &s.d_packed, &s.packed_cap, (size_t)total + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
+  if ((rc = dev_realloc(h, &s.d_exc_bits, &s.exc_bits_cap, (size_t)n / 32 + 2))) return rc;
+  if (total) HIP_TRY(h, hipMemcpyAsync(s.d_packed, s.h_bases, total, hipMemcpyHostToDevice, s.stream));
+  if (n) {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
+    hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed, n, len, bpr, s.bases());
   }
-}
-#if defined(__x86_64__)
-__attribute__((target("avx2"))) void pack_avx2(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index,
-                                               std::vector<uint64_t> &exc) {
-  const __m256i three = _mm256_set1_epi8(3);
-  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
-  const __m256i w1 = _mm256_set1_epi16(0x0401), w2 = _mm256_set1_epi32(0x00100001);
-  const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1,
-                                        -1, -1, -1, -1, -1, -1, -1);
-  const __m256i gather = _mm256_setr_epi32(0, 4, 1, 1, 1, 1, 1, 1);
-  uint64_t i = 0;
-  for (; i + 32 <= n; i += 32) {
-    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
-    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, cA), _mm256_cmpeq_epi8(v, cC)),
-                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, cG), _mm256_cmpeq_epi8(v, cT)));
-    // (16-bit shifts: what crosses a byte border lands in bits 6-7 and is masked off)
-    __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
-    code = _mm256_and_si256(code, ok);
-    const __m256i pairs = _mm256_maddubs_epi16(code, w1);  // c0 + 4 c1 per 16 bits
-    const __m256i quads = _mm256_madd_epi16(pairs, w2);    // + 16 (c2 + 4 c3) per 32 bits: the packed byte
-    const __m256i bytes = _mm256_permutevar8x32_epi32(_mm256_shuffle_epi8(quads, pick), gather);
-    _mm_storel_epi64((__m128i *)(dst + (i >> 2)), _mm256_castsi256_si128(bytes));
-    uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok);
-    while (bad) {
-      const uint64_t at = i + (uint64_t)__builtin_ctz(bad);
-      exc.push_back(((first_index + at) << 8) | src[at]);
-      bad &= bad - 1;
-    }
+  HIP_TRY(h, hipMemsetAsync(s.d_exc_bits, 0, ((size_t)n / 32 + 1) * sizeof(uint32_t), s.stream));
+  if (n_exc) {
+    const dim3 g((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u));
+    hipLaunchKernelGGL(femk::scatter_chars_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes),
+                       (const uint8_t *)(s.d_packed + code_bytes + 4u * n_exc), n_exc, s.bases());
+    hipLaunchKernelGGL(femk::mark_exception_reads_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes), n_exc, len,
+                       s.d_exc_bits);
   }
-  if (i < n) pack_scalar(src + i, n - i, dst + (i >> 2), first_index + i, exc);
-}
-#endif
-void pack_bases(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t first_index, std::vector<uint64_t> &exc) {
-#if defined(__x86_64__)
-  static const bool avx2 = __builtin_cpu_supports("avx2");
-  if (avx2) return pack_avx2(src, n, dst, first_index, exc);
-#endif
-  pack_scalar(src, n, dst, first_index, exc);
+  s.packed_bpr = bpr;
+  hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
+                     s.stream, s.d_off, n, len);
+  HIP_TRY(h, hipGetLastError());
+  s.n_reads = n, s.n_bases = n_bases, s.max_len = len;
+  s.staged = true, s.mapped = false, s.synced = false;
+  s.h2d_bytes = total, s.sent_packed = true;
+  return FEM_OK;
 }
 
 unsigned stage_threads(uint64_t n_reads) {
@@ -1315,6 +1295,41 @@ int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_
   return FEM_OK;
 }
 
+int fem_dev_packed_layout(uint64_t n_reads, uint32_t read_len, uint32_t *bytes_per_read, uint64_t *exc_offset, uint64_t *exc_cap) {
+  if (read_len == 0 || read_len > kMaxReadLen) return FEM_ERR_INVALID;
+  const uint64_t n_bases = n_reads * (uint64_t)read_len, cb = fempack::code_bytes(n_reads, read_len);
+  if (bytes_per_read) *bytes_per_read = fempack::bytes_per_read(read_len);
+  if (exc_offset) *exc_offset = cb;
+  // what a staging buffer acquired for n_reads * read_len characters has left behind the codes, and never more than one
+  // byte in sixteen (beyond that the characters themselves are the smaller message: fem_dev_commit_stage_uniform)
+  if (exc_cap) *exc_cap = std::min<uint64_t>((n_bases + 64 - std::min<uint64_t>(cb, n_bases + 64)) / 5u, n_bases / 16u);
+  return FEM_OK;
+}
+
+int fem_dev_commit_stage_packed(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len, uint64_t n_exceptions) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!s.h_bases) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
+  if (read_len == 0 && n_reads) return fail(h, FEM_ERR_INVALID, "packed batches hold reads of one non-zero length");
+  if (read_len > kMaxReadLen)
+    return fail(h, FEM_ERR_UNSUPPORTED, "read longer than the device path supports (" + std::to_string(kMaxReadLen) + ")");
+  const uint64_t n_bases = n_reads * (uint64_t)read_len;
+  if (n_reads > s.acq_reads || n_bases > s.acq_bases) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
+  if (n_bases >= 0xFFFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "a packed batch holds fewer than 2^32 bases; split the batch");
+  const uint64_t code_bytes = fempack::code_bytes(n_reads, read_len);
+  if (code_bytes + n_exceptions * 5u > s.acq_bases + 64 || n_exceptions > n_bases / 16u)
+    return fail(h, FEM_ERR_INVALID, "more exceptions than a packed batch may carry (fem_dev_packed_layout): commit the characters instead");
+  // the positions are the one thing here a wrong value of which would make a kernel write outside its buffers
+  const uint32_t *pos = (const uint32_t *)(s.h_bases + code_bytes);
+  for (uint64_t i = 0; i < n_exceptions; ++i)
+    if (pos[i] >= n_bases) return fail(h, FEM_ERR_INVALID, "exception position outside the batch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((rc = enqueue_packed(h, s, n_reads, read_len, n_exceptions))) return rc;
+  s.staged_by_copy = true;  // (a quarter of the characters' bytes go out: the results may come home behind the kernels, launch_batch)
+  return FEM_OK;
+}
+
 int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
@@ -1393,29 +1408,8 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
       uint8_t *hc = (uint8_t *)(he + n_exc);
       for (const auto &v : exc)
         for (uint64_t x : v) *he++ = (uint32_t)(x >> 8), *hc++ = (uint8_t)x;
-      const uint64_t total = code_bytes + n_exc * 5u;
-      if ((rc = dev_realloc(h, &s.d_packed, &s.packed_cap, (size_t)total + 64))) return rc;
-      if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
-      if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
-      HIP_TRY(h, hipMemcpyAsync(s.d_packed, hb, total, hipMemcpyHostToDevice, s.stream));
-      const uint32_t grid = (uint32_t)std::min<uint64_t>((n * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
-      hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed, n, len, bpr, s.bases());
-      if ((rc = dev_realloc(h, &s.d_exc_bits, &s.exc_bits_cap, (size_t)n / 32 + 2))) return rc;
-      HIP_TRY(h, hipMemsetAsync(s.d_exc_bits, 0, ((size_t)n / 32 + 1) * sizeof(uint32_t), s.stream));
-      if (n_exc) {
-        const dim3 g((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u));
-        hipLaunchKernelGGL(femk::scatter_chars_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes),
-                           (const uint8_t *)(s.d_packed + code_bytes + 4u * n_exc), n_exc, s.bases());
-        hipLaunchKernelGGL(femk::mark_exception_reads_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes), n_exc, len,
-                           s.d_exc_bits);
-      }
-      s.packed_bpr = bpr;
-      hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
-                         s.stream, s.d_off, n, len);
-      HIP_TRY(h, hipGetLastError());
-      s.n_reads = n, s.n_bases = n_bases, s.max_len = len;
-      s.staged = true, s.mapped = false, s.synced = false;
-      s.h2d_bytes = total, s.sent_packed = true, s.staged_by_copy = true;
+      if ((rc = enqueue_packed(h, s, n, len, n_exc))) return rc;
+      s.staged_by_copy = true;
       return FEM_OK;
     }
   }

@@ -1,5 +1,6 @@
 // fem_host.cc — host side of the drop-in (see fem_host.h).  C++17, OpenMP for the per-read loops.
 #include "fem_host.h"
+#include "fem_pack.h"
 
 #include <fcntl.h>
 #include <omp.h>
@@ -982,6 +983,74 @@ int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *pl, int n_threads, char *ba
   return 0;
 }
 
+// The same with the bases written at two bits per base (fem_pack.h; include/fem_hip.h fem_dev_commit_stage_packed) into
+// the staging buffer: no ASCII copy of the batch exists anywhere on the host.  Needs reads of one length (the plan's shape:
+// min_len == max_len == read_len).  Returns 1 — and leaves the plan alive for fem_seqfile_fill — when the batch holds more
+// non-ACGT characters than exc_cap.
+int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off) {
+  if (!f || !pl || !codes || !names || !name_off || !n_exc_out || read_len == 0) return -1;
+  if (n_threads < 1) n_threads = 1;
+  const uint32_t bpr = fempack::bytes_per_read(read_len);
+  *n_exc_out = 0;
+  std::vector<std::vector<uint64_t>> exc;
+  uint64_t n_total = 0;
+  if (!pl->fast) {
+    const fem_seqset &h = pl->held;
+    for (uint64_t i = 0; i < h.n; ++i)
+      if (h.off[i + 1] - h.off[i] != read_len) return -1;
+    exc.resize(1);
+    for (uint64_t i = 0; i < h.n; ++i)
+      fempack::pack_bases((const uint8_t *)h.bases + h.off[i], read_len, codes + i * bpr, i * (uint64_t)read_len, exc[0]);
+    const uint64_t nb = h.n ? h.off[h.n] : 0, nn = h.n ? h.name_off[h.n] : 0;
+    if (quals && h.quals && nb) memcpy(quals, h.quals, nb);
+    if (nn) memcpy(names, h.names, nn);
+    for (uint64_t i = 0; i <= h.n; ++i) name_off[i] = h.n ? h.name_off[i] : 0;
+    n_total = h.n;
+  } else {
+    const char *m = pl->m;
+    const int nt = (int)pl->count.size();
+    std::vector<uint64_t> r0((size_t)nt + 1, 0), n0((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) {
+      if (pl->count[(size_t)t].n && (pl->count[(size_t)t].min_len != read_len || pl->count[(size_t)t].max_len != read_len)) return -1;
+      r0[(size_t)t + 1] = r0[(size_t)t] + pl->count[(size_t)t].n;
+      n0[(size_t)t + 1] = n0[(size_t)t] + pl->count[(size_t)t].names;
+    }
+    exc.resize((size_t)nt);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; ++t) {
+      size_t p = pl->cut[(size_t)t];
+      const size_t h = pl->cut[(size_t)t + 1];
+      uint64_t r = r0[(size_t)t], nm = n0[(size_t)t];
+      FqRec rec;
+      bool bad = false;
+      while (next_fq(m, p, h, rec, bad)) {
+        if (rec.len == 0) continue;
+        name_off[r] = nm;
+        fempack::pack_bases((const uint8_t *)rec.seq, read_len, codes + r * bpr, r * (uint64_t)read_len, exc[(size_t)t]);
+        if (quals) memcpy(quals + r * (uint64_t)read_len, rec.qual, rec.len);
+        memcpy(names + nm, rec.name, rec.name_len);
+        ++r, nm += rec.name_len;
+      }
+    }
+    n_total = r0[(size_t)nt];
+    name_off[n_total] = n0[(size_t)nt];
+  }
+  uint64_t n_exc = 0;
+  for (const auto &v : exc) n_exc += v.size();
+  if (n_exc > exc_cap) return 1;  // (the plan stays: fem_seqfile_fill writes the characters)
+  // the bytes between the codes and the 8-byte boundary the exception positions start at; positions, then the bytes
+  const uint64_t exc_off = fempack::code_bytes(n_total, read_len);
+  for (uint64_t i = n_total * bpr; i < exc_off; ++i) codes[i] = 0;
+  uint32_t *exc_pos = (uint32_t *)(codes + exc_off);
+  uint8_t *exc_chr = (uint8_t *)(exc_pos + n_exc);
+  for (const auto &v : exc)
+    for (uint64_t x : v) *exc_pos++ = (uint32_t)(x >> 8), *exc_chr++ = (uint8_t)x;
+  *n_exc_out = n_exc;
+  fem_batch_plan_free(pl);
+  return 0;
+}
+
 void fem_batch_plan_free(fem_batch_plan *pl) {
   if (!pl) return;
   fem_seqset_free(&pl->held);
@@ -1851,6 +1920,32 @@ void fem_synth_reads_ex(uint64_t seed, const char *ref_text, const uint64_t *seq
       }
     }
   }
+}
+
+// The same reads at two bits per base (fem_pack.h), written straight into `codes` (e.g. the pinned staging lent by
+// fem_dev_acquire_stage): ceil(L / 4) bytes per read.  The generator draws A C G T only, so there are no exceptions.
+void fem_synth_reads_packed(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len, uint32_t n_seq,
+                            uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, uint8_t *codes, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  const uint32_t bpr = fempack::bytes_per_read(L);
+  constexpr uint64_t kPiece = 4096;  // reads generated as characters and packed at a time (they stay in the core's cache)
+  const int64_t n_pieces = (int64_t)((n_reads + kPiece - 1) / kPiece);
+#pragma omp parallel num_threads(n_threads)
+  {
+    std::vector<char> tmp(kPiece * L + 64);
+    std::vector<uint64_t> exc;
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t pc = 0; pc < n_pieces; ++pc) {
+      const uint64_t lo = (uint64_t)pc * kPiece, n = std::min<uint64_t>(kPiece, n_reads - lo);
+      fem_synth_reads_ex(seed, ref_text, seq_off, seq_len, n_seq, first_read + lo, n, L, e, tmp.data(), nullptr, 1);
+      if ((L & 3u) == 0u) {
+        fempack::pack_bases((const uint8_t *)tmp.data(), n * L, codes + lo * bpr, lo * L, exc);
+      } else {
+        for (uint64_t i = 0; i < n; ++i) fempack::pack_bases((const uint8_t *)tmp.data() + i * L, L, codes + (lo + i) * bpr, (lo + i) * L, exc);
+      }
+    }
+  }
+  for (uint64_t i = n_reads * bpr; i < fempack::code_bytes(n_reads, L); ++i) codes[i] = 0;
 }
 
 int fem_synth_write_fastq(const char *path, const char *bases, uint32_t L, uint64_t n_reads, uint64_t first_index) {

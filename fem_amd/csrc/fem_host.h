@@ -61,6 +61,15 @@ typedef struct {
 int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_batch_plan **plan, fem_batch_shape *shape);
 int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *plan, int n_threads, char *bases, uint64_t *off, char *quals,
                      char *names, uint64_t *name_off);
+/* fill with the bases written at TWO BITS PER BASE, the form fem_dev_commit_stage_packed (include/fem_hip.h) takes: `codes`
+ * is the staging buffer; the characters outside "ACGT" are listed behind the codes as that call wants them (positions at
+ * the 8-byte boundary behind n_reads * ceil(read_len / 4) code bytes, then the bytes; fem_dev_packed_layout gives exc_cap,
+ * how many the buffer and the format take).  For plans whose shape has min_len == max_len == read_len.  quals, names and
+ * name_off as in fem_seqfile_fill (qualities of read i at quals + i * read_len).  Returns 0 (plan freed, *n_exc set), 1 =
+ * the batch holds more than exc_cap such characters (nothing is lost: the plan is still there, call fem_seqfile_fill for
+ * the characters), < 0 on a bad argument. */
+int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *plan, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                            uint64_t *n_exc, char *quals, char *names, uint64_t *name_off);
 void fem_batch_plan_free(fem_batch_plan *plan);
 
 /* ---------------- index files (src/index.c:100-168) ---------------- */
@@ -157,6 +166,11 @@ void fem_synth_reads(uint64_t seed, const char *ref_text, const uint64_t *seq_of
 void fem_synth_reads_ex(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len,
                         uint32_t n_seq, uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, char *bases_out,
                         uint8_t *n_err_out, int n_threads);
+
+/* the same reads at two bits per base, ceil(L / 4) bytes per read (the form fem_dev_commit_stage_packed takes; the
+ * generator draws A C G T only: no exceptions), padded with zero bytes to the next multiple of 8 */
+void fem_synth_reads_packed(uint64_t seed, const char *ref_text, const uint64_t *seq_off, const uint32_t *seq_len, uint32_t n_seq,
+                            uint64_t first_read, uint64_t n_reads, uint32_t L, int32_t e, uint8_t *codes, int n_threads);
 
 /* Writes reads as FASTQ ("@r<index>", constant quality 'I') or a reference as FASTA (60 columns); for the
  * end-to-end measurements and tests.  Returns 0 or <0. */

@@ -224,7 +224,8 @@ struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pa
   uint64_t *off = nullptr;
   uint64_t reads_cap = 0, bases_cap = 0;
   Growable quals, names, name_off;  // host formatting (FEM_HOST_FORMAT=1 / FEM_HOST_TAIL=1): names and qualities stay on the host
-  Growable bases_host, off_host;                // packed transfer: the parser's bases, packed into the staging by the library
+  bool packed = false;                          // the parser wrote this batch at two bits per base (fem_seqfile_fill_packed)
+  uint64_t n_exc = 0;                           // ... and this many characters outside "ACGT" behind the codes
   char *q_stage = nullptr, *n_stage = nullptr;  // device SAM text: pinned staging lent by the library
   uint64_t *no_stage = nullptr;
   uint64_t names_cap = 0, want_names = 0;
@@ -331,8 +332,9 @@ int map_main(int argc, char **argv) {
   // host threads) or FEM_HOST_TAIL=1 (ordering, traceback and text by the host threads)
   const char *hf = getenv("FEM_HOST_FORMAT");
   const bool device_text = !host_tail && !(hf && hf[0] == '1');
-  // With the text on the device the link is what bounds the run: the bases then cross it packed (fem_dev_stage_reads: two
-  // bits per base for equal-length reads) instead of through the zero-copy staging (FEM_PACK_BASES=0: as characters).
+  // With the text on the device the link is what bounds the run: batches of equal-length reads then cross it at two bits per
+  // base — the parser writes that form straight into the pinned staging (fem_seqfile_fill_packed ->
+  // fem_dev_commit_stage_packed: no host work per base beyond the parse itself) (FEM_PACK_BASES=0: always as characters).
   const char *pk = getenv("FEM_PACK_BASES");
   const bool pack_bases = device_text && !(pk && pk[0] == '0');
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
@@ -526,15 +528,7 @@ int map_main(int argc, char **argv) {
         char *pb = nullptr;
         uint64_t *po = nullptr;
         int rc = 0;
-        if (pack_bases) {  // the parser writes to ordinary memory; the library packs from there into its staging
-          if (!b->bases_host.reserve(bases_cap + 64) || !b->off_host.reserve((reads_cap + 1) * sizeof(uint64_t))) {
-            if (!exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] out of memory\n");
-            return false;
-          }
-          pb = b->bases_host.p, po = (uint64_t *)b->off_host.p;
-        } else {
-          rc = fem_dev_acquire_stage(h, b->slot, reads_cap, bases_cap, &pb, &po);
-        }
+        rc = fem_dev_acquire_stage(h, b->slot, reads_cap, bases_cap, &pb, &po);
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "staging buffers", rc);
           return false;
@@ -610,9 +604,8 @@ int map_main(int argc, char **argv) {
         }
         BatchBuf *b = m.b;  // kFilled
         b->t_submit = real_time();
-        fem_read_batch rb{b->bases, b->off, b->shape.n_reads};
         int rc = exit_code ? FEM_ERR_STATE
-                 : pack_bases ? fem_dev_stage_reads(h, b->slot, &rb)
+                 : b->packed ? fem_dev_commit_stage_packed(h, b->slot, b->shape.n_reads, b->shape.max_len, b->n_exc)
                  : b->shape.min_len == b->shape.max_len  // reads of one length: the offsets need not cross the link
                      ? fem_dev_commit_stage_uniform(h, b->slot, b->shape.n_reads, b->shape.max_len)
                      : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
@@ -680,8 +673,19 @@ int map_main(int argc, char **argv) {
         busy_read += real_time() - t0;
         break;  // end of input (or failure)
       }
-      rc = device_text ? fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->q_stage, b->n_stage, b->no_stage)
-                       : fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
+      b->packed = false, b->n_exc = 0;
+      rc = 1;
+      if (pack_bases && b->shape.min_len == b->shape.max_len && b->shape.n_bases < 0xFFFFFFF0ull) {
+        // reads of one length: two bits per base straight into the staging; 1 = too many characters outside "ACGT" for that form
+        uint64_t exc_cap = 0;
+        if (fem_dev_packed_layout(b->shape.n_reads, b->shape.max_len, nullptr, nullptr, &exc_cap) == FEM_OK)
+          rc = fem_seqfile_fill_packed(f, plan, rd_threads, b->shape.max_len, (uint8_t *)b->bases, exc_cap, &b->n_exc, b->q_stage, b->n_stage,
+                                       b->no_stage);
+        b->packed = rc == 0;
+      }
+      if (rc == 1)
+        rc = device_text ? fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->q_stage, b->n_stage, b->no_stage)
+                         : fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->quals.p, b->names.p, (uint64_t *)b->name_off.p);
       busy_read += real_time() - t0;
       if (rc) {
         fprintf(stderr, "[FEM] reading failed\n");

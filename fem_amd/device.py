@@ -12,7 +12,7 @@ ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
-    "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
@@ -85,6 +85,8 @@ def load_hip():
     L.fem_dev_acquire_stage.argtypes = [vp, C.c_int, u64, u64, C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_stage.argtypes = [vp, C.c_int, u64, C.c_uint32]
     L.fem_dev_commit_stage_uniform.argtypes = [vp, C.c_int, u64, C.c_uint32]
+    L.fem_dev_packed_layout.argtypes = [u64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), C.POINTER(u64)]
+    L.fem_dev_commit_stage_packed.argtypes = [vp, C.c_int, u64, C.c_uint32, u64]
     L.fem_dev_map_staged.argtypes = [vp, C.c_int, C.POINTER(Params)]
     L.fem_dev_sync.argtypes = [vp, C.c_int]
     L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
@@ -125,6 +127,38 @@ def device_numa(device=0):
 def bind_near_device(device=0):
     """Restricts the calling thread (and the threads it starts later) to the CPUs next to GPU `device`; True if bound."""
     return load_hip().fem_bind_thread_near_device(int(device)) == 0
+
+
+def packed_layout(n_reads, read_len):
+    """(bytes per read, offset of the exception positions behind the codes, most exceptions a packed batch may carry)
+    of fem_dev_commit_stage_packed's staging layout."""
+    bpr, off, cap = C.c_uint32(), C.c_uint64(), C.c_uint64()
+    rc = load_hip().fem_dev_packed_layout(int(n_reads), int(read_len), C.byref(bpr), C.byref(off), C.byref(cap))
+    if rc != 0:
+        raise FemError("fem_dev_packed_layout: %d" % rc)
+    return bpr.value, off.value, cap.value
+
+
+def pack_reads(bases, n_reads, read_len, out):
+    """numpy restatement of the packed form (tests): characters of n_reads reads of read_len -> codes + exceptions
+    written into `out` (a staging view); returns the number of exceptions."""
+    bpr, exc_off, exc_cap = packed_layout(n_reads, read_len)
+    b = np.asarray(bases[:n_reads * read_len], dtype=np.uint8).reshape(n_reads, read_len)
+    ok = (b == 65) | (b == 67) | (b == 71) | (b == 84)
+    code = np.where(ok, ((b >> 1) ^ (b >> 2)) & 3, 0).astype(np.uint8)
+    pad = bpr * 4 - read_len
+    if pad:
+        code = np.concatenate([code, np.zeros((n_reads, pad), np.uint8)], axis=1)
+    q = code.reshape(n_reads, bpr, 4)
+    out[:n_reads * bpr] = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).reshape(-1)
+    out[n_reads * bpr:exc_off] = 0
+    pos = np.flatnonzero(~ok.reshape(-1)).astype(np.uint32)
+    n_exc = len(pos)
+    if n_exc > exc_cap:
+        raise FemError("too many exceptions for a packed batch")
+    out[exc_off:exc_off + 4 * n_exc] = pos.view(np.uint8)
+    out[exc_off + 4 * n_exc:exc_off + 5 * n_exc] = b.reshape(-1)[pos]
+    return n_exc
 
 
 def _copy(ptr, n, dtype, copy=True):
@@ -273,6 +307,10 @@ class Device:
             self._check(self._L.fem_dev_commit_stage_uniform(self._h, slot, n_reads, max_len))
         else:
             self._check(self._L.fem_dev_commit_stage(self._h, slot, n_reads, max_len))
+
+    def commit_stage_packed(self, n_reads, read_len, n_exc=0, slot=0):
+        """The slot's staging holds the batch at two bits per base + n_exc exceptions (packed_layout)."""
+        self._check(self._L.fem_dev_commit_stage_packed(self._h, slot, n_reads, read_len, n_exc))
 
     def map_staged(self, e=3, a=1, k=12, step=3, slot=0):
         p = Params(k, step, e, a)

@@ -64,6 +64,7 @@ def lib():
         L.fem_seqfile_read_bytes.argtypes = [vp, u64, C.c_int, C.POINTER(SeqSet)]
         L.fem_seqfile_plan.argtypes = [vp, u64, C.c_int, C.POINTER(vp), C.POINTER(BatchShape)]
         L.fem_seqfile_fill.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        L.fem_seqfile_fill_packed.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, u64, C.POINTER(u64), vp, vp, vp]
         L.fem_batch_plan_free.argtypes = [vp]
         L.fem_records_sam.argtypes = [C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(RecordView), C.c_int, C.POINTER(vp),
                                       C.POINTER(u64)]
@@ -81,6 +82,7 @@ def lib():
         L.fem_synth_reference.argtypes = [u64, C.c_uint32, vp, vp, vp, C.c_int]
         L.fem_synth_reads.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
         L.fem_synth_reads_ex.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, vp, C.c_int]
+        L.fem_synth_reads_packed.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
         L.fem_synth_write_fastq.argtypes = [C.c_char_p, vp, C.c_uint32, u64, u64]
         L.fem_synth_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint32]
         L.free = C.CDLL(None).free
@@ -129,6 +131,16 @@ def synth_reads(seed, text, off, lens, n_reads, L, e, first_read=0, threads=8, o
         offsets = out_offsets
         offsets[:n_reads + 1] = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
     return bases, offsets
+
+
+def synth_reads_packed(seed, text, off, lens, n_reads, L, e, out, first_read=0, threads=8):
+    """The reads of synth_reads at two bits per base, written into `out` (uint8; e.g. the staging view of
+    Device.acquire_stage): ceil(L / 4) bytes per read, zero-padded to a multiple of 8.  No exceptions (A C G T only)."""
+    bpr = (L + 3) // 4
+    assert out.dtype == np.uint8 and len(out) >= ((n_reads * bpr + 7) & ~7)
+    lib().fem_synth_reads_packed(seed, text.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens), first_read, n_reads,
+                                 L, e, out.ctypes.data, threads)
+    return out
 
 
 def write_fastq(path, bases, L, n_reads, first_index=0):
@@ -225,9 +237,32 @@ class PlannedBatch:
         return self.names_raw[int(self.name_off[i]):int(self.name_off[i + 1])].tobytes().decode()
 
 
-def read_planned_batches(path, approx_bytes, threads=4, alloc=None):
+class PackedBatch:
+    """One batch read by fem_seqfile_plan + fem_seqfile_fill_packed: `codes` holds the staging layout of
+    fem_dev_commit_stage_packed (codes, exception positions, exception bytes)."""
+
+    def __init__(self, shape, codes, n_exc, quals, names, name_off):
+        self.n = int(shape.n_reads)
+        self.read_len = int(shape.max_len)
+        self.codes, self.n_exc, self.quals, self.names_raw, self.name_off = codes, int(n_exc), quals, names, name_off
+
+    def unpack(self):
+        """The batch's characters, rebuilt on the host as the device rebuilds them (tests)."""
+        n, L = self.n, self.read_len
+        bpr = (L + 3) // 4
+        c = self.codes[:n * bpr].reshape(n, bpr)
+        q = np.stack([(c >> (2 * j)) & 3 for j in range(4)], axis=2).reshape(n, bpr * 4)[:, :L]
+        out = np.frombuffer(b"ACGT", np.uint8)[q].reshape(-1).copy()
+        exc_off = (n * bpr + 7) & ~7
+        pos = self.codes[exc_off:exc_off + 4 * self.n_exc].view(np.uint32)
+        out[pos] = self.codes[exc_off + 4 * self.n_exc:exc_off + 5 * self.n_exc]
+        return out
+
+
+def read_planned_batches(path, approx_bytes, threads=4, alloc=None, packed=False):
     """All records of a file through the two-phase reader the command line uses; `alloc(n_reads, n_bases)` may hand
-    out the (bases uint8[n_bases + 64], off uint64[n_reads + 1]) arrays (e.g. pinned staging views)."""
+    out the (bases uint8[n_bases + 64], off uint64[n_reads + 1]) arrays (e.g. pinned staging views).  packed=True:
+    batches of equal-length reads come back as PackedBatch (fem_seqfile_fill_packed), others as PlannedBatch."""
     L = lib()
     f = L.fem_seqfile_open(path.encode())
     if not f:
@@ -252,6 +287,18 @@ def read_planned_batches(path, approx_bytes, threads=4, alloc=None):
             quals = np.zeros(nb + 1, np.uint8) if shape.has_qual else None
             names = np.zeros(int(shape.n_name_bytes) + 1, np.uint8)
             name_off = np.zeros(n + 1, np.uint64)
+            if packed and shape.min_len == shape.max_len:
+                bpr = (int(shape.max_len) + 3) // 4
+                exc_off = (n * bpr + 7) & ~7
+                exc_cap = min((nb + 64 - min(exc_off, nb + 64)) // 5, nb // 16)
+                n_exc = C.c_uint64()
+                rc = L.fem_seqfile_fill_packed(f, plan, threads, shape.max_len, bases.ctypes.data, exc_cap, C.byref(n_exc),
+                                               quals.ctypes.data if quals is not None else None, names.ctypes.data, name_off.ctypes.data)
+                if rc == 0:
+                    out.append(PackedBatch(shape, bases, n_exc.value, quals, names, name_off))
+                    continue
+                if rc != 1:
+                    raise ValueError("fem_seqfile_fill_packed failed (%d)" % rc)
             rc = L.fem_seqfile_fill(f, plan, threads, bases.ctypes.data, off.ctypes.data,
                                     quals.ctypes.data if quals is not None else None, names.ctypes.data, name_off.ctypes.data)
             if rc != 0:

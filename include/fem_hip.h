@@ -174,6 +174,22 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
  * read i sits at bases + i * read_len, and the offset table is neither read from the staging buffer nor copied —
  * it is generated on the device (8 of the 108 bytes per 100 bp read that cross the host link otherwise). */
 int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len);
+/* The same for a batch the caller (a FASTQ parser, a sequencer's base caller) already holds at TWO BITS PER BASE — what the
+ * device consumes; fem_dev_stage_reads produces this form from characters on the library's host threads, this entry point
+ * takes it as it is: no host work per base, a quarter of the bytes over the link.  The reusable batch of
+ * src/input_queue.c:34-79 in the form the GPU wants.  Layout inside the `bases` buffer lent by fem_dev_acquire_stage
+ * (acquired for n_reads * read_len characters as before):
+ *   codes    read i takes bytes [i * bpr, (i + 1) * bpr), bpr = ceil(read_len / 4); base j of a read sits in bits
+ *            2 (j & 3) of its byte j / 4; A C G T = 0 1 2 3 (src/utils.h:72); unused bits zero;
+ *   at byte exc_offset = n_reads * bpr rounded up to 8:  uint32 pos[n_exceptions], then uint8 chr[n_exceptions] —
+ *            every character of the batch that is not one of the upper-case letters A C G T (N, lower case, anything):
+ *            its index in the batch (i * read_len + j; its code bits are 0) and the byte itself.  The device rebuilds the
+ *            batch byte for byte (the traceback compares characters, src/align.c:289-300).
+ * fem_dev_packed_layout: bpr, exc_offset and the most exceptions such a batch may carry (one byte in sixteen, and what
+ * the buffer has room for); a batch with more goes through fem_dev_commit_stage_uniform as characters.  Needs no handle.
+ * commit_stage_packed checks the exception positions (a wrong one would write outside the batch) and nothing else. */
+int fem_dev_packed_layout(uint64_t n_reads, uint32_t read_len, uint32_t *bytes_per_read, uint64_t *exc_offset, uint64_t *exc_cap);
+int fem_dev_commit_stage_packed(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len, uint64_t n_exceptions);
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p);          /* kernels only, asynchronous */
 int fem_dev_sync(fem_dev *h, int slot);                                     /* wait; re-runs on scratch overflow */
 int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* sync + the five counters */
@@ -220,7 +236,8 @@ const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
  * form queued, or every read when the fast form does not apply); of
  * fem_dev_fetch_records: 3 = ordering of the mappings, 4 = traceback + MD,
  * 5 = compaction (one entry per call, several kernels each);
- * 6 = per-read mapping counts + counters after verification; of fem_dev_fetch_sam: 7 = the SAM text kernels;
+ * 6 = unused, always 0 (the count kernel of rounds 1-2; the counters come out of kernel 1 now); of fem_dev_fetch_sam:
+ * 7 = the SAM text kernels;
  * 8 = seed selection kernel of the dense-index path (it runs beside the previous batch's kernel 0: its event time is
  * what it takes there, not what it would take alone). */
 int fem_dev_set_timing(fem_dev *h, int on);

@@ -125,3 +125,120 @@ def test_dense_form_declines_what_its_32_bit_coordinates_cannot_hold():
         assert want.stats[1] > 150
     finally:
         dev.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The OVERLAPPED pipeline on a dense index — what bench.py's `value` times: four slots, four batches in flight, batch
+# i + 1's seed_select_kernel running beside batch i's seed_join_kernel (launch_batch, fem_hip.hip).  Every batch's
+# candidates / edit distances / end offsets / counters (and, in the second form, records) against the oracle, array for
+# array (src/map.c:27-55 per read).
+# ---------------------------------------------------------------------------------------------------------------------
+_SHAPES = [(3, 100), (7, 150), (5, 125), (2, 64), (3, 101), (4, 100)]
+
+
+def _pipeline_batches(d, seed, n_batches, sizes, with_records, extra_of=None):
+    from fem_amd import host
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n_batches):
+        e, L = _SHAPES[int(rng.integers(0, len(_SHAPES)))]
+        n = int(rng.choice(sizes))
+        bases, offsets = host.synth_reads(seed * 1000 + i, d["text"], d["off"], d["lens"], n, L, e, threads=8)
+        reads = [bases[int(offsets[j]):int(offsets[j + 1])].tobytes() for j in range(n)]
+        if extra_of is not None and i % 5 == 2:
+            reads += extra_of(L)
+        if i % 7 == 3 and n > 4:  # mixed lengths: characters + offsets instead of the packed transfer
+            reads[1] = reads[1][:L - 7]
+        if i % 6 == 1 and n:
+            reads[0] = b"N" * 3 + reads[0][3:]
+        b = fo.ReadBatch(reads)
+        stages = fo.STAGE_SEED | fo.STAGE_VERIFY | (fo.STAGE_ALIGN if with_records else 0)
+        out.append((b, e, fo.map_reads(d["ref"], d["idx"], b, e=e, threads=8, stages=stages)))
+    return out
+
+
+def _run_overlapped(dev, items, with_records, depth=4, n_slots=4, form="stage_reads"):
+    from fem_amd import device
+
+    def check(i):
+        b, e, want = items[i]
+        s = i % n_slots
+        if with_records and i % 2 == 0:  # the device tail of this batch while the next batches' kernels run
+            rec = dev.fetch_records(slot=s)
+            assert np.array_equal(rec.stats, want.stats), i
+            assert np.array_equal(rec.rec_begin, want.rec_off) and np.array_equal(rec.flag, want.r_flag), i
+            assert np.array_equal(rec.pos0, want.r_pos) and np.array_equal(rec.nm, want.r_nm) and np.array_equal(rec.tid, want.r_tid), i
+            assert np.array_equal(rec.cigar_off, want.cig_off) and np.array_equal(rec.cigar, want.cig), i
+            assert np.array_equal(rec.md_off, want.md_off) and np.array_equal(rec.md, want.md), i
+        got = dev.fetch(slot=s, copy=False)
+        off, cand, ed, end = got.per_strand()
+        assert np.array_equal(got.stats, want.stats), (i, got.stats, want.stats)
+        assert np.array_equal(off, want.cand_off), i
+        assert np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed), i
+        assert np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF]), i
+
+    for i, (b, e, want) in enumerate(items):
+        if i >= depth:
+            check(i - depth)
+        s = i % n_slots
+        n = len(b.off) - 1
+        lens = np.diff(b.off.astype(np.int64))
+        if form == "packed_commit" and n and lens.min() == lens.max():
+            L = int(lens[0])
+            hb, _ = dev.acquire_stage(n, n * L, slot=s)
+            dev.commit_stage_packed(n, L, device.pack_reads(b.bases, n, L, hb), slot=s)
+        else:
+            dev.stage_reads(b.bases, b.off, slot=s)
+        dev.map_staged(e=e, slot=s)
+    for i in range(max(0, len(items) - depth), len(items)):
+        check(i)
+
+
+def test_overlapped_pipeline_on_a_dense_index_equals_the_oracle(dense):
+    assert dense["dev"].seed_kernel(e=3) == "seed_join_kernel"
+    items = _pipeline_batches(dense, 9101, 28, [0, 1, 900, 20_000, 45_000, 70_000], False, extra_of=lambda L: _edge_reads(dense, L))
+    _run_overlapped(dense["dev"], items, False)
+    _run_overlapped(dense["dev"], items[:12], False, form="packed_commit")
+
+
+def test_overlapped_pipeline_with_records_on_a_dense_index_equals_the_oracle(dense):
+    items = _pipeline_batches(dense, 9102, 24, [1, 700, 15_000, 30_000], True, extra_of=lambda L: _edge_reads(dense, L))
+    _run_overlapped(dense["dev"], items, True)
+
+
+@pytest.mark.parametrize("banked", [False, True])
+def test_overlapped_pipeline_on_a_forced_dense_index(banked):
+    # a small repeat-rich reference through the dense kernels (FEM_FORCE_DENSE=1), whole and cut into banks
+    # (FEM_TEST_BANK_BASES): long lists, reads the join hands to the generic kernel, many candidates per strand
+    from fem_amd import Device
+    from tests import util
+    rng = np.random.default_rng(515 + banked)
+    seqs = util.repeat_rich_reference(rng, n_seq=4, unit_len=300, n_units=10, copies=30)
+    bank_bases = int(0.6 * sum(len(s) + 2048 for s in seqs)) if banked else 0  # two banks of two sequences
+    ref = fo.Reference(seqs)
+    idx = fo.OracleIndex(ref)
+    os.environ["FEM_FORCE_DENSE"] = "1"
+    if bank_bases:
+        os.environ["FEM_TEST_BANK_BASES"] = str(bank_bases)
+    try:
+        dev = Device(0)
+    finally:
+        os.environ.pop("FEM_FORCE_DENSE")
+        os.environ.pop("FEM_TEST_BANK_BASES", None)
+    try:
+        dev.upload_reference(seqs)
+        dev.upload_index(12, 3, idx.lookup, idx.occ[:idx.n_occ])
+        assert dev.seed_kernel(e=3) == ("seed_join_banked_kernel" if bank_bases else "seed_join_kernel")
+        items = []
+        for i in range(26):
+            e, L = _SHAPES[int(rng.integers(0, len(_SHAPES)))]
+            n = int(rng.choice([0, 3, 400, 2500, 6000]))
+            reads = util.make_reads(rng, seqs, n, L, e, n_rate=0.01 if i % 4 == 0 else 0.0)
+            if i % 7 == 3 and n > 4:
+                reads[2] = reads[2][:L - 9]
+            b = fo.ReadBatch(reads)
+            items.append((b, e, fo.map_reads(ref, idx, b, e=e, threads=8)))
+        _run_overlapped(dev, items, True)
+        _run_overlapped(dev, items[:10], False, form="packed_commit")
+    finally:
+        dev.close()

@@ -123,3 +123,67 @@ def test_batches_the_packing_declines(setup):
     one = fo.ReadBatch([mixed[0]])
     got = dev.map_batch(one.bases, one.off, e=3)
     assert dev.stage_info()[1] and got.stats[0] == 1
+
+
+@pytest.mark.parametrize("L,e,n", [(100, 3, 3000), (150, 7, 1200), (101, 3, 900), (37, 1, 300), (64, 2, 70000)])
+def test_packed_commit_gives_the_results_of_stage_reads_and_the_oracle(setup, L, e, n):
+    # fem_dev_commit_stage_packed: the caller writes two bits per base + the exceptions into the pinned staging itself
+    # (here numpy's restatement of the layout, fem_amd.device.pack_reads) — no host work in the library
+    from fem_amd import device
+    rng, seqs, ref, idx, dev = setup
+    reads = _odd_characters(rng, util.make_reads(rng, seqs, n, L, e), 0.3)
+    reads[0] = b"N" + reads[0][1:]
+    reads[-1] = reads[-1][:-1] + b"n"
+    batch = fo.ReadBatch(reads)
+    want = fo.map_reads(ref, idx, batch, e=e, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    hb, _ = dev.acquire_stage(n, n * L, slot=2)
+    n_exc = device.pack_reads(batch.bases, n, L, hb)
+    assert n_exc == sum(sum(1 for c in r if c not in b"ACGT") for r in reads)
+    dev.commit_stage_packed(n, L, n_exc, slot=2)
+    n_bytes, packed = dev.stage_info(2)
+    bpr, exc_off, exc_cap = device.packed_layout(n, L)
+    assert packed and n_bytes == exc_off + 5 * n_exc and bpr == (L + 3) // 4 and exc_off == (n * bpr + 7) // 8 * 8 and exc_cap >= n_exc
+    dev.map_staged(e=e, slot=2)
+    got = dev.fetch(slot=2)
+    ref_run = dev.map_batch(batch.bases, batch.off, e=e, slot=1)
+    assert _same(got, ref_run)
+    off, cand, ed, end = got.per_strand()
+    assert np.array_equal(got.stats, want.stats)
+    assert np.array_equal(off, want.cand_off) and np.array_equal(cand, want.cands) and np.array_equal(ed, want.v_ed)
+    assert np.array_equal(end[ed != 0xFF], want.v_end[want.v_ed != 0xFF])
+    # the same staging committed again without another acquire (the reusable batch), and the device tail behind it
+    dev.commit_stage_packed(n, L, n_exc, slot=2)
+    dev.map_staged(e=e, slot=2)
+    rec = dev.fetch_records(slot=2)
+    dev.stage_reads(batch.bases, batch.off, slot=1)
+    dev.map_staged(e=e, slot=1)
+    rec1 = dev.fetch_records(slot=1)
+    for f in ("rec_begin", "flag", "tid", "pos0", "nm", "cigar_off", "cigar", "md_off", "md"):
+        assert np.array_equal(getattr(rec, f), getattr(rec1, f)), f
+
+
+def test_packed_commit_refuses_what_it_cannot_take(setup):
+    from fem_amd import FemError, device
+    rng, seqs, ref, idx, dev = setup
+    n, L = 64, 100
+    hb, _ = dev.acquire_stage(n, n * L, slot=3)
+    reads = util.make_reads(rng, seqs, n, L, 3)
+    n_exc = device.pack_reads(fo.ReadBatch(reads).bases, n, L, hb)
+    assert n_exc == 0
+    with pytest.raises(FemError):
+        dev.commit_stage_packed(n + 1, L, 0, slot=3)          # more reads than acquired
+    with pytest.raises(FemError):
+        dev.commit_stage_packed(n, 2000, 0, slot=3)           # beyond fem_dev_limits
+    with pytest.raises(FemError):
+        dev.commit_stage_packed(n, L, n * L // 16 + 1, slot=3)  # more exceptions than the form takes
+    bpr, exc_off, _ = device.packed_layout(n, L)
+    hb[exc_off:exc_off + 4] = np.array([n * L], np.uint32).view(np.uint8)  # a position outside the batch
+    with pytest.raises(FemError):
+        dev.commit_stage_packed(n, L, 1, slot=3)
+    dev.commit_stage_packed(n, L, 0, slot=3)
+    dev.map_staged(e=3, slot=3)
+    assert dev.fetch_stats(slot=3)[0] == n
+    # an empty batch
+    dev.commit_stage_packed(0, L, 0, slot=3)
+    dev.map_staged(e=3, slot=3)
+    assert dev.fetch_stats(slot=3)[0] == 0

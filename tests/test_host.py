@@ -437,3 +437,63 @@ def test_sequential_reads_then_batches_on_one_handle(tmp_path, kind):
         finally:
             L.fem_seqfile_close(f)
         assert names == ["q%d" % i for i in range(n)], (kind, second, len(names))
+
+
+def test_packed_fill_equals_the_characters(tmp_path):
+    # fem_seqfile_fill_packed (the parser writing two bits per base straight into the staging that
+    # fem_dev_commit_stage_packed sends): unpacked as the device unpacks it, the batch is the one fem_seqfile_fill gives,
+    # byte for byte — N, lower case, IUPAC, CRLF, every batch size, plain and gzip
+    rng = np.random.default_rng(77)
+    for L, n in ((100, 6000), (101, 3000), (37, 2000), (150, 1500)):
+        odd = [ord(c) for c in "NnacgtRY."]
+        recs = []
+        for i in range(n):
+            seq = bytearray(util.rand_seq(rng, L))
+            if i % 7 == 0:
+                for at in rng.integers(0, L, int(rng.integers(1, 4))):
+                    seq[int(at)] = odd[int(rng.integers(0, len(odd)))]
+            if i == 0:
+                seq[0] = 78
+            if i == n - 1:
+                seq[L - 1] = ord("n")
+            qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8))
+            recs.append(b"@p%d c\n" % i + bytes(seq) + (b"\r\n" if i % 11 == 0 else b"\n") + b"+\n" + qual + b"\n")
+        fq = tmp_path / ("packed_%d.fq" % L)
+        fq.write_bytes(b"".join(recs))
+        whole = host.read_sequences(str(fq))
+        for approx, threads in ((0, 4), (200_000, 3), (1 << 20, 8)):
+            parts = host.read_planned_batches(str(fq), approx, threads=threads, packed=True)
+            assert all(isinstance(p, host.PackedBatch) for p in parts) and sum(p.n for p in parts) == n
+            assert b"".join(p.unpack().tobytes() for p in parts) == whole.bases.tobytes()
+            assert b"".join(p.quals[:p.n * L].tobytes() for p in parts) == whole.quals.tobytes()
+            assert b"".join(p.names_raw[:int(p.name_off[p.n])].tobytes() for p in parts) == whole.names_raw.tobytes()
+            n_odd = sum(int(np.count_nonzero(~np.isin(p.unpack(), [65, 67, 71, 84]))) for p in parts)
+            assert sum(p.n_exc for p in parts) == n_odd > 0
+        if L == 100:
+            gzp = tmp_path / "packed.fq.gz"
+            with gzip.open(str(gzp), "wb", compresslevel=1) as f:
+                f.write(fq.read_bytes())
+            parts = host.read_planned_batches(str(gzp), 1 << 19, threads=4, packed=True)
+            assert b"".join(p.unpack().tobytes() for p in parts) == whole.bases.tobytes()
+    # reads of different lengths, and a batch with too many odd characters, come back as characters
+    mixed = tmp_path / "mixed.fq"
+    mixed.write_bytes(b"@a\nACGTACGT\n+\nIIIIIIII\n@b\nACGTA\n+\nIIIII\n")
+    parts = host.read_planned_batches(str(mixed), 0, packed=True)
+    assert len(parts) == 1 and isinstance(parts[0], host.PlannedBatch) and parts[0].seq(1) == b"ACGTA"
+    noisy = tmp_path / "noisy.fq"
+    noisy.write_bytes(b"".join(b"@n%d\nACGTNNNNNNNNACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n" % i for i in range(50)))
+    parts = host.read_planned_batches(str(noisy), 0, packed=True)
+    assert isinstance(parts[0], host.PlannedBatch) and parts[0].n == 50 and parts[0].seq(49) == b"ACGTNNNNNNNNACGTACGT"
+
+
+def test_packed_generator_equals_the_character_generator():
+    text, off, lens = host.synth_reference(6, [300_000, 40_000], threads=4)
+    for L, n in ((100, 10_000), (150, 5_001), (101, 3_000)):
+        bases, _ = host.synth_reads(11, text, off, lens, n, L, 3, first_read=17, threads=3)
+        bpr = (L + 3) // 4
+        out = np.full(((n * bpr + 7) & ~7) + 8, 0xAA, np.uint8)
+        host.synth_reads_packed(11, text, off, lens, n, L, 3, out, first_read=17, threads=4)
+        c = out[:n * bpr].reshape(n, bpr)
+        q = np.stack([(c >> (2 * j)) & 3 for j in range(4)], axis=2).reshape(n, bpr * 4)
+        assert np.array_equal(util.ACGT[q[:, :L]].reshape(-1), bases[:n * L])
+        assert not q[:, L:].any() and not out[n * bpr:(n * bpr + 7) & ~7].any() and out[-1] == 0xAA
