@@ -7,9 +7,16 @@ N > 1: bench.py starts its N ranks itself (children made before anything touches
 it is already under torch.distributed.run (RANK / WORLD_SIZE in the environment).  One rank per GPU.
 
 One step = one batch of `--batch` (2.5 M) synthetic reads through the DEVICE PIPELINE of libfemhip.so:
-    the caller's batch in ordinary host memory --fem_dev_map_batch_submit: packed to 2 bits per base into pinned
-    staging by the library's host threads, H2D, expanded--> seed/filter kernel(s) + verify kernel --D2H--> fem_batch_result
-with four batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).
+    the batch at two bits per base in the slot's pinned staging (what the FASTQ parser of `FEM map` writes there:
+    fem_seqfile_fill_packed; here the generator) --fem_dev_commit_stage_packed: H2D, expanded--> seed/filter kernel(s) +
+    verify kernel --D2H--> fem_batch_result
+with four batches in flight on four slots and a different batch in every slot (fresh H2D and D2H every step).  No host
+work per base happens inside a step, so N ranks need no host cores to speak of.  The same pipeline fed by
+fem_dev_map_batch_submit (a caller-owned batch of characters, packed by the library's host threads) and by the zero-copy
+character form are measured next to it at N = 1 (`stage_reads_mreads`, `zero_copy_ascii_mreads`).
+After the timed steps the pipeline checks itself (`config.pipeline_check`): every repeat of a slot's batch gave the same
+five counters, and — at N = 1, where the oracle's index exists — one slot's candidates / edit distances / end offsets of
+a 100 k-read prefix, fetched out of the running four-deep pipeline, equal the oracle's.
 `value`, `ms_per_step` and `roofline` all come from the SAME workload, the headline one: C3 (100 bp, e=3, 3 Gbp
 reference: the HBM-resident configuration SURVEY.md 8d calls bandwidth-relevant; 20 steps x 2.5 M = BASELINE's 50 M
 reads).  `value` is the first timed run of exactly K steps; `spread` has min / median / max over that run and
@@ -43,11 +50,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = "r04"   # profiles/<round>_<workload>_hbm_traffic.json: the committed PMC passes `roofline.traffic` comes from
+
+
+def kernel_sources_sha16():
+    """Hash of the device sources: a committed profile only speaks for the build it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "fem_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "fem_amd", "csrc", "*.hip.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (a device copy reaches ~6.3 TB/s)
 N_SLOTS = 4  # batch slots of the library
 # batches in flight: all four slots (a dense index has the device work on two batches at once — the selection of one beside
 # the join of the previous — so three in flight left the host one batch short now and then: 225-250 against 248-258 Mreads/s)
 DEPTH = int(os.environ.get("FEM_BENCH_DEPTH", "4"))
+CHECK_READS = 100_000  # prefix of one slot's batch whose full pipeline result is compared with the oracle's (N = 1)
 PRIME_TO = 12          # untimed batches a workload has seen before its timed steps (warm-up included), at least
 
 WORKLOADS = {
@@ -108,7 +130,7 @@ class Rank:
         self.dist = self.world > 1 or os.environ.get("FEM_BENCH_FORCE_DIST") == "1"
 
 
-def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads, reps=1):
+def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev, threads, reps=1, compare_forms=False):
     """Pipeline measurement + resident-kernel replay of one workload on this rank's device.  `data` = (text, off, lens)."""
     import numpy as np
     from fem_amd import host
@@ -119,13 +141,15 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     # world x N_SLOTS batches of read indices; this rank maps its contiguous range of them (fem_amd/shard.py)
     from fem_amd.shard import reduce_stats, shard_range
     t0 = time.time()
-    batches = []
     lo, hi = shard_range(rk.rank, rk.world, rk.world * N_SLOTS * batch)
     assert hi - lo == N_SLOTS * batch
+    # the slots' pinned staging, lent by the library, filled ONCE with this rank's four batches at two bits per base (the
+    # generator writes the form directly; the FASTQ parser of `FEM map` does the same): a step only commits it again
     for s in range(N_SLOTS):
-        b, o = host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=lo + s * batch, threads=threads)
-        batches.append((b, o))
-    log("rank %d %s: %d x %d reads generated in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
+        hb, _ = dev.acquire_stage(batch, batch * L, slot=s)
+        host.synth_reads_packed(w["seed"], text, off, lens, batch, L, e, hb, first_read=lo + s * batch, threads=threads)
+    log("rank %d %s: %d x %d reads generated (2-bit, into the pinned staging) in %.1fs" % (rk.rank, key, N_SLOTS, batch, time.time() - t0))
+    batches = []  # the same batches as characters in ordinary host memory: made later, for the N = 1 comparison forms
 
     def fence():
         if rk.dist:
@@ -133,15 +157,22 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         torch.cuda.synchronize()
 
     d2h_bytes = [0]
-    form = ["stage_reads"]
-    host_s = [0.0, 0.0]  # seconds this rank's thread spent in the staging call (packing, enqueueing) / waiting in the fetch
+    form = ["packed_commit"]
+    host_s = [0.0, 0.0]  # seconds this rank's thread spent in the staging call (enqueueing; packing in the stage_reads form) / waiting in the fetch
+    seen = [[] for _ in range(N_SLOTS)]  # the five counters of every batch retired, per slot
+    keep = {}                            # slot -> True: keep a copy of that slot's next full result (the self-check)
+    kept = {}
 
     def submit(i):
         s = i % N_SLOTS
         t_in = time.perf_counter()
-        if form[0] == "stage_reads":
-            # fem_dev_map_batch_submit (include/fem_hip.h): the caller's batch is packed to two bits per base into the slot's
-            # pinned staging by the library's host threads, sent, expanded on the device; everything behind it asynchronous
+        if form[0] == "packed_commit":
+            # fem_dev_commit_stage_packed (include/fem_hip.h): the staging holds the batch at two bits per base; sent,
+            # expanded on the device; everything asynchronous, no host work per base
+            dev.commit_stage_packed(batch, L, 0, slot=s)
+        elif form[0] == "stage_reads":
+            # fem_dev_map_batch_submit: the caller's batch of characters is packed to two bits per base into the slot's
+            # pinned staging by the library's host threads, then as above
             dev.stage_reads(batches[s][0], batches[s][1], slot=s)
         elif form[0] == "acquire_commit":
             # zero-copy form: the batch already sits in the slot's pinned staging as characters (a parser wrote it there)
@@ -151,12 +182,19 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         host_s[0] += time.perf_counter() - t_in
 
     def retire(i):
+        sl = i % N_SLOTS
         if form[0] == "resident":
-            return dev.fetch_stats(slot=i % N_SLOTS)  # nothing but the counters comes back
+            st = dev.fetch_stats(slot=sl)  # nothing but the counters comes back
+            seen[sl].append(st.copy())
+            return st
         t_in = time.perf_counter()
-        r = dev.fetch(slot=i % N_SLOTS, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
+        r = dev.fetch(slot=sl, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
         host_s[1] += time.perf_counter() - t_in
         d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
+        seen[sl].append(r.stats.copy())
+        if keep.pop(sl, False):
+            n_chk = min(batch, CHECK_READS)
+            kept[sl] = (r.cand_begin[:2 * n_chk].copy(), r.cand_count[:2 * n_chk].copy(), r.cand.copy(), r.ed.copy(), r.end.copy())
         return r.stats
 
     def pipeline(n):
@@ -205,20 +243,55 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     dev.set_timing(False)
     elapsed, kt = runs[0]
 
-    # the zero-copy form, for comparison (the staging buffers held the packed batches until now)
-    form[0] = "acquire_commit"
-    for s in range(N_SLOTS):
-        hb, ho = dev.acquire_stage(batch, batch * L + 8, slot=s)
-        hb[:batch * L] = batches[s][0][:batch * L]
-        ho[:batch + 1] = batches[s][1]
-    pipeline(N_SLOTS + 2)  # (every slot's buffers exist after this)
-    fence()
-    tz = time.perf_counter()
-    n_z = max(4, min(steps, 10))
-    pipeline(n_z)
-    fence()
-    zero_copy = batch * n_z / (time.perf_counter() - tz) / 1e6
-    h2d_zero_copy = dev.stage_info(0)[0]
+    # ---- the pipeline checks itself (untimed): the same four-deep pipeline once more round the slots, with a copy of slot
+    #      0's full result taken out of it; every repeat of a slot's batch, timed steps included, must have given the same
+    #      five counters ----
+    keep[0] = True
+    pipeline(2 * N_SLOTS)
+    repeats_identical = all(all(np.array_equal(x, sl[0]) for x in sl) for sl in seen if sl)
+    n_repeats = [len(sl) for sl in seen]
+    pipe_check = {"repeats_identical": bool(repeats_identical), "batches_retired_per_slot": n_repeats,
+                  "what": "every retired batch of a slot (priming, warm-up, timed steps, this check) gave the same five counters"}
+    if rk.dist:  # every rank's verdict
+        ok_t = torch.tensor([1 if repeats_identical else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        pipe_check["repeats_identical"] = bool(ok_t.item())
+    pipe_check["_kept"] = kept.get(0)
+    pipe_check["_first_read"] = lo
+    pipe_check["_slot0_stats"] = seen[0][0] if seen[0] else None
+
+    stage_reads_rate = zero_copy = None
+    h2d_zero_copy = 0
+    host_stage_reads = None
+    if compare_forms:
+        # the same pipeline fed by fem_dev_map_batch_submit: caller-owned batches of characters in ordinary host memory, packed
+        # by the library's host threads (round 3's `value`)
+        for s in range(N_SLOTS):
+            batches.append(host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=lo + s * batch, threads=threads))
+        form[0] = "stage_reads"
+        pipeline(N_SLOTS + 2)
+        fence()
+        host_s[0] = host_s[1] = 0.0
+        tz = time.perf_counter()
+        n_z = max(4, min(steps, 10))
+        pipeline(n_z)
+        fence()
+        stage_reads_rate = batch * n_z / (time.perf_counter() - tz) / 1e6
+        host_stage_reads = (host_s[0] * 1e3 / n_z, host_s[1] * 1e3 / n_z)
+        # the zero-copy character form (the staging buffers held the packed batches until now)
+        form[0] = "acquire_commit"
+        for s in range(N_SLOTS):
+            hb, ho = dev.acquire_stage(batch, batch * L + 8, slot=s)
+            hb[:batch * L] = batches[s][0][:batch * L]
+            ho[:batch + 1] = batches[s][1]
+        pipeline(N_SLOTS + 2)  # (every slot's buffers exist after this)
+        fence()
+        tz = time.perf_counter()
+        pipeline(n_z)
+        fence()
+        zero_copy = batch * n_z / (time.perf_counter() - tz) / 1e6
+        h2d_zero_copy = dev.stage_info(0)[0]
+        batches.clear()
 
     # the kernels alone on batches already resident in HBM (every slot as staged by the pipeline steps above), the four
     # slots in rotation: as in the pipeline, a batch's seed selection runs beside the previous batch's join
@@ -239,6 +312,10 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     torch.cuda.synchronize()
     alone = {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}
     dev.set_timing(False)
+    # (the comparison forms and the resident replay mapped the same four batches again: their counters count too)
+    local_ok = all(all(np.array_equal(x, sl[0]) for x in sl) for sl in seen if sl)
+    pipe_check["repeats_identical"] = bool(pipe_check["repeats_identical"] and local_ok)
+    pipe_check["batches_retired_per_slot"] = [len(sl) for sl in seen]
 
     seed_name = dev.seed_kernel(e=e, a=a, k=k, step=step)
 
@@ -275,6 +352,13 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
                    "mean launch duration inside the timed pipeline (HIP events on the kernel's stream)")
     roof["bytes_are"] = ("8 P: the occurrence entries of the selected seeds (SURVEY.md 8d's third term)" if split and dominant == "seed_join_kernel"
                          else "SURVEY.md 8d's terms for this kernel")
+    if split and dominant == "seed_join_kernel":
+        # what this implementation needs to move for the same work: 4-byte entries of the 32-bit occurrence table + the
+        # selection's hand-over (8 bytes per selected seed, 6 R per read) — NOT what `achieved` / `frac` are computed from
+        R = e + 1 + a
+        impl = 4 * P + 8 * 6 * R * N + 8 * N
+        roof["implementation_bytes_per_launch"] = int(impl / max(dom_launches, 1.0))
+        roof["implementation_gbs"] = round(impl / max(dom_launches, 1.0) / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0
     by_kernel = {dominant: roof}
     for n_ in per_launch:
         if n_ in bytes_of and n_ != dominant and n_ in alone_ms and n_ != "seed_filter_kernel":
@@ -289,16 +373,22 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     # HBM-side bytes of the dominant kernel: NOT measured in this run.  They come from the committed rocprofv3 --pmc passes
     # of this same command (profiles/r03_<wl>_hbm_traffic.json: FETCH_SIZE + WRITE_SIZE, corrected by the calibration of
     # profiles/r03_fetch_calibration.json for this kernel's access pattern), scaled to this batch size.
-    tpath = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % key)
+    tname = "%s_%s_hbm_traffic.json" % (PROFILE_ROUND, key)
+    tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath):
         try:
             prof = json.load(open(tpath))
-            for kname, ctr in prof["kernels"].items():
-                if dominant in kname and "hbm_bytes_per_launch" in ctr:
-                    roof["traffic"] = int(ctr["hbm_bytes_per_launch"] * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
-                    roof["traffic_source"] = ("committed profile profiles/r03_%s_hbm_traffic.json (FETCH_SIZE x %.2f + WRITE_SIZE: "
-                                              "calibrated on this kernel's access pattern), rescaled (not measured in this run)"
-                                              % (key, ctr.get("fetch_factor", 1.0)))
+            if prof.get("kernel_sources_sha16") != kernel_sources_sha16():
+                # the kernels changed since the PMC passes were taken: their bytes say nothing about this build
+                roof["traffic_source"] = ("profiles/%s was collected on other kernel sources (%s, now %s): run profiles/make_profiles.py"
+                                          % (tname, prof.get("kernel_sources_sha16"), kernel_sources_sha16()))
+            else:
+                for kname, ctr in prof["kernels"].items():
+                    if dominant in kname and "hbm_bytes_per_launch" in ctr:
+                        roof["traffic"] = int(ctr["hbm_bytes_per_launch"] * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
+                        roof["traffic_source"] = ("committed profile profiles/%s of these kernel sources (FETCH_SIZE x %.2f + WRITE_SIZE: "
+                                                  "calibrated on this kernel's access pattern), rescaled (not measured in this run)"
+                                                  % (tname, ctr.get("fetch_factor", 1.0)))
         except Exception as ex:  # a malformed profile file must not break the measurement
             log("could not read %s: %s" % (tpath, ex))
     values = [rk.world * batch * steps / r[0] / 1e6 for r in runs]
@@ -310,14 +400,19 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
         "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_bytes[0],
-        "zero_copy_ascii_mreads": round(zero_copy, 3), "zero_copy_h2d_bytes_per_step": int(h2d_zero_copy),
-        "priming_steps": priming,
+        "stage_reads_mreads": None if stage_reads_rate is None else round(stage_reads_rate, 3),
+        "zero_copy_ascii_mreads": None if zero_copy is None else round(zero_copy, 3), "zero_copy_h2d_bytes_per_step": int(h2d_zero_copy),
+        "priming_steps": priming, "pipeline_check": pipe_check,
+        "distinct_reads": "%d distinct reads per GPU (%d slots x %d), each slot's batch mapped again every %d steps"
+                          % (N_SLOTS * batch, N_SLOTS, batch, N_SLOTS),
         # what this rank's host thread does per step: the staging call (2-bit packing of the batch on the library's threads,
         # enqueueing the copies and kernels) and the wait inside the fetch (device not done yet, or results on their way);
         # packing reads batch x L bytes of host memory and writes a quarter of that
         "host_ms_per_step": {"stage_call": round(host_first[0], 3), "fetch_wait": round(host_first[1], 3),
-                             "stage_threads": int(os.environ.get("FEM_STAGE_THREADS", "12")),
-                             "host_read_gb_per_s_while_packing": round(batch * L / max(host_first[0], 1e-6) / 1e6, 1)},
+                             "form": "fem_dev_commit_stage_packed + fem_dev_map_staged: enqueues only, no host work per base",
+                             "stage_reads_form": None if host_stage_reads is None else
+                             {"stage_call": round(host_stage_reads[0], 3), "fetch_wait": round(host_stage_reads[1], 3),
+                              "stage_threads": int(os.environ.get("FEM_STAGE_THREADS", "12"))}},
         "counters": {"reads": int(job[0]), "mapped_reads": int(job[1]), "pre_filter": int(job[2]),
                      "candidates": int(job[3]), "mappings": int(job[4])},
         "counters_last_step_per_gpu": [int(x) for x in last_stats],
@@ -371,7 +466,29 @@ def profile_replay(key, dev, data, n, batch, torch, threads):
             "event_times": times}
 
 
-def cpu_baseline(w, data, n_sample, dev, threads, label="C2"):
+def check_prefix_against_oracle(fo, ref, idx, w, data, pipe_check, threads):
+    """One slot's result out of the running pipeline (run_workload kept a copy) against the oracle on a prefix of that
+    slot's batch: candidates, edit distances, end offsets per (read, strand), array for array."""
+    import numpy as np
+    from fem_amd import host
+    kept = pipe_check.get("_kept")
+    if kept is None:
+        return None
+    text, off, lens = data
+    cand_begin, cand_count, cand, ed, end = kept
+    n_chk = len(cand_begin) // 2
+    bases, offsets = host.synth_reads(w["seed"], text, off, lens, n_chk, w["L"], w["e"], first_read=pipe_check["_first_read"], threads=threads)
+    want = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offsets), e=w["e"], a=1, threads=threads, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
+    cnt = cand_count.astype(np.int64)
+    o = np.zeros(len(cnt) + 1, np.uint64)
+    o[1:] = np.cumsum(cnt)
+    sel = np.arange(int(o[-1]), dtype=np.int64) + np.repeat(cand_begin.astype(np.int64) - o[:-1].astype(np.int64), cnt)
+    ok = (np.array_equal(o, want.cand_off) and np.array_equal(cand[sel], want.cands) and np.array_equal(ed[sel], want.v_ed)
+          and np.array_equal(end[sel][ed[sel] != 0xFF], want.v_end[want.v_ed != 0xFF]))
+    return {"reads": n_chk, "candidates": int(o[-1]), "mappings": int(np.count_nonzero(ed[sel] != 0xFF)), "equal_to_oracle": bool(ok)}
+
+
+def cpu_baseline(w, data, n_sample, dev, threads, label="C2", pipe_check=None):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of the
     same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
     import numpy as np
@@ -392,6 +509,8 @@ def cpu_baseline(w, data, n_sample, dev, threads, label="C2"):
     fo.lib().fo_result_stats(h, st.ctypes.data)
     fo.free_result(h)
     got = dev.map_batch(bases, offsets, e=e, a=1, slot=1).stats  # the same sample through the device path
+    if pipe_check is not None:
+        pipe_check["prefix_vs_oracle"] = check_prefix_against_oracle(fo, ref, idx, w, data, pipe_check, threads)
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "port",
             "sample": "%d reads of the %s workload, seeding+filter+verification, %d threads (every core this process may use)" % (n_sample, label, threads),
             "seconds": round(dt, 3), "index_build_seconds": round(t_index, 2),
@@ -471,6 +590,7 @@ def main():
                                                                      "already in HBM, slots in rotation, no copies in flight), this many steps; "
                                                                      "prints the HIP-event means of exactly those launches")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-compare", action="store_true", help="skip the stage_reads / zero-copy comparison forms (N = 1 runs them by default)")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.batch < 1:
@@ -533,7 +653,8 @@ def main():
         w3 = WORKLOADS["c3"]
         ref_key3 = (3, tuple(w3["seq_lens"]))
         if cpu_c3[0] is None and not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0 and ref_key3 in data_cache:
-            cpu_c3[0] = cpu_baseline(w3, data_cache[ref_key3][:3], args.cpu_sample_c3, dev, threads, label="C3")
+            cpu_c3[0] = cpu_baseline(w3, data_cache[ref_key3][:3], args.cpu_sample_c3, dev, threads, label="C3",
+                                     pipe_check=results["c3"]["pipeline_check"])
             cpu_c3[0].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota,
                              device_pipeline_over_cpu=round(results["c3"]["value"] / max(cpu_c3[0]["value"], 1e-9), 1))
 
@@ -562,7 +683,7 @@ def main():
             dev.close()
             return
         res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads,
-                           reps=args.reps if key == args.workload else 1)
+                           reps=args.reps if key == args.workload else 1, compare_forms=rk.world == 1 and not args.no_compare)
         res["index_entries"] = n_occ
         results[key] = res
         log("rank %d %s: pipeline %.1f Mreads/s, kernels only %.1f, %s" % (rk.rank, key, res["value"], res["kernel_only_mreads"], res["kernel_ms_per_launch"]))
@@ -575,7 +696,6 @@ def main():
         return
 
     head = results[args.workload]
-    stage_threads = int(os.environ.get("FEM_STAGE_THREADS", "12"))
     out = {
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
         "value": head["value"], "unit": "Mreads/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
@@ -583,9 +703,9 @@ def main():
         "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic", "spread": head["spread"],
         "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline", "roofline_step",
                                                                          "roofline_by_kernel", "spread")},
-                       value_is="device pipeline: caller-owned batch in host memory -> fem_dev_map_batch_submit (2-bit packing into pinned "
-                                "staging on %d host threads, H2D, expansion) -> kernels -> D2H of fem_batch_result, %d batches in "
-                                "flight, a different batch per slot" % (stage_threads, DEPTH),
+                       value_is="device pipeline: the batch at two bits per base in the slot's pinned staging (as the FASTQ parser of FEM map "
+                                "writes it) -> fem_dev_commit_stage_packed (H2D, expansion) -> kernels -> D2H of fem_batch_result, %d batches "
+                                "in flight, a different batch per slot, fresh H2D and D2H every step; no host work per base" % DEPTH,
                        parallelism="reads sharded x%d, index replicated" % rk.world, bandwidths=bw),
         "roofline": dict(head["roofline"], workload=args.workload),
         "roofline_step": dict(head["roofline_step"], workload=args.workload),
@@ -594,7 +714,8 @@ def main():
         "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
                                                            "reads_per_step_per_gpu", "kernel_ms_per_launch", "kernel_ms_alone", "counters_last_step_per_gpu",
                                                            "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step",
-                                                           "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps", "host_ms_per_step", "spread")}
+                                                           "stage_reads_mreads", "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps",
+                                                           "host_ms_per_step", "spread", "pipeline_check")}
                                  for k_, v_ in results.items()},
     }
     if cpu_c3[0] is not None:
@@ -613,7 +734,8 @@ def main():
             c2_data = t2
     if not args.no_cpu and rk.world == 1:
         key_cb = "cpu_baseline_c2" if "cpu_baseline" in out else "cpu_baseline"
-        out[key_cb] = cpu_baseline(WORKLOADS["c2"], c2_data, args.cpu_sample, dev, threads)
+        out[key_cb] = cpu_baseline(WORKLOADS["c2"], c2_data, args.cpu_sample, dev, threads,
+                                   pipe_check=results["c2"]["pipeline_check"] if "c2" in results else None)
         out[key_cb].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota)
     dev.close()
     if not args.no_e2e and rk.world == 1 and args.e2e_reads > 0:
@@ -621,6 +743,11 @@ def main():
             out["e2e_cli"] = e2e_cli(WORKLOADS["c2"], c2_data, args.e2e_reads, threads)
         except Exception as ex:
             out["e2e_cli"] = {"error": repr(ex)}
+    for v_ in results.values():
+        for k_ in [k_ for k_ in v_["pipeline_check"] if k_.startswith("_")]:
+            del v_["pipeline_check"][k_]
+    pc = head["pipeline_check"]
+    out["counters_match_pipeline"] = bool(pc["repeats_identical"] and (pc.get("prefix_vs_oracle") or {"equal_to_oracle": True})["equal_to_oracle"])
     out["config"]["counter_reduction"] = ("torch.distributed all_reduce, backend %s, %d rank(s)" % (backend, rk.world)) if rk.dist else "single process: none"
     print(json.dumps(out), flush=True)
     if rk.dist:

@@ -40,7 +40,13 @@ def test_single_gpu_line_has_the_contract_fields():
     c = d["config"]
     # the timed steps + the W warm-up steps + the disclosed priming steps are all the batches the workload saw before / in them
     assert c["priming_steps"] == 12 - 2 and c["h2d_packed"] is True and c["h2d_bytes_per_step"] == 200000 * 25
-    assert c["zero_copy_ascii_mreads"] > 0 and c["zero_copy_h2d_bytes_per_step"] == 200000 * 100
+    assert c["zero_copy_ascii_mreads"] > 0 and c["zero_copy_h2d_bytes_per_step"] == 200000 * 100 and c["stage_reads_mreads"] > 0
+    # the pipeline checked itself: every repeat of a slot's batch gave the same counters, and slot 0's result, taken out of the
+    # running four-deep pipeline, equals the oracle's on its prefix
+    pc = c["pipeline_check"]
+    assert d["counters_match_pipeline"] is True and pc["repeats_identical"] is True and min(pc["batches_retired_per_slot"]) >= 5
+    assert pc["prefix_vs_oracle"]["equal_to_oracle"] is True and pc["prefix_vs_oracle"]["reads"] == 100000 and pc["prefix_vs_oracle"]["mappings"] > 50000
+    assert c["host_ms_per_step"]["stage_call"] < 1.0
 
 
 def test_two_ranks_start_by_themselves_and_reduce_their_counters():
@@ -48,6 +54,7 @@ def test_two_ranks_start_by_themselves_and_reduce_their_counters():
     two = _run(["--workload", "c2", "--reps", "1", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "100000", "--extra", "none", "--no-cpu", "--no-e2e"],
                env={"FEM_BENCH_ONE_GPU": "1", "FEM_BENCH_BACKEND": "gloo"})
     assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["counters_match_pipeline"] is True and one["counters_match_pipeline"] is True
     assert two["config"]["counters"]["reads"] == 2 * one["config"]["counters"]["reads"]
     # rank 0 maps the same read indices as the single-rank run; rank 1 different reads of the same distribution
     assert two["config"]["counters_last_step_per_gpu"] == one["config"]["counters_last_step_per_gpu"]
@@ -73,5 +80,7 @@ def test_headline_workload_is_c3_with_two_seed_kernels():
     assert set(d["roofline_by_kernel"]) >= {"seed_join_kernel", "seed_select_kernel"}
     assert d["roofline"]["avg_launch_ms"] <= d["ms_per_step"]
     c = d["config"]["counters_last_step_per_gpu"]
+    assert d["counters_match_pipeline"] is True
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * c[2]
+    assert d["roofline"]["implementation_bytes_per_launch"] == 4 * c[2] + (8 * 6 * 5 + 8) * 100000
     assert c[1] > 0.97 * c[0]  # 98.4 % of the reads map on the 3 Gbp reference
