@@ -30,6 +30,16 @@ namespace femk {
 #ifndef FEM_JOIN_SLOTS_HI
 #define FEM_JOIN_SLOTS_HI 32768u
 #endif
+// Round-4 instruction diet, bit by bit (all on in the product; FEM_JOIN_OPT builds the ablations of DESIGN.md 4.2):
+//   1  exact filter as ONE all-pairs compare (8 x 8 or 16 x 16 lanes) instead of a readlane loop per flagged value, and the
+//      second probe only beyond 16 flagged values
+//   2  lanes behind a list's end hold a sentinel of their OWN (no two in one slot), so insert / window / flag test nothing:
+//      validity is one scalar AND of masks the loads' compares left behind
+//   4  a second chunk only for the runs that have one (was: for every run of a unit in which some list is long)
+//   8  marks under `if (hit)` alone (the ballot around it cost three scalar instructions per chunk)
+#ifndef FEM_JOIN_OPT
+#define FEM_JOIN_OPT 15
+#endif
 constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
 // Chunks whose LDS steps are issued together at R >= 7 (see join_read): one — with the 80 registers of six waves per SIMD
 // five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134)
