@@ -37,8 +37,13 @@ namespace femk {
 //      validity is one scalar AND of masks the loads' compares left behind
 //   4  a second chunk only for the runs that have one (was: for every run of a unit in which some list is long)
 //   8  marks under `if (hit)` alone (the ballot around it cost three scalar instructions per chunk)
+// At R >= 7 the kernel lives in the 80 registers of six waves per SIMD: 1 and 2 (their lane constants and masks) spill there
+// and cost more than they save (C5, ms per 2.5 M reads: none 14.85, 1: 15.2, 1+2: 15.7, all four 16.1, 1+4+8: 14.8).
 #ifndef FEM_JOIN_OPT
 #define FEM_JOIN_OPT 15
+#endif
+#ifndef FEM_JOIN_OPT_HI
+#define FEM_JOIN_OPT_HI 12
 #endif
 constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
 // Chunks whose LDS steps are issued together at R >= 7 (see join_read): one — with the 80 registers of six waves per SIMD
@@ -73,8 +78,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   constexpr uint32_t kWords = kSlots / 32u;          // the guard word sits at bitmap[kWords]
   constexpr uint32_t kPeriodBits = kSlotBits + 3u;   // values this many bits apart share a slot
   constexpr uint32_t kFlagCap = dense_flag_cap(R);   // flagged values one unit may have (one or two per lane)
+  constexpr int kOpt = R <= 6 ? FEM_JOIN_OPT : FEM_JOIN_OPT_HI;
+  constexpr bool kOptPairs = (kOpt & 1) != 0, kOptSent = (kOpt & 2) != 0, kOptLong = (kOpt & 4) != 0, kOptHit = (kOpt & 8) != 0;
   constexpr bool kSecondProbe = true;  // weed the chance flags out before the exact filter ...
-  constexpr uint32_t kProbeMin = 8u;   // ... when there are more flagged values than this
+  constexpr uint32_t kProbeMin = kOptPairs ? 16u : 8u;  // ... when there are more flagged values than this (what the all-pairs filter takes)
   constexpr uint32_t kFlgStride = kFlagCap + 1u;     // the entry behind a group's array takes the overflow writes
   constexpr uint32_t kUnits = 2u * (uint32_t)kStep;
   const uint32_t e = (uint32_t)p.e;
@@ -91,6 +98,18 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   const uint64_t s_addr = (uint64_t)(uintptr_t)(occ32 + s_lo);
   const uint32_t s_alo = (uint32_t)s_addr, s_ahi = (uint32_t)(s_addr >> 32);
   const uint32_t lane4 = ln * 4u;
+  // Sentinels of a lane's own (kOptSent).  Slots repeat every 2^kPeriodBits positions; within one unit no two lanes
+  // without an entry may land in one slot (a "second value of a slot" costs its marks): a lane behind a list's end holds
+  // sent_a - start (lanes 2304 apart — starts are below 1024 and, within a unit, at least 12 apart; 2304 = 9 words of the
+  // bitmap: consecutive lanes in different LDS banks, where 2048 put all of them into four), a dropped entry of the last
+  // run sent_b (256 apart = one word, beyond the first family's range of 64 x 2304).  All of them are >= kDenseVLimit and
+  // more than e from each other.
+  const uint32_t sent_a = 0xF0000000u + ln * 2304u, sent_b = 0xF0000000u + 149504u + (ln << 8);
+  static_assert(64u * 2304u + 2048u == 149504u && 149504u + 64u * 256u + 2048u < (1u << kPeriodBits), "sentinel families inside one period");
+  // all-pairs filter: which of four ballots holds lane i's row (i >> 2), and where in it (16 (i & 3))
+  const uint64_t q_is1 = __builtin_amdgcn_ballot_w64((ln >> 2) == 1u), q_is2 = __builtin_amdgcn_ballot_w64((ln >> 2) == 2u),
+                 q_is3 = __builtin_amdgcn_ballot_w64((ln >> 2) == 3u);
+  const uint32_t sh16 = 16u * (ln & 3u);
   uint32_t nxt[R], nxt_sf[R];  // first chunk of every run of the next unit (raw table entries), its packed scalars
   typedef const __attribute__((address_space(1))) uint8_t *GlobalBytes;  // (an address rebuilt from integers is "flat" to the compiler otherwise)
   auto run_base_of = [&](uint32_t alo, uint32_t ahi, uint32_t lane) -> GlobalBytes {
@@ -100,11 +119,16 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   };
   auto run_base = [&](uint32_t lane) -> GlobalBytes { return run_base_of(s_alo, s_ahi, lane); };
   auto prefetch_of = [&](uint32_t sf, uint32_t alo, uint32_t ahi, uint32_t u) {
+    GlobalBytes base[R];  // (all the readlanes first: a load may use a readlane's scalar only four wait states later)
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       nxt_sf[t] = (uint32_t)__builtin_amdgcn_readlane((int)sf, (int)(u * R + t));
+      base[t] = run_base_of(alo, ahi, u * R + t);
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
       const uint32_t last4 = nxt_sf[t] >> 24;
-      nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base_of(alo, ahi, u * R + t) + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
+      nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(base[t] + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
     }
   };
   auto prefetch = [&](uint32_t u) { prefetch_of(s_sf, s_alo, s_ahi, u); };
@@ -117,16 +141,26 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     const uint32_t widx = valid ? __builtin_amdgcn_ubfe(v, 8u, kWordBits) : ln;
     return lds_or_rtn(bitmap + widx, bit) & bit;
   };
+  // word of the bitmap that holds slot q >> 5 ... as v_bfe + v_lshl_add: left alone the compiler makes shift, and, add of it
+  auto word_of = [&](uint32_t x, uint32_t from) -> uint32_t * {
+    uint32_t idx = __builtin_amdgcn_ubfe(x, from, kWordBits);
+    asm("" : "+v"(idx));
+    return bitmap + idx;
+  };
+  auto insert_plain = [&](uint32_t v) -> uint32_t {  // the same where every lane holds a value or a sentinel of its own
+    const uint32_t bit = 1u << ((v >> 3) & 31u);
+    return lds_or_rtn(word_of(v, 8u), bit) & bit;
+  };
   auto mark = [&](uint32_t v, uint32_t hit) {  // second value of a slot: both neighbours "present"
     if (hit) {
       const uint32_t qm = (v >> 3) - 1u, qp = (v >> 3) + 1u;
-      lds_or(bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits), 1u << (qm & 31u));
-      lds_or(bitmap + __builtin_amdgcn_ubfe(qp, 5u, kWordBits), 1u << (qp & 31u));
+      lds_or(word_of(qm, 5u), 1u << (qm & 31u));
+      lds_or(word_of(qp, 5u), 1u << (qp & 31u));
     }
   };
   auto window = [&](uint32_t v) -> uint32_t {  // bit 0: slot - 1 present, bit 1: own slot, bit 2: slot + 1
     const uint32_t qm = (v >> 3) - 1u;
-    const uint32_t *w = bitmap + __builtin_amdgcn_ubfe(qm, 5u, kWordBits);
+    const uint32_t *w = word_of(qm, 5u);
     return __builtin_amdgcn_alignbit(w[1], w[0], qm & 31u);
   };
   prefetch(0);
@@ -158,6 +192,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     const bool skip = n_g <= (uint32_t)p.a || (n_g == f[R - 1] && !keep_all);
     uint32_t n_flag = 0;
     uint32_t *flg_g = flg + g * kFlgStride;
+    if (kOptPairs) {  // behind the unit's flagged values the array reads "no value": the all-pairs filter compares whole rows
+      flg_g[ln] = 0xFFFFFFFFu;
+      if (kFlagCap > (uint32_t)kWave) flg_g[ln + (uint32_t)kWave] = 0xFFFFFFFFu;
+    }
     if (!skip) {
       const bool long_lists = f_max > (uint32_t)kWave;  // some list has a second chunk (entries 64..127)
       uint32_t hv[R];
@@ -166,6 +204,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       if (long_lists) {
 #pragma unroll
         for (int t = 0; t < R; ++t) {
+          if (kOptLong && f[t] <= (uint32_t)kWave) continue;  // (wave-uniform: only the runs that have a second chunk)
           const uint32_t last4 = f[t] > (uint32_t)kWave ? (f[t] - 1u) * 4u : 0u;
           const uint32_t at4 = lane4 + 4u * (uint32_t)kWave;
           hv[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
@@ -178,12 +217,15 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         for (int t = 1; t < R; ++t) raw_max = val[t] > raw_max ? val[t] : raw_max;
         if (long_lists) {
 #pragma unroll
-          for (int t = 0; t < R; ++t) raw_max = hv[t] > raw_max ? hv[t] : raw_max;
+          for (int t = 0; t < R; ++t) raw_max = hv[t] > raw_max ? hv[t] : raw_max;  // (kDenseSent < kDenseRemap: a run without a second chunk says nothing)
         }
         remap = __builtin_amdgcn_ballot_w64(raw_max >= kDenseRemap) != 0;
       }
       uint32_t max_u = 0;
       bool any_u = true;
+      uint64_t vm[R];  // lanes that hold an entry of run t's first chunk (kOptSent): scalar arithmetic on the run's length
+#pragma unroll
+      for (int t = 0; t < R; ++t) vm[t] = 0;
       if (__builtin_expect(remap, 0)) {
         // rare: entries within kDenseNear of a sequence start are resolved exactly (pos >= start or dropped); the maximum
         // of U then comes from a wave reduction (a dropped entry may sit at the end of a run)
@@ -214,15 +256,31 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
             if (a_ < kDenseVLimit) mx = a_ > mx ? a_ : mx, have_u = 1;
             if (b_ < kDenseVLimit) mx = b_ > mx ? b_ : mx, have_u = 1;
           }
+          if (kOptSent) a_ = a_ < kDenseVLimit ? a_ : sent_b;  // (a sentinel of the lane's own: no two dropped entries in one slot)
 #pragma unroll
           for (int q = 0; q < R; ++q) val[q] = q == t ? a_ : val[q], hv[q] = q == t ? b_ : hv[q];
         }
         any_u = __builtin_amdgcn_ballot_w64(have_u != 0) != 0;
         max_u = wave_max_u32(mx);
+        if (kOptSent) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) vm[t] = __builtin_amdgcn_ballot_w64(val[t] < kDenseVLimit);
+        }
       } else {
         // every entry is real and lists ascend: the maximum of U is the largest last entry of runs 0..R-2
+        if (kOptSent) {
+          // a lane behind the list's end takes a sentinel of its own (sent_a - start: no two in one slot, fem_seed_join.hip.h
+          // top) instead of the list's last entry again; which lanes hold entries stays behind as a scalar mask
 #pragma unroll
-        for (int t = 0; t < R; ++t) val[t] = ln < f[t] ? val[t] - st[t] : kDenseSent;
+          for (int t = 0; t < R; ++t) {
+            const bool in = ln < f[t];
+            vm[t] = __builtin_amdgcn_ballot_w64(in);  // (the compare's own result: no instruction)
+            val[t] = (in ? val[t] : sent_a) - st[t];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < R; ++t) val[t] = ln < f[t] ? val[t] - st[t] : kDenseSent;
+        }
         if (long_lists) {
 #pragma unroll
           for (int t = 0; t < R; ++t) hv[t] = ln + (uint32_t)kWave < f[t] ? hv[t] - st[t] : kDenseSent;
@@ -243,8 +301,14 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       }
       if (keep_all) any_u = true, max_u = 0xFFFFFFFFu;
       if (any_u) {
-        // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes the sentinel
-        val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
+        // the last run keeps values <= max(U) only (src/filter.c:85); everything dropped becomes a sentinel
+        if (kOptSent) {
+          const bool keep = val[R - 1] <= max_u;
+          vm[R - 1] &= __builtin_amdgcn_ballot_w64(keep);
+          val[R - 1] = keep ? val[R - 1] : sent_b;
+        } else {
+          val[R - 1] = val[R - 1] <= max_u ? val[R - 1] : kDenseSent;
+        }
         if (long_lists) hv[R - 1] = hv[R - 1] <= max_u ? hv[R - 1] : kDenseSent;
         // ---- insert, then flag (a neighbouring slot is present: the flagged values are compacted into the group's array).
         //      In batches of kBatch chunks: all of a batch's atomics back to back, its marks, later all of a batch's window
@@ -253,46 +317,67 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         //      instruction issue, not by the LDS round trips) (hit bits, window words) decides whether the kernel fits the 80 registers of six waves per SIMD,
         //      i.e. whether five of its blocks or four sit on a CU beside seed_select_kernel ----
         constexpr int kBatch = R <= 6 ? R : FEM_JOIN_BATCH_HI;
-        auto flag_chunk = [&](uint32_t v, uint32_t xw) {
-          const bool near = (xw & 5u) != 0u && v < kDenseVLimit;
-          const uint64_t m = __builtin_amdgcn_ballot_w64(near);
+        // `exact`: the lanes without an entry are tested one by one (v < kDenseVLimit).  Otherwise `valid` says which lanes count
+        // and a flagged lane WITHOUT an entry — always above the run's lanes with one: lists ascend, both ends of a run are
+        // cut from the top — stores its sentinel at the place the next flagged value will take, or behind the last one,
+        // where the exact filter reads it as "no value" (it lies above every coordinate).
+        auto flag_chunk = [&](uint32_t v, uint32_t xw, uint64_t valid, bool exact) {
+          bool near = (xw & 5u) != 0u;
+          if (exact) near = near && v < kDenseVLimit;
+          const uint64_t m = exact ? __builtin_amdgcn_ballot_w64(near) : __builtin_amdgcn_ballot_w64(near) & valid;
+          if (!exact && m == 0) return;  // (wave-uniform)
           uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_flag));
           pos = pos < kFlagCap ? pos : kFlagCap;
           if (near) flg_g[pos] = v;
           n_flag += (uint32_t)__popcll(m);
         };
-        auto insert_all = [&](uint32_t (&vals)[R]) {
+        auto insert_all = [&](uint32_t (&vals)[R], bool checked, bool second) {
 #pragma unroll
           for (int t0 = 0; t0 < R; t0 += kBatch) {
             uint32_t hit[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; ++q)
-              if (t0 + q < R) hit[q] = insert(vals[t0 + q]);
+              if (t0 + q < R) {
+                hit[q] = 0;
+                if (second && kOptLong && f[t0 + q] <= (uint32_t)kWave) continue;
+                hit[q] = checked ? insert(vals[t0 + q]) : insert_plain(vals[t0 + q]);
+              }
             // a slot that took a second value (every true hit does): chunk by chunk, only where some lane saw one
 #pragma unroll
             for (int q = 0; q < kBatch; ++q)
               if (t0 + q < R) {
-                if (__builtin_amdgcn_ballot_w64(hit[q] != 0u)) mark(vals[t0 + q], hit[q]);
+                if (second && kOptLong && f[t0 + q] <= (uint32_t)kWave) continue;
+                if (kOptHit) {
+                  mark(vals[t0 + q], hit[q]);
+                } else if (__builtin_amdgcn_ballot_w64(hit[q] != 0u)) {
+                  mark(vals[t0 + q], hit[q]);
+                }
               }
           }
         };
-        auto flag_all = [&](uint32_t (&vals)[R]) {
+        auto flag_all = [&](uint32_t (&vals)[R], bool second, bool exact) {
 #pragma unroll
           for (int t0 = 0; t0 < R; t0 += kBatch) {
             uint32_t x[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; ++q)
-              if (t0 + q < R) x[q] = window(vals[t0 + q]);
+              if (t0 + q < R) {
+                if (second && kOptLong && f[t0 + q] <= (uint32_t)kWave) continue;
+                x[q] = window(vals[t0 + q]);
+              }
 #pragma unroll
             for (int q = 0; q < kBatch; ++q)
-              if (t0 + q < R) flag_chunk(vals[t0 + q], x[q]);
+              if (t0 + q < R) {
+                if (second && kOptLong && f[t0 + q] <= (uint32_t)kWave) continue;
+                flag_chunk(vals[t0 + q], x[q], vm[t0 + q], exact);
+              }
           }
         };
-        insert_all(val);
-        if (long_lists) insert_all(hv);
+        insert_all(val, !kOptSent, false);
+        if (long_lists) insert_all(hv, true, true);
         wave_sync_lds();
-        flag_all(val);
-        if (long_lists) flag_all(hv);
+        if (!kOptSent || __builtin_expect(remap, 0)) flag_all(val, false, true); else flag_all(val, false, false);
+        if (long_lists) flag_all(hv, true, true);  // (second chunks keep the compare against the sentinel: they are the exception)
         wave_sync_lds();
         {  // leave the bitmap clean: every lane clears its 16-byte pieces (the guard word sits behind them)
           uint4 *b4 = (uint4 *)bitmap;
@@ -342,33 +427,60 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       if (keep1) flg_g[__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c0))] = v1;
       n_flag = c0 + (uint32_t)__popcll(m1);
       wave_sync_lds();
+      if (kOptPairs) {  // what was dropped must read "no value" again
+        if (ln >= n_flag) flg_g[ln] = 0xFFFFFFFFu;
+        if (kFlagCap > (uint32_t)kWave && ln + (uint32_t)kWave >= n_flag) flg_g[ln + (uint32_t)kWave] = 0xFFFFFFFFu;
+        wave_sync_lds();
+      }
     }
     if (n_flag > (uint32_t)p.a) {
       // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
       const bool have = ln < n_flag;
-      const uint32_t fv = have ? flg_g[ln] : 0u;
-      const uint32_t n_lo = n_flag < (uint32_t)kWave ? n_flag : (uint32_t)kWave;
+      uint32_t fv;
       uint32_t cnt = 0;
       bool pass_hi = false;
       uint32_t fv_hi = 0;
-      if (kFlagCap > (uint32_t)kWave && n_flag > (uint32_t)kWave) {
-        // more than one flagged value per lane (long lists): the second goes through the same counts
-        const bool have_hi = ln + (uint32_t)kWave < n_flag;
-        fv_hi = have_hi ? flg_g[ln + (uint32_t)kWave] : 0u;
-        uint32_t cnt_hi = 0;
-        for (uint32_t j = 0; j < n_lo; ++j) {
-          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
-          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
-        }
-        for (uint32_t j = (uint32_t)kWave; j < n_flag; ++j) {
-          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv_hi, (int)(j - (uint32_t)kWave));
-          cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
-        }
-        pass_hi = have_hi && cnt_hi > (uint32_t)p.a;
+      if (kOptPairs && n_flag <= 8u) {
+        // all pairs at once: lane 8 i + j compares value j with value i; row i of the ballot is byte i, which lane i counts
+        const uint32_t xj = flg_g[ln & 7u], fi = flg_g[ln >> 3];
+        const uint64_t m = __builtin_amdgcn_ballot_w64(xj - fi <= e);
+        cnt = (uint32_t)__popc((uint32_t)(m >> (8u * (ln & 7u))) & 0xFFu);
+        fv = have ? xj : 0u;
+      } else if (kOptPairs && n_flag <= 16u) {
+        // four passes of 16 x 4 pairs: pass q, lane 16 r + j: value j against value r + 4 q; row i = 16 bits of ballot i >> 2
+        const uint32_t xj = flg_g[ln & 15u];
+        const uint32_t *fp = flg_g + (ln >> 4);
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(xj - fp[0] <= e), m1 = __builtin_amdgcn_ballot_w64(xj - fp[4] <= e);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(xj - fp[8] <= e), m3 = __builtin_amdgcn_ballot_w64(xj - fp[12] <= e);
+        const uint32_t r0 = (uint32_t)(m0 >> sh16), r1 = (uint32_t)(m1 >> sh16), r2 = (uint32_t)(m2 >> sh16), r3 = (uint32_t)(m3 >> sh16);
+        uint32_t row = r0;  // (three conditional moves on lane masks that never change: as selects the compiler turns them into branches)
+        asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(row) : "v"(r1), "s"(q_is1));
+        asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(row) : "v"(r2), "s"(q_is2));
+        asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(row) : "v"(r3), "s"(q_is3));
+        cnt = (uint32_t)__popc(row & 0xFFFFu);
+        fv = have ? xj : 0u;
       } else {
-        for (uint32_t j = 0; j < n_lo; ++j) {
-          const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
-          cnt += (uint32_t)(x - fv <= e);
+        fv = have ? flg_g[ln] : 0u;
+        const uint32_t n_lo = n_flag < (uint32_t)kWave ? n_flag : (uint32_t)kWave;
+        if (kFlagCap > (uint32_t)kWave && n_flag > (uint32_t)kWave) {
+          // more than one flagged value per lane (long lists): the second goes through the same counts
+          const bool have_hi = ln + (uint32_t)kWave < n_flag;
+          fv_hi = have_hi ? flg_g[ln + (uint32_t)kWave] : 0u;
+          uint32_t cnt_hi = 0;
+          for (uint32_t j = 0; j < n_lo; ++j) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+            cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+          }
+          for (uint32_t j = (uint32_t)kWave; j < n_flag; ++j) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv_hi, (int)(j - (uint32_t)kWave));
+            cnt += (uint32_t)(x - fv <= e), cnt_hi += (uint32_t)(x - fv_hi <= e);
+          }
+          pass_hi = have_hi && cnt_hi > (uint32_t)p.a;
+        } else {
+          for (uint32_t j = 0; j < n_lo; ++j) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)j);
+            cnt += (uint32_t)(x - fv <= e);
+          }
         }
       }
       const bool pass = have && cnt > (uint32_t)p.a;
