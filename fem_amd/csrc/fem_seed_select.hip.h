@@ -24,6 +24,8 @@
 //     frequency sort (a sorting network on frequency << 14 | traceback order << 10 | start: stable by construction)
 //     and the lookup of the selected seeds' list bases stay in the lane.
 #pragma once
+#include <type_traits>
+
 #include "fem_seed_fast.hip.h"
 
 namespace femk {
@@ -67,11 +69,24 @@ __global__ void freq11_kernel(const uint32_t *lookup, uint32_t *freq11) {
   }
 }
 
-// 32 consecutive bits of a big-endian packed 2-bit stream, starting at base `pos`
+// 32 consecutive bits of a big-endian packed 2-bit stream, starting at base `pos`.  The word pair is taken one base
+// early — words (pos + 15) / 16 - 1 and the next —, so that the funnel shift is by -2 pos mod 32 in every case: where the
+// window starts on a word boundary the shift is 0 and the first word of the pair (strm[-1] at pos 0: any readable word
+// of the wave's LDS) drops out.  No branch and no multiply (a 32-bit integer multiply issues at a quarter of the rate).
 __device__ __forceinline__ uint32_t stream_window(const uint32_t *strm, uint32_t pos) {
-  const uint32_t w = pos >> 4, sh = 2u * (pos & 15u);
-  const uint32_t w0 = strm[w], w1 = strm[w + 1u];
-  return sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+  const uint32_t *w = strm + ((pos + 15u) >> 4) - 1;
+  uint32_t twice = pos << 1;
+  asm("" : "+v"(twice));  // (left to itself the compiler makes -2 pos mod 32 a multiplication by 30)
+  return __builtin_amdgcn_alignbit(w[0], w[1], 0u - twice);
+}
+// x / 3 and x / 6 for x < 4096 with the full-rate 24-bit multiply (the compiler's division by a constant is a v_mul_hi_u32)
+__device__ __forceinline__ uint32_t div3_small(uint32_t x) { return __umul24(x, 21846u) >> 16; }
+__device__ __forceinline__ uint32_t div6_small(uint32_t x) { return __umul24(x, 10923u) >> 16; }
+// 3 x as one shift-add (written as a product the compiler folds it into a v_mul_lo_u32 / v_mad_u64_u32 with its neighbours)
+__device__ __forceinline__ uint32_t times3(uint32_t x) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 // hash of the reverse complement of a 12-mer whose forward hash is hf (N counted as A on both strands: nm marks them)
 __device__ __forceinline__ uint32_t rc_hash(uint32_t hf, uint32_t nm) {
@@ -243,7 +258,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         // and gates are worked out again.
         auto place = [&](uint32_t w, uint32_t &i_c, uint32_t &j, uint32_t &S) -> bool {
           const uint32_t i = __umulhi(w, magic);
-          j = w - i * SP;
+          j = w - __umul24(i, SP);
           i_c = i < cnt ? i : 0u;
           const uint32_t fl = r_flag[i_c];
           S = r_len[i_c] - (uint32_t)(kK - 1);
@@ -281,10 +296,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
                 f_rev = p.lookup[hr + 1u] - p.lookup[hr];
               }
               const uint32_t jr = S - 1u - j;
-              const uint32_t gi = __umulhi(j, 0x55555556u), gr = __umulhi(jr, 0x55555556u);  // / 3
-              uint16_t *row = fq + (size_t)i * 6u * gstride;
-              row[(j - 3u * gi) * gstride + gi] = (uint16_t)(f_fwd < 0xFFFFu ? f_fwd : 0xFFFFu);
-              row[(3u + jr - 3u * gr) * gstride + gr] = (uint16_t)(f_rev < 0xFFFFu ? f_rev : 0xFFFFu);
+              const uint32_t gi = div3_small(j), gr = div3_small(jr);
+              uint16_t *row = fq + __umul24(i, 6u * gstride);
+              row[__umul24(j - times3(gi), gstride) + gi] = (uint16_t)(f_fwd < 0xFFFFu ? f_fwd : 0xFFFFu);
+              row[__umul24(3u + jr - times3(gr), gstride) + gr] = (uint16_t)(f_rev < 0xFFFFu ? f_rev : 0xFFFFu);
               if (f_fwd >= 0xFFFFu || f_rev >= 0xFFFFu) atomicOr(&r_flag[i], kSlow);  // (16 bits do not hold it: generic kernel)
             }
           }
@@ -295,45 +310,58 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
       const uint32_t n_gl = cnt * 6u;
       for (uint32_t gl0 = 0; gl0 < n_gl; gl0 += (uint32_t)kWave) {
         const uint32_t gl = gl0 + ln;
-        const uint32_t i = __umulhi(gl, 0x2AAAAAABu), u = gl - 6u * i;  // / 6
+        const uint32_t i = div6_small(gl), u = gl - __umul24(i, 6u);
         const uint32_t i_c = gl < n_gl ? i : 0u;
-        const uint32_t strand = u >= 3u ? 1u : 0u, si = u - 3u * strand;
+        const uint32_t strand = u >= 3u ? 1u : 0u, si = u - times3(strand);
         const uint32_t fl = r_flag[i_c], S = r_len[i_c] - (uint32_t)(kK - 1);
         const bool read_ok = gl < n_gl && (fl & kShape) && !(fl & kSlow);
         const bool valid = read_ok && ((fl >> strand) & 1u);
-        const uint32_t ncols = valid ? (S - si) / 3u - (uint32_t)(R * kLg) + 1u : 0u;
+        const uint32_t ncols = valid ? div3_small(S - si) - (uint32_t)(R * kLg) + 1u : 0u;
         const uint32_t maxcols = wave_max_u32(ncols);
-        const uint16_t *F = fq + ((size_t)i_c * 6u + u) * gstride;
+        const uint16_t *F = fq + __umul24(__umul24(i_c, 6u) + u, gstride);
         uint32_t key[R];  // frequency << 14 | traceback order << 10 | start, per selected seed
 #pragma unroll
         for (int t = 0; t < R; ++t) key[t] = (uint32_t)t << 10;  // a seed that was never taken is all zero (see below)
         if (maxcols != 0) {
           uint32_t tlo[R], thi[R], m_last = 0, iters = 0;
-          if (maxcols <= 32u)
+          const bool wide = maxcols > 32u;  // (wave-uniform)
+          if (!wide)
             select_dp<R, false>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
           else
             select_dp<R, true>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
           if (valid) atomicAdd(&r_pre[i_c], m_last);  // M[R][C-1] (src/filter.c:202)
           // ---- traceback (src/filter.c:30-41): row R first; the highest taken column at or below the previous one.
           //      If column 0 is reached before R seeds were taken the reference's remaining seeds are uninitialised
-          //      (src/filter.c:33-41): all zero here, as in the oracle ----
+          //      (src/filter.c:33-41): all zero here, as in the oracle.  (Up to 32 columns — every BASELINE shape — the take
+          //      masks are one word: no 64-bit shifts.) ----
           int col = (int)ncols - 1;
           bool alive = valid;
+          auto traceback = [&](auto wide_c) {
 #pragma unroll
-          for (int r = R - 1; r >= 0; --r) {
-            const int t = R - 1 - r;
-            if (alive) {
-              const uint32_t shift = iters - 1u - (uint32_t)col;  // bits >= shift are the columns <= col
-              const uint64_t seg = ((((uint64_t)thi[r]) << 32) | tlo[r]) >> shift;
-              if (seg == 0) {
-                alive = false;
-              } else {
-                col -= __builtin_ctzll(seg);
-                const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
-                key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + 3u * idx);  // (65 534 << 14 fits)
+            for (int r = R - 1; r >= 0; --r) {
+              const int t = R - 1 - r;
+              if (alive) {
+                const uint32_t shift = iters - 1u - (uint32_t)col;  // bits >= shift are the columns <= col
+                int step_back;
+                bool none;
+                if constexpr (decltype(wide_c)::value) {
+                  const uint64_t seg = ((((uint64_t)thi[r]) << 32) | tlo[r]) >> shift;
+                  none = seg == 0, step_back = __builtin_ctzll(seg);
+                } else {
+                  const uint32_t seg = tlo[r] >> shift;
+                  none = seg == 0, step_back = __builtin_ctz(seg);
+                }
+                if (none) {
+                  alive = false;
+                } else {
+                  col -= step_back;
+                  const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
+                  key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + times3(idx));  // (65 534 << 14 fits)
+                }
               }
             }
-          }
+          };
+          if (!wide) traceback(std::false_type{}); else traceback(std::true_type{});
         }
         // ---- qsort(compare_seed) (src/filter.c:204): ascending frequency, stable (glibc's merge sort):
         //      the traceback order in the key breaks ties, so any sorting network gives the stable order ----
