@@ -247,6 +247,15 @@ struct fem_dev {
 
 namespace {
 
+// Test / measurement switches of the library are read only when FEM_TESTING=1 (tests/conftest.py sets it): a production
+// process does not steer kernels through its environment.
+bool testing_switch(const char *name) {
+  static const bool testing = [] { const char *v = getenv("FEM_TESTING"); return v && v[0] == '1'; }();
+  if (!testing) return false;
+  const char *v = getenv(name);
+  return v && v[0] == '1';
+}
+
 int fail(fem_dev *h, int rc, const std::string &msg) {
   if (h) h->err = msg;
   return rc;
@@ -475,13 +484,16 @@ uint32_t kernel_regs_r(bool join, bool banked) {
   return hipFuncGetAttributes(&a, f) == hipSuccess && a.numRegs > 0 ? (uint32_t)a.numRegs : 128u;
 }
 // vector registers per lane of seed_join_kernel<R> / seed_select_kernel<R>
+// (handles of several GPUs launch from their own threads: the cache is atomic; every thread would store the same value)
 uint32_t kernel_regs(int R, bool join, bool banked = false) {
-  static uint32_t cache[2][2][femk::kMaxR + 1] = {};
-  uint32_t &c = cache[banked ? 1 : 0][join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
+  static std::atomic<uint32_t> cache[2][2][femk::kMaxR + 1] = {};
+  std::atomic<uint32_t> &slot = cache[banked ? 1 : 0][join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
+  uint32_t c = slot.load(std::memory_order_relaxed);
   if (c) return c;
 #define FEM_CALL(r) c = kernel_regs_r<r>(join, banked)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
+  slot.store(c, std::memory_order_relaxed);
   return c;
 }
 int select_blocks_per_cu(int R, bool banked, int block, uint32_t lds) {
@@ -780,7 +792,7 @@ int launch_batch(fem_dev *h, Slot &s) {
         // extra waves cost the verify kernel lanes.)  FEM_GRID_MULT overrides the multiple (measurement only).
         const uint64_t key = ((uint64_t)R << 40) | ((uint64_t)hash << 32) | lds_bytes;
         if (h->fast_occ_key != key) h->fast_occ_key = key, h->fast_occ_blocks = fast_blocks_per_cu((int)R, hash, (int)(64u * wpb), lds_bytes);
-        static const uint64_t mult = getenv("FEM_GRID_MULT") ? (uint64_t)atoi(getenv("FEM_GRID_MULT")) : 1;
+        static const uint64_t mult = testing_switch("FEM_TESTING") && getenv("FEM_GRID_MULT") ? (uint64_t)std::max(1, atoi(getenv("FEM_GRID_MULT"))) : 1;
         const uint64_t per_cu = h->fast_occ_blocks > 0 ? (uint64_t)h->fast_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         const uint64_t wanted = (s.n_reads + (uint64_t)femk::kReadBlock * wpb - 1) / ((uint64_t)femk::kReadBlock * wpb);
         grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wanted, (uint64_t)h->n_cu * per_cu * mult));
@@ -819,7 +831,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.prefetched_reads2 = 0, s.prefetched_cand = 0;
-  static const bool no_prefetch = [] { const char *e = getenv("FEM_NO_PREFETCH"); return e && e[0] == '1'; }();
+  static const bool no_prefetch = testing_switch("FEM_NO_PREFETCH");
   // (only behind fem_dev_stage_reads, whose caller packs the next batch in the meantime; a caller of the zero-copy form is
   // idle until it fetches, and the extra traffic next to its four-times-larger H2D cost 5 % there)
   if (s.prefetch_results && s.staged_by_copy && !no_prefetch) {
@@ -1073,20 +1085,18 @@ int fem_dev_open(int device, fem_dev **out) {
     delete h;
     return FEM_ERR_HIP;
   }
-  const char *no = getenv("FEM_NO_OVERLAP");
-  h->no_overlap = no && no[0] == '1';
-  const char *fg = getenv("FEM_FORCE_GENERIC");
-  h->force_generic = fg && fg[0] == '1';
-  const char *fh = getenv("FEM_FORCE_HASH");
-  h->force_hash = fh && fh[0] == '1';
-  const char *fd = getenv("FEM_FORCE_DENSE");
-  h->force_dense = fd && fd[0] == '1';
-  const char *nd = getenv("FEM_NO_DENSE");
-  h->no_dense = nd && nd[0] == '1';
-  const char *tb = getenv("FEM_TEST_TINY_BUFFERS");
-  h->tiny_buffers = tb && tb[0] == '1';
-  if (const char *bl = getenv("FEM_TEST_BANK_BASES")) h->bank_limit = strtoull(bl, nullptr, 10);
-  if (const char *bs = getenv("FEM_TEST_BANK_SEQS")) h->bank_seqs = (uint32_t)strtoul(bs, nullptr, 10);
+  // Kernel-choice and buffer-size overrides exist for the parity tests and for A/B measurements only: a production process
+  // does not look at its environment for them unless FEM_TESTING=1 says so.
+  if (testing_switch("FEM_TESTING")) {
+    h->no_overlap = testing_switch("FEM_NO_OVERLAP");
+    h->force_generic = testing_switch("FEM_FORCE_GENERIC");
+    h->force_hash = testing_switch("FEM_FORCE_HASH");
+    h->force_dense = testing_switch("FEM_FORCE_DENSE");
+    h->no_dense = testing_switch("FEM_NO_DENSE");
+    h->tiny_buffers = testing_switch("FEM_TEST_TINY_BUFFERS");
+    if (const char *bl = getenv("FEM_TEST_BANK_BASES")) h->bank_limit = strtoull(bl, nullptr, 10);
+    if (const char *bs = getenv("FEM_TEST_BANK_SEQS")) h->bank_seqs = (uint32_t)strtoul(bs, nullptr, 10);
+  }
   *out = h;
   return FEM_OK;
 }
@@ -1376,8 +1386,7 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
   // ---- reads of one length: two bits per base cross the link instead of eight ----
   // (test hook, read per batch on purpose: tests/test_gpu_packed.py switches it between two batches of one handle; one
   // getenv per batch of >= 10^4 reads is not measurable)
-  const char *np = getenv("FEM_NO_PACK");
-  const bool no_pack = np && np[0] == '1';
+  const bool no_pack = testing_switch("FEM_NO_PACK");
   if (n && min_len == max_len && max_len > 0 && n_bases < 0xFFFFFFF0ull && !no_pack) {
     const uint32_t len = max_len, bpr = (len + 3u) / 4u;
     const uint64_t code_bytes = (n * bpr + 7u) & ~7ull;

@@ -307,8 +307,8 @@ int map_main(int argc, char **argv) {
 
   // Host placement: with one GPU the whole process (parser, formatter, staging buffers) moves next to it, before any
   // thread pool exists; with several, each GPU's worker thread does so for itself and the buffers it acquires.
-  const char *sg = getenv("FEM_TEST_SHARE_GPU");
-  const bool share_gpu = sg && sg[0] == '1';
+  const char *sg = getenv("FEM_TEST_SHARE_GPU"), *tg = getenv("FEM_TESTING");  // (test hook: honoured under FEM_TESTING=1 only)
+  const bool share_gpu = sg && sg[0] == '1' && tg && tg[0] == '1';
   if (n_gpus == 1 || share_gpu) (void)fem_bind_thread_near_device(0);
   Reference ref;
   if (!ref.load(ref_path)) exit(EXIT_FAILURE);

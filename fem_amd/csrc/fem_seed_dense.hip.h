@@ -24,8 +24,9 @@
 namespace femk {
 
 constexpr uint32_t kDenseGap = 2048u;          // positions between two sequences in the global coordinate (> e + 1)
-constexpr uint32_t kDenseNear = 1024u;         // entries with pos < this are stored remapped (>= the longest read)
-constexpr uint32_t kDenseRemap = 0xF0000000u;  // remapped entry: kDenseRemap | seq << 10 | pos  (seq: index within its bank, < 2^18)
+// kDenseNear = 1024 (entries with pos < this are stored remapped: >= the longest read) and kDenseRemap = 0xF0000000 (remapped
+// entry: kDenseRemap | seq << 10 | pos, seq = index within its bank, < 2^18) live in fem_seed_select.hip.h: the selection looks
+// at such entries too, where a reference is cut into banks.
 constexpr uint32_t kDenseMaxSeq = 1u << 18;
 // A reference whose sequences do not fit one 32-bit coordinate space is cut into up to kDenseMaxBanks BANKS of consecutive
 // sequences, each with coordinates of its own (goff restarts at kDenseGap).  A bucket's list is sorted by (sequence,

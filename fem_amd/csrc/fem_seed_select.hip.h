@@ -31,6 +31,8 @@
 namespace femk {
 
 constexpr uint32_t kDenseMaxBanks = 4;       // banks of sequences with coordinates of their own (fem_seed_dense.hip.h)
+constexpr uint32_t kDenseNear = 1024u;         // entries of the 32-bit occurrence table with pos < this are stored remapped ...
+constexpr uint32_t kDenseRemap = 0xF0000000u;  // ... as kDenseRemap | seq << 10 | pos (fem_seed_dense.hip.h)
 constexpr uint32_t kSelKeepAll = 1u << 15;  // in a last run's (start | frequency << 16) word: no truncation at max(U) in this bank
 constexpr uint32_t kSelOk = 0u, kSelNone = 1u, kSelSlow = 2u;  // sel_hdr[read].x & 3: joined / no candidates / generic kernel
 constexpr uint32_t kSelMaxCols = 64u;                          // DP columns a lane's take masks hold
@@ -398,28 +400,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
           } else {
             // ---- banks (fem_seed_dense.hip.h): every list cut at the banks' boundaries; per bank the part's base and
             //      length, and for the last run what becomes of "values <= max(U) only" (src/filter.c:85) ----
-            const uint32_t nb = p.n_banks;
+            const uint32_t n_banks = p.n_banks;
             uint32_t cut[R];  // where the current bank's part of list t starts
 #pragma unroll
             for (int t = 0; t < R; ++t) cut[t] = lo[t];
             uint32_t u_banks = 0;  // bit b: some run of U (t < R - 1) has entries in bank b
             uint32_t part[kDenseMaxBanks][R];
-            for (uint32_t b = 0; b < nb; ++b) {
+            bool unsure = false;
+            for (uint32_t b = 0; b < n_banks; ++b) {
 #pragma unroll
               for (int t = 0; t < R; ++t) {
                 const uint32_t f = key[t] >> 14;
                 uint32_t end = lo[t] + f;
-                if (f != 0u && b + 1u < nb) end = p.bank_lo[(size_t)b * p.n_buckets + hs[t]];
+                if (f != 0u && b + 1u < n_banks) end = p.bank_lo[(size_t)b * p.n_buckets + hs[t]];
                 part[b][t] = f != 0u ? end - cut[t] : 0u;
-                if (t < R - 1 && part[b][t] != 0u) u_banks |= 1u << b;
+                if (t < R - 1 && part[b][t] != 0u) {
+                  u_banks |= 1u << b;
+                  // "U has entries in this bank" must mean entries the reference keeps: one with pos < start is dropped
+                  // (src/filter.c:89,106), and if that is all the bank holds of U, max(U) lies in a lower bank.  A part is
+                  // ascending, so it is dropped whole only if its first AND its last entry are (both near a sequence
+                  // start, stored remapped): such a read goes to the generic kernel (review of round 3).
+                  const uint32_t start = key[t] & 1023u;
+                  const uint32_t first = p.occ32[cut[t]], last = p.occ32[end - 1u];
+                  if (first >= kDenseRemap && (first & (kDenseNear - 1u)) < start && last >= kDenseRemap && (last & (kDenseNear - 1u)) < start) unsure = true;
+                }
               }
 #pragma unroll
               for (int t = 0; t < R; ++t) cut[t] += part[b][t];
             }
+            too_long |= unsure;
 #pragma unroll
             for (int t = 0; t < R; ++t) cut[t] = lo[t];
-            for (uint32_t b = 0; b < nb; ++b) {
-              uint2 *out = p.sel + (((size_t)(rd0 + i_c) * nb + b) * 6u + u) * (uint32_t)R;
+            for (uint32_t b = 0; b < n_banks; ++b) {
+              uint2 *out = p.sel + (((size_t)(rd0 + i_c) * n_banks + b) * 6u + u) * (uint32_t)R;
               const bool above = (u_banks >> (b + 1u)) != 0u;                 // U has entries in a higher bank: keep all of the last run
               const bool gone = !above && !((u_banks >> b) & 1u) && u_banks;  // ... only in lower banks: the last run is dropped here
 #pragma unroll

@@ -1456,7 +1456,7 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
     TAIL_TRY(hipStreamSynchronize(stream));
     n_overflow = h_ctl[1];
-    if (getenv("FEM_TAIL_DEBUG"))
+    if (getenv("FEM_TESTING") && getenv("FEM_TAIL_DEBUG"))
       fprintf(stderr, "[tail] records %u, queued for ordering %u, walked %u, overflow pass %u, lanes %u/%u\n", nr, h_ctl[0], h_ctl[3], n_overflow, fast_lanes, lanes);
     if (n_overflow) {  // records whose CIGAR or MD outgrew the first staging: once more, with room for any walk
       TAIL_TRY(m.o_ops.need((size_t)n_overflow * o_ops_cap * 4));

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the library reads its test / measurement switches (FEM_FORCE_*, FEM_TEST_*, FEM_NO_*) only under FEM_TESTING=1
+os.environ.setdefault("FEM_TESTING", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

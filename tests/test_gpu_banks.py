@@ -148,3 +148,32 @@ def test_fuzz_slice_on_a_banked_reference():
         os.environ.pop("FEM_TEST_BANK_BASES")
     assert n == 60 and bad == 0
     assert seen.count("seed_join_banked_kernel") > 40, seen  # (e + 1 + a > 10 runs the generic kernel)
+
+
+def test_a_higher_bank_whose_part_of_u_is_dropped_whole():
+    # Round-3 review: "U has entries in bank b" must mean entries the reference KEEPS.  Here a piece of the read sits at the very
+    # start of the first sequence of bank 1, so that the occurrences of its k-mers there have pos < the seed's offset in the read
+    # and are dropped (src/filter.c:89,106): max(U) then lies in bank 0, and the last run — a poly-A k-mer with a tandem of
+    # occurrences above max(U) in bank 0 — must be cut there (src/filter.c:85) instead of being merged whole.  Many placements of
+    # the pieces, both strands, every one against the oracle.
+    rng = np.random.default_rng(8585)
+    L, e = 100, 3
+    reads, seqs_sets = [], []
+    for trial in range(12):
+        core = bytearray(util.rand_seq(rng, L))
+        at = int(rng.integers(30, 70))
+        core[at:at + 14] = b"A" * 14                      # the read holds a poly-A k-mer: frequent, hence the last run
+        core = bytes(core)
+        cut0 = int(rng.integers(8, 40))
+        piece = core[cut0:cut0 + int(rng.integers(20, 45))]  # its k-mers start at read offset cut0 + j, at pos j of sequence B
+        a_seq = (util.rand_seq(rng, int(rng.integers(1500, 4000))) + core + util.rand_seq(rng, int(rng.integers(400, 2500))) +
+                 b"A" * int(rng.integers(20, 70)) + util.rand_seq(rng, 900) + b"A" * 40 + util.rand_seq(rng, 1200))
+        b_seq = piece + util.rand_seq(rng, int(rng.integers(2500, 5000)))
+        seqs_sets.append([a_seq, b_seq])
+        reads.append([core, fo.revcomp(core), util.mutate(rng, core, 1)[:L].ljust(L, b"C"), core[:L - 1] + b"G"])
+    for seqs, rds in zip(seqs_sets, reads):
+        dev = _device(len(seqs[0]) + 2048 + 100)  # bank 0 = sequence A, bank 1 = sequence B
+        try:
+            _compare(dev, seqs, rds + util.make_reads(rng, seqs, 60, L, e), e, 1)
+        finally:
+            dev.close()
