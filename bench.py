@@ -517,7 +517,7 @@ def cpu_baseline(w, data, n_sample, dev, threads, label="C2", pipe_check=None):
             "counters_match_device": bool(np.array_equal(got, st))}
 
 
-def e2e_cli(w, data, n_reads, threads):
+def e2e_cli(w, data, n_reads, threads, label="C2"):
     """`FEM index` + `FEM map` on generated FASTA / FASTQ files: the mapping-phase time the reference prints itself
     ("Time:", src/FEM_map.c:172,219), FASTQ -> SAM."""
     import re
@@ -526,6 +526,11 @@ def e2e_cli(w, data, n_reads, threads):
     L, e = w["L"], w["e"]
     exe = os.path.join(ROOT, "fem_amd", "csrc", "FEM")
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    need = int(len(text) * 1.02) + 9 * (len(text) // 3) + n_reads * (2 * L + 16)  # FASTA + index file + FASTQ
+    if base and shutil.disk_usage(base).free < need + (4 << 30):
+        base = None  # (inputs then sit behind the page cache of the ordinary temporary directory)
+    if shutil.disk_usage(base or tempfile.gettempdir()).free < need + (2 << 30):
+        return {"error": "not enough room for %.1f GB of input files" % (need / 1e9)}
     d = tempfile.mkdtemp(prefix="fem_e2e_", dir=base)
     # the SAM file goes to the ordinary temporary directory (a disk file system behind the page cache: what a user writes
     # to), the inputs sit in memory.  (tmpfs takes 6 GB/s from one writer, the page cache of the GPU box's /tmp 11 GB/s:
@@ -537,10 +542,13 @@ def e2e_cli(w, data, n_reads, threads):
         host.write_fasta(fa, text, off, lens)
         bases, _ = host.synth_reads(w["seed"], text, off, lens, n_reads, L, e, first_read=0, threads=threads)
         host.write_fastq(fq, bases, L, n_reads)
-        r = subprocess.run([exe, "index", "12", "3", fa, ix], capture_output=True, text=True, timeout=300)
+        t_ix = time.perf_counter()
+        r = subprocess.run([exe, "index", "12", "3", fa, ix], capture_output=True, text=True, timeout=600)
+        t_ix = time.perf_counter() - t_ix
         if r.returncode != 0:
             return {"error": "FEM index failed: " + r.stderr[-300:]}
         env = dict(os.environ, FEM_STAGE_TIMES="1")
+        load = [None]
 
         def run_map(out_path):
             t0 = time.perf_counter()
@@ -551,6 +559,8 @@ def e2e_cli(w, data, n_reads, threads):
                 return None, wall, "FEM map failed: " + r.stderr[-300:]
             m = re.search(r"Time: ([0-9.]+)s", r.stderr)
             st = re.search(r"stage busy seconds: (.*)", r.stderr)
+            ld = re.search(r"resident on \d+ GPUs? in ([0-9.]+)s", r.stderr)
+            load[0] = float(ld.group(1)) if ld else None
             return (float(m.group(1)) if m else None), wall, (st.group(1) if st else None)
 
         secs, wall, busy = run_map(sam)
@@ -561,9 +571,10 @@ def e2e_cli(w, data, n_reads, threads):
         # the same run with the SAM text discarded: what the host stages do when no file system is in the way
         null_secs, _, null_busy = run_map("/dev/null")
         return {"value": round(n_reads / secs / 1e6, 3), "unit": "Mreads/s",
-                "what": "FEM map mapping phase (its own 'Time:' line): FASTQ parse -> device -> SAM text -> file, %d reads of C2, -t %d, "
-                        "inputs in %s, SAM file in %s" % (n_reads, threads, base or "tmp", d_out),
+                "what": "FEM map mapping phase (its own 'Time:' line, src/FEM_map.c:172,219): FASTQ parse -> device -> SAM text -> file, "
+                        "%d reads of %s, -t %d, inputs in %s, SAM file in %s" % (n_reads, label, threads, base or "tmp", d_out),
                 "seconds": secs, "wall_seconds_incl_load": round(wall, 3), "sam_bytes": sam_bytes, "stage_busy": busy,
+                "fem_index_wall_seconds": round(t_ix, 2), "reference_and_index_resident_seconds": load[0],
                 "to_dev_null": {"value": round(n_reads / null_secs / 1e6, 3) if null_secs else None, "seconds": null_secs,
                                 "stage_busy": null_busy}}
     finally:
@@ -585,7 +596,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
     ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
                                                                          "the oracle's 3 Gbp index takes ~30 s to build)")
-    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run on C2 (0 = skip)")
+    ap.add_argument("--e2e-reads-c3", type=int, default=8_000_000, help="reads of the end-to-end FEM map run on the headline configuration "
+                                                                        "(3 GB FASTA + 8 GB index file + FASTQ in /dev/shm; 0 = skip)")
     ap.add_argument("--profile-replay", type=int, default=0, help="profiling aid: only the resident replay of --workload (kernels on batches "
                                                                      "already in HBM, slots in rotation, no copies in flight), this many steps; "
                                                                      "prints the HIP-event means of exactly those launches")
@@ -647,6 +660,7 @@ def main():
     dev = None
     bw = {}
     cpu_c3 = [None]
+    e2e_c3 = [None]
 
     def cpu_c3_now():
         """The headline configuration on the host cores, while the 3 Gbp reference is at hand (host text + device)."""
@@ -657,6 +671,12 @@ def main():
                                      pipe_check=results["c3"]["pipeline_check"])
             cpu_c3[0].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota,
                              device_pipeline_over_cpu=round(results["c3"]["value"] / max(cpu_c3[0]["value"], 1e-9), 1))
+        # ... and `FEM index` + `FEM map` end to end on the headline configuration (its own process and handle)
+        if e2e_c3[0] is None and not args.no_e2e and rk.world == 1 and "c3" in results and args.e2e_reads_c3 > 0 and ref_key3 in data_cache:
+            try:
+                e2e_c3[0] = e2e_cli(w3, data_cache[ref_key3][:3], args.e2e_reads_c3, threads, label="C3")
+            except Exception as ex:
+                e2e_c3[0] = {"error": repr(ex)}
 
     for key in [args.workload] + extras:
         w = WORKLOADS[key]
@@ -748,6 +768,8 @@ def main():
             del v_["pipeline_check"][k_]
     pc = head["pipeline_check"]
     out["counters_match_pipeline"] = bool(pc["repeats_identical"] and (pc.get("prefix_vs_oracle") or {"equal_to_oracle": True})["equal_to_oracle"])
+    if e2e_c3[0] is not None:
+        out["e2e_cli_c3"] = e2e_c3[0]
     out["config"]["counter_reduction"] = ("torch.distributed all_reduce, backend %s, %d rank(s)" % (backend, rk.world)) if rk.dist else "single process: none"
     print(json.dumps(out), flush=True)
     if rk.dist:
