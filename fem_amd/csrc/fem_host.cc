@@ -987,9 +987,29 @@ int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *pl, int n_threads, char *ba
 // the staging buffer: no ASCII copy of the batch exists anywhere on the host.  Needs reads of one length (the plan's shape:
 // min_len == max_len == read_len).  Returns 1 — and leaves the plan alive for fem_seqfile_fill — when the batch holds more
 // non-ACGT characters than exc_cap.
+static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, const fem_read_refs *refs);
+
 int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
                             uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off) {
-  if (!f || !pl || !codes || !names || !name_off || !n_exc_out || read_len == 0) return -1;
+  if (!names || !name_off) return -1;
+  return fill_packed_impl(f, pl, n_threads, read_len, codes, exc_cap, n_exc_out, quals, names, name_off, nullptr);
+}
+
+// The same without a copy of anything but the packed bases: where read r's name, bases and qualities lie in the input goes
+// into refs (arrays of the caller, n_reads entries each; refs->n and refs->read_len are set here).  Only for batches whose
+// records sit in the file's own mapping (a plain, uncompressed 4-line FASTQ file: the mapping lives as long as the handle):
+// 2 = not such a batch, the plan is still there (fem_seqfile_fill_packed or fem_seqfile_fill copy the fields instead).
+int fem_seqfile_fill_packed_refs(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                                 uint64_t *n_exc_out, fem_read_refs *refs) {
+  if (!f || !pl || !refs || !refs->name || !refs->name_len || !refs->seq || !refs->qual) return -1;
+  if (!pl->fast || !f->map || pl->m != f->map) return 2;
+  return fill_packed_impl(f, pl, n_threads, read_len, codes, exc_cap, n_exc_out, nullptr, nullptr, nullptr, refs);
+}
+
+static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, const fem_read_refs *refs) {
+  if (!f || !pl || !codes || !n_exc_out || read_len == 0) return -1;
   if (n_threads < 1) n_threads = 1;
   const uint32_t bpr = fempack::bytes_per_read(read_len);
   *n_exc_out = 0;
@@ -1026,15 +1046,20 @@ int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *pl, int n_threads, u
       bool bad = false;
       while (next_fq(m, p, h, rec, bad)) {
         if (rec.len == 0) continue;
-        name_off[r] = nm;
         fempack::pack_bases((const uint8_t *)rec.seq, read_len, codes + r * bpr, r * (uint64_t)read_len, exc[(size_t)t]);
-        if (quals) memcpy(quals + r * (uint64_t)read_len, rec.qual, rec.len);
-        memcpy(names + nm, rec.name, rec.name_len);
+        if (refs) {  // nothing else is copied: the formatter takes the fields from the mapping
+          ((const char **)refs->name)[r] = rec.name, ((uint32_t *)refs->name_len)[r] = (uint32_t)rec.name_len;
+          ((const char **)refs->seq)[r] = rec.seq, ((const char **)refs->qual)[r] = rec.qual;
+        } else {
+          name_off[r] = nm;
+          if (quals) memcpy(quals + r * (uint64_t)read_len, rec.qual, rec.len);
+          memcpy(names + nm, rec.name, rec.name_len);
+        }
         ++r, nm += rec.name_len;
       }
     }
     n_total = r0[(size_t)nt];
-    name_off[n_total] = n0[(size_t)nt];
+    if (!refs) name_off[n_total] = n0[(size_t)nt];
   }
   uint64_t n_exc = 0;
   for (const auto &v : exc) n_exc += v.size();
@@ -1047,6 +1072,7 @@ int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *pl, int n_threads, u
   for (const auto &v : exc)
     for (uint64_t x : v) *exc_pos++ = (uint32_t)(x >> 8), *exc_chr++ = (uint8_t)x;
   *n_exc_out = n_exc;
+  if (refs) ((fem_read_refs *)refs)->n = n_total, ((fem_read_refs *)refs)->read_len = read_len;
   fem_batch_plan_free(pl);
   return 0;
 }
@@ -1737,10 +1763,21 @@ int fem_records_sam(const fem_tail_ref *ref, const fem_seqset *reads, const fem_
   return join_parts(parts, n_threads, text, text_len);
 }
 
-int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rv, int n_threads,
-                          char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted) {
-  if (!ref || !reads || !rv || !buf || !cap || !parts) return -1;
-  if (rv->n_reads > reads->n) return -1;
+}  // extern "C"
+
+namespace {
+// What a record line takes from its read: name, bases as they were read, qualities.
+struct ReadFields {
+  const char *name, *fwd, *qual;
+  size_t name_len;
+  uint32_t len;
+};
+// fem_records_sam_parts / fem_records_sam_refs: `read_of(r)` says where read r's fields are.
+template <typename ReadOf>
+int records_sam_parts_impl(const fem_tail_ref *ref, uint64_t n_reads_have, ReadOf read_of, const fem_record_view *rv, int n_threads,
+                           char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted) {
+  if (!ref || !rv || !buf || !cap || !parts) return -1;
+  if (rv->n_reads > n_reads_have) return -1;
   if (n_threads < 1) n_threads = 1;
   const uint64_t n = rv->n_reads;
   const uint64_t total = n ? rv->rec_begin[n] : 0;
@@ -1763,8 +1800,8 @@ int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, cons
       for (uint64_t r = lo[(size_t)k]; r < lo[(size_t)k + 1]; ++r) {
         const uint32_t rb = rv->rec_begin[r], re = rv->rec_begin[r + 1];
         if (rb == re) continue;
-        const uint64_t name_len = reads->name_off[r + 1] - reads->name_off[r], len = reads->off[r + 1] - reads->off[r];
-        b += (uint64_t)(re - rb) * (name_len + max_rname + 2 * len + 96) + 11ull * (rv->cigar_off[re] - rv->cigar_off[rb]) + (rv->md_off[re] - rv->md_off[rb]);
+        const ReadFields rf = read_of(r);
+        b += (uint64_t)(re - rb) * (rf.name_len + max_rname + 2 * (uint64_t)rf.len + 96) + 11ull * (rv->cigar_off[re] - rv->cigar_off[rb]) + (rv->md_off[re] - rv->md_off[rb]);
       }
       need[(size_t)k + 1] = b;
     }
@@ -1787,11 +1824,10 @@ int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, cons
         for (uint64_t r = lo[(size_t)k]; r < lo[(size_t)k + 1]; ++r) {
           const uint32_t b = rv->rec_begin[r], e_ = rv->rec_begin[r + 1];
           if (b == e_) continue;  // unmapped reads produce no record (src/map.c:50)
-          const char *fwd = reads->bases + reads->off[r];
-          const uint32_t len = (uint32_t)(reads->off[r + 1] - reads->off[r]);
-          const char *qual = reads->quals ? reads->quals + reads->off[r] : nullptr;
-          const char *name = reads->names + reads->name_off[r];
-          const size_t name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
+          const ReadFields rf = read_of(r);
+          const char *fwd = rf.fwd, *qual = rf.qual, *name = rf.name;
+          const uint32_t len = rf.len;
+          const size_t name_len = rf.name_len;
           for (uint32_t j = b; j < e_; ++j) {
             Record rec;
             rec.flag = rv->flag[j], rec.tid = rv->tid[j], rec.pos0 = rv->pos0[j], rec.nm = rv->nm[j];
@@ -1807,6 +1843,36 @@ int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, cons
   if (failed) return -4;
   if (n_asserted) *n_asserted = asserted;
   return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rv, int n_threads,
+                          char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted) {
+  if (!reads) return -1;
+  auto read_of = [reads](uint64_t r) {
+    ReadFields f;
+    f.fwd = reads->bases + reads->off[r], f.len = (uint32_t)(reads->off[r + 1] - reads->off[r]);
+    f.qual = reads->quals ? reads->quals + reads->off[r] : nullptr;
+    f.name = reads->names + reads->name_off[r], f.name_len = (size_t)(reads->name_off[r + 1] - reads->name_off[r]);
+    return f;
+  };
+  return records_sam_parts_impl(ref, reads->n, read_of, rv, n_threads, buf, cap, parts, n_asserted);
+}
+
+// The same for reads that were never copied: name, bases and qualities of read r are where the parser found them in the
+// (still mapped) input file — fem_seqfile_fill_packed_refs.  Reads of one length.
+int fem_records_sam_refs(const fem_tail_ref *ref, const fem_read_refs *reads, const fem_record_view *rv, int n_threads, char **buf,
+                         uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted) {
+  if (!reads || (reads->n && (!reads->name || !reads->name_len || !reads->seq || !reads->qual))) return -1;
+  auto read_of = [reads](uint64_t r) {
+    ReadFields f;
+    f.fwd = reads->seq[r], f.len = reads->read_len, f.qual = reads->qual[r];
+    f.name = reads->name[r], f.name_len = reads->name_len[r];
+    return f;
+  };
+  return records_sam_parts_impl(ref, reads->n, read_of, rv, n_threads, buf, cap, parts, n_asserted);
 }
 
 // ------------------------------------------------------------------------------------------------

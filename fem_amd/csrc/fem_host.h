@@ -70,6 +70,21 @@ int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *plan, int n_threads, char *
  * the characters), < 0 on a bad argument. */
 int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *plan, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
                             uint64_t *n_exc, char *quals, char *names, uint64_t *name_off);
+/* Reads that are not copied at all: where name, bases and qualities of read r lie in the input (arrays of n entries owned
+ * by the caller; reads of one length).  fem_seqfile_fill_packed_refs fills them — and packs the bases as fem_seqfile_fill_packed
+ * does — for batches whose records sit in the mapping of a plain, uncompressed 4-line FASTQ file (valid until
+ * fem_seqfile_close); it returns 2 and leaves the plan alone for any other batch (gzip / BGZF windows are reused, the
+ * sequential reader holds copies), 1 as fem_seqfile_fill_packed.  fem_records_sam_refs (below) renders records from them. */
+typedef struct {
+  uint64_t n;
+  uint32_t read_len;
+  const char **name;
+  uint32_t *name_len;
+  const char **seq;
+  const char **qual;
+} fem_read_refs;
+int fem_seqfile_fill_packed_refs(fem_seqfile *f, fem_batch_plan *plan, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
+                                 uint64_t *n_exc, fem_read_refs *refs);
 void fem_batch_plan_free(fem_batch_plan *plan);
 
 /* ---------------- index files (src/index.c:100-168) ---------------- */
@@ -149,6 +164,10 @@ typedef struct {
 } fem_text_part;
 int fem_records_sam_parts(const fem_tail_ref *ref, const fem_seqset *reads, const fem_record_view *rec, int n_threads,
                           char **buf, uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted);
+/* fem_records_sam_parts for reads the parser did not copy (fem_seqfile_fill_packed_refs): QNAME, SEQ and QUAL of a line come
+ * straight out of the input file's mapping. */
+int fem_records_sam_refs(const fem_tail_ref *ref, const fem_read_refs *reads, const fem_record_view *rec, int n_threads, char **buf,
+                         uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted);
 /* "@SQ\tSN:%s\tLN:%d\n" per sequence (src/output_queue.c:104-108). *text is malloc'd. */
 int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len);
 

@@ -226,6 +226,9 @@ struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pa
   Growable quals, names, name_off;  // host formatting (FEM_HOST_FORMAT=1 / FEM_HOST_TAIL=1): names and qualities stay on the host
   bool packed = false;                          // the parser wrote this batch at two bits per base (fem_seqfile_fill_packed)
   uint64_t n_exc = 0;                           // ... and this many characters outside "ACGT" behind the codes
+  bool spliced = false;                         // ... and copied nothing else: names, bases, qualities stay in the input's mapping
+  Growable r_name, r_name_len, r_seq, r_qual;   //     (where each read's fields lie: fem_seqfile_fill_packed_refs)
+  fem_read_refs refs{};
   char *q_stage = nullptr, *n_stage = nullptr;  // device SAM text: pinned staging lent by the library
   uint64_t *no_stage = nullptr;
   uint64_t names_cap = 0, want_names = 0;
@@ -328,15 +331,22 @@ int map_main(int argc, char **argv) {
 
   const char *ht = getenv("FEM_HOST_TAIL");
   const bool host_tail = ht && ht[0] == '1';
-  // SAM text is rendered on the device (fem_dev_fetch_sam) unless FEM_HOST_FORMAT=1 (records from the device, text by the
-  // host threads) or FEM_HOST_TAIL=1 (ordering, traceback and text by the host threads)
-  const char *hf = getenv("FEM_HOST_FORMAT");
+  // Where the SAM text is made.  Default: on the device (fem_dev_fetch_sam: qualities and names go there with the bases, the
+  // finished text comes back: ~365 bytes per read over the link).  FEM_HOST_FORMAT=1: the device maps, orders, traces back and
+  // hands over RECORDS (FLAG, RNAME id, POS, CIGAR, NM, MD: ~30 bytes per read) and the host threads splice them between
+  // QNAME, SEQ and QUAL, which never leave the host — for a plain FASTQ file they are not even copied: the formatter reads them
+  // out of the input's mapping (fem_seqfile_fill_packed_refs; FEM_SPLICE=0: copied by the parser).  ~55 bytes per read cross
+  // the link; the price is ~0.07 core-microseconds of formatting per read, which on a 16-core share of the host is more than
+  // the link costs (measured, 16 M reads of C2 to /dev/null: 75-93 Mreads/s against 100-117), so it is the
+  // option, not the default.  FEM_HOST_TAIL=1: ordering, traceback and text by the host threads from the per-candidate outcome.
+  const char *hf = getenv("FEM_HOST_FORMAT"), *spl = getenv("FEM_SPLICE");
   const bool device_text = !host_tail && !(hf && hf[0] == '1');
+  const bool splice = !host_tail && !device_text && !(spl && spl[0] == '0');
   // With the text on the device the link is what bounds the run: batches of equal-length reads then cross it at two bits per
   // base — the parser writes that form straight into the pinned staging (fem_seqfile_fill_packed ->
   // fem_dev_commit_stage_packed: no host work per base beyond the parse itself) (FEM_PACK_BASES=0: always as characters).
   const char *pk = getenv("FEM_PACK_BASES");
-  const bool pack_bases = device_text && !(pk && pk[0] == '0');
+  const bool pack_bases = !host_tail && !(pk && pk[0] == '0');
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
   // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are unusual
   // (the reader asks for larger buffers when a batch needs them)
@@ -504,7 +514,8 @@ int map_main(int argc, char **argv) {
                            rec.cigar_off, rec.cigar, rec.md_off, rec.md};
         t->parts.assign((size_t)fmt_threads, fem_text_part{0, 0});
         uint64_t na = 0;
-        fmt = fem_records_sam_parts(&ref.view, &reads, &rv, fmt_threads, &t->buf, &t->cap, t->parts.data(), &na);
+        fmt = b->spliced ? fem_records_sam_refs(&ref.view, &b->refs, &rv, fmt_threads, &t->buf, &t->cap, t->parts.data(), &na)
+                         : fem_records_sam_parts(&ref.view, &reads, &rv, fmt_threads, &t->buf, &t->cap, t->parts.data(), &na);
         n_asserted += na;
       }
       busy_text += real_time() - t0;
@@ -673,15 +684,29 @@ int map_main(int argc, char **argv) {
         busy_read += real_time() - t0;
         break;  // end of input (or failure)
       }
-      b->packed = false, b->n_exc = 0;
+      b->packed = false, b->spliced = false, b->n_exc = 0;
       rc = 1;
       if (pack_bases && b->shape.min_len == b->shape.max_len && b->shape.n_bases < 0xFFFFFFF0ull) {
         // reads of one length: two bits per base straight into the staging; 1 = too many characters outside "ACGT" for that form
         uint64_t exc_cap = 0;
-        if (fem_dev_packed_layout(b->shape.n_reads, b->shape.max_len, nullptr, nullptr, &exc_cap) == FEM_OK)
+        const bool lay = fem_dev_packed_layout(b->shape.n_reads, b->shape.max_len, nullptr, nullptr, &exc_cap) == FEM_OK;
+        if (lay && splice) {
+          // ... and nothing else copied: where each read's name, bases and qualities lie in the file's mapping (2 = the records
+          // do not sit in a mapping that stays: gzip / BGZF windows, the sequential reader)
+          const uint64_t n = b->shape.n_reads;
+          if (b->r_name.reserve(n * sizeof(char *)) && b->r_seq.reserve(n * sizeof(char *)) && b->r_qual.reserve(n * sizeof(char *)) &&
+              b->r_name_len.reserve(n * sizeof(uint32_t))) {
+            b->refs.name = (const char **)b->r_name.p, b->refs.seq = (const char **)b->r_seq.p, b->refs.qual = (const char **)b->r_qual.p;
+            b->refs.name_len = (uint32_t *)b->r_name_len.p;
+            rc = fem_seqfile_fill_packed_refs(f, plan, rd_threads, b->shape.max_len, (uint8_t *)b->bases, exc_cap, &b->n_exc, &b->refs);
+            b->packed = b->spliced = rc == 0;
+            if (rc == 2) rc = 1;
+          }
+        } else if (lay && device_text) {
           rc = fem_seqfile_fill_packed(f, plan, rd_threads, b->shape.max_len, (uint8_t *)b->bases, exc_cap, &b->n_exc, b->q_stage, b->n_stage,
                                        b->no_stage);
-        b->packed = rc == 0;
+          b->packed = rc == 0;
+        }
       }
       if (rc == 1)
         rc = device_text ? fem_seqfile_fill(f, plan, rd_threads, b->bases, b->off, b->q_stage, b->n_stage, b->no_stage)
