@@ -35,7 +35,7 @@ constexpr uint32_t kDenseNear = 1024u;         // entries of the 32-bit occurren
 constexpr uint32_t kDenseRemap = 0xF0000000u;  // ... as kDenseRemap | seq << 10 | pos (fem_seed_dense.hip.h)
 constexpr uint32_t kSelKeepAll = 1u << 15;  // in a last run's (start | frequency << 16) word: no truncation at max(U) in this bank
 constexpr uint32_t kSelOk = 0u, kSelNone = 1u, kSelSlow = 2u;  // sel_hdr[read].x & 3: joined / no candidates / generic kernel
-constexpr uint32_t kSelMaxCols = 64u;                          // DP columns a lane's take masks hold
+constexpr uint32_t kSelMaxCols = 128u;                         // DP columns a lane's take masks hold (1, 2 or 4 words per row)
 constexpr uint32_t kSelMaxList = 128u;                         // longest list seed_join_kernel takes (kDenseMaxList)
 constexpr uint32_t kX11 = 1u << 22;                            // number of 11-mers
 
@@ -101,12 +101,16 @@ __device__ __forceinline__ uint32_t rc_hash(uint32_t hf, uint32_t nm) {
 // seed; ncols = C - 1 of this lane's group (0: idle lane), maxcols = the largest in the wave.  Column c (0-based)
 // of row r (0-based) uses seed c + 4 r.  take[r] receives the take bits: column c at bit iters - 1 - c.
 // ---------------------------------------------------------------------------------------------------------
-template <int R, bool WIDE>
-__device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&tlo)[R],
-                                          uint32_t (&thi)[R], uint32_t &m_last, uint32_t &iters) {
+template <int R, int W>
+__device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&take)[R][W],
+                                          uint32_t &m_last, uint32_t &iters) {
   uint32_t M[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) M[r] = inf, tlo[r] = 0, thi[r] = 0;
+  for (int r = 0; r < R; ++r) {
+    M[r] = inf;
+#pragma unroll
+    for (int w = 0; w < W; ++w) take[r][w] = 0;
+  }
   for (uint32_t c = 0; c < maxcols; ++c) {
     uint32_t f[R];
 #pragma unroll
@@ -116,15 +120,29 @@ __device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uin
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t v = up + f[r];      // uint32 wrap as in the reference
-      const bool take = in && v < M[r];  // strict: ties go horizontal (src/filter.c:20); M[r][0] = inf (src/filter.c:9)
-      M[r] = take ? v : M[r];
+      const bool tk = in && v < M[r];    // strict: ties go horizontal (src/filter.c:20); M[r][0] = inf (src/filter.c:9)
+      M[r] = tk ? v : M[r];
       up = M[r];
-      if (WIDE) thi[r] = (thi[r] << 1) | (tlo[r] >> 31);
-      tlo[r] = (tlo[r] << 1) | (uint32_t)take;
+#pragma unroll
+      for (int w = W - 1; w > 0; --w) take[r][w] = (take[r][w] << 1) | (take[r][w - 1] >> 31);
+      take[r][0] = (take[r][0] << 1) | (uint32_t)tk;
     }
   }
   m_last = M[R - 1];
   iters = maxcols;
+}
+// lowest set bit at or above position `from` of a W-word mask (word 0 = bits 0..31); -1 if none
+template <int W>
+__device__ __forceinline__ int first_set_from(const uint32_t (&m)[W], uint32_t from) {
+  int best = -1;
+#pragma unroll
+  for (int w = W - 1; w >= 0; --w) {  // (high words first: the lowest hit is written last)
+    const uint32_t lo = 32u * (uint32_t)w;
+    uint32_t x = m[w];
+    if (from > lo) x = from - lo >= 32u ? 0u : x & (0xFFFFFFFFu << (from - lo));
+    if (x) best = (int)lo + __builtin_ctz(x);
+  }
+  return best;
 }
 
 #ifndef FEM_SELECT_WAVES
@@ -325,45 +343,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
 #pragma unroll
         for (int t = 0; t < R; ++t) key[t] = (uint32_t)t << 10;  // a seed that was never taken is all zero (see below)
         if (maxcols != 0) {
-          uint32_t tlo[R], thi[R], m_last = 0, iters = 0;
-          const bool wide = maxcols > 32u;  // (wave-uniform)
-          if (!wide)
-            select_dp<R, false>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
-          else
-            select_dp<R, true>(F, ncols, maxcols, inf, tlo, thi, m_last, iters);
-          if (valid) atomicAdd(&r_pre[i_c], m_last);  // M[R][C-1] (src/filter.c:202)
-          // ---- traceback (src/filter.c:30-41): row R first; the highest taken column at or below the previous one.
-          //      If column 0 is reached before R seeds were taken the reference's remaining seeds are uninitialised
-          //      (src/filter.c:33-41): all zero here, as in the oracle.  (Up to 32 columns — every BASELINE shape — the take
-          //      masks are one word: no 64-bit shifts.) ----
-          int col = (int)ncols - 1;
-          bool alive = valid;
-          auto traceback = [&](auto wide_c) {
+          // take masks of 1, 2 or 4 words per row: up to 32 columns (every BASELINE shape), 64, 128 (reads of ~450 bases at e = 3)
+          auto select_group = [&](auto words_c) {
+            constexpr int W = decltype(words_c)::value;
+            uint32_t take[R][W], m_last = 0, iters = 0;
+            select_dp<R, W>(F, ncols, maxcols, inf, take, m_last, iters);
+            if (valid) atomicAdd(&r_pre[i_c], m_last);  // M[R][C-1] (src/filter.c:202)
+            // ---- traceback (src/filter.c:30-41): row R first; the highest taken column at or below the previous one.
+            //      If column 0 is reached before R seeds were taken the reference's remaining seeds are uninitialised
+            //      (src/filter.c:33-41): all zero here, as in the oracle ----
+            int col = (int)ncols - 1;
+            bool alive = valid;
 #pragma unroll
             for (int r = R - 1; r >= 0; --r) {
               const int t = R - 1 - r;
               if (alive) {
                 const uint32_t shift = iters - 1u - (uint32_t)col;  // bits >= shift are the columns <= col
-                int step_back;
-                bool none;
-                if constexpr (decltype(wide_c)::value) {
-                  const uint64_t seg = ((((uint64_t)thi[r]) << 32) | tlo[r]) >> shift;
-                  none = seg == 0, step_back = __builtin_ctzll(seg);
-                } else {
-                  const uint32_t seg = tlo[r] >> shift;
-                  none = seg == 0, step_back = __builtin_ctz(seg);
-                }
-                if (none) {
+                const int at = first_set_from<W>(take[r], shift);
+                if (at < 0) {
                   alive = false;
                 } else {
-                  col -= step_back;
+                  col -= at - (int)shift;
                   const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
                   key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + times3(idx));  // (65 534 << 14 fits)
                 }
               }
             }
           };
-          if (!wide) traceback(std::false_type{}); else traceback(std::true_type{});
+          if (maxcols <= 32u) select_group(std::integral_constant<int, 1>{});
+          else if (maxcols <= 64u) select_group(std::integral_constant<int, 2>{});
+          else select_group(std::integral_constant<int, 4>{});
         }
         // ---- qsort(compare_seed) (src/filter.c:204): ascending frequency, stable (glibc's merge sort):
         //      the traceback order in the key breaks ties, so any sorting network gives the stable order ----

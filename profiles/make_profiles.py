@@ -1,7 +1,10 @@
 """Regenerates the rocprofv3 summaries under profiles/ (run on the GPU box, from the repo root):
 
-    python3 profiles/make_profiles.py calib       # -> profiles/r03_fetch_calibration.json
-    python3 profiles/make_profiles.py c3          # -> profiles/r03_c3_kernel_stats.csv, r03_c3_kernel_times.json, r03_c3_hbm_traffic.json
+    python3 profiles/make_profiles.py calib       # -> profiles/r04_fetch_calibration.json
+    python3 profiles/make_profiles.py c3          # -> profiles/r04_c3_kernel_stats.csv, r04_c3_kernel_times.json, r04_c3_hbm_traffic.json
+
+Every file carries `git_head` and `kernel_sources_sha16` (bench.kernel_sources_sha16: a hash of fem_amd/csrc/*.hip*): bench.py
+takes `roofline.traffic` from a profile only if the hash is that of the sources it runs on.
 
 The command profiled for a workload is the RESIDENT REPLAY of bench.py (`--profile-replay 20`): the four slots' batches
 are staged once, then nothing but kernels run (no copies in flight: under rocprofv3 every copy is a
@@ -21,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("FEM_PROFILE_ROUND", "r03")
+ROUND = os.environ.get("FEM_PROFILE_ROUND", "r04")
 PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slots: one per pass
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
@@ -31,6 +34,16 @@ PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slot
 ]
 KERNELS = ("seed_select_kernel", "seed_join_kernel", "seed_fast_kernel", "seed_filter_kernel", "verify_kernel",
            "calib_runs", "calib_gather", "calib_pairs")
+
+
+def stamp():
+    sys.path.insert(0, ROOT)
+    import bench
+    try:
+        head = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        head = os.environ.get("FEM_GIT_HEAD", "unknown (the GPU box gets a snapshot without .git; FEM_GIT_HEAD names it)")
+    return {"git_head": head, "kernel_sources_sha16": bench.kernel_sources_sha16()}
 
 
 def run(cmd, log, timeout=600):
@@ -84,8 +97,8 @@ def calibrate():
             for c, v in cs.items():
                 got.setdefault(k, {})[c] = v[-1]  # the second launch (caches warm for the tables)
     known = json.loads("".join(l for l in open(os.path.join(out, "pmc0.log")) if l.lstrip().startswith(("{", '"'))))
-    res = {"what": "FETCH_SIZE of rocprofv3 (KiB) against known byte counts, profiles/fetch_calibration.hip; second launch of each kernel",
-           "known": known, "measured": got, "ratios": {}}
+    res = dict(stamp(), what="FETCH_SIZE of rocprofv3 (KiB) against known byte counts, profiles/fetch_calibration.hip; second launch of each kernel",
+               known=known, measured=got, ratios={})
     if "calib_runs" in got and "FETCH_SIZE" in got["calib_runs"]:
         f = got["calib_runs"]["FETCH_SIZE"] * 1024.0
         r = known["runs"]
@@ -123,7 +136,7 @@ def workload(wl):
         k = short_name(r["Kernel_Name"])
         if k:
             per.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    times = {"command": note, "bench": bench_out, "kernels": {}}
+    times = dict(stamp(), command=note, bench=bench_out, kernels={})
     for k, v in per.items():
         timed = v[warm:] if len(v) > warm else v
         ev = bench_out.get("event_times", {}).get(k, {})
@@ -157,7 +170,8 @@ def workload(wl):
         cs["fetch_factor"] = factor
         cs["fetch_factor_from"] = why
         cs["hbm_bytes_per_launch"] = cs["FETCH_SIZE"]["mean_per_launch"] * 1024.0 * factor + cs.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) * 1024.0
-    summary = {
+    summary = dict(stamp())
+    summary.update({
         "command": note + "  (one rocprofv3 --pmc pass per counter group with --profile-replay 6; the durations come from a separate "
                    "--kernel-trace --stats pass, profiles/%s_%s_kernel_stats.csv and _kernel_times.json)" % (ROUND, wl),
         "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch as rocprofv3 reports them; hbm_bytes_per_launch = FETCH_SIZE x fetch_factor "
@@ -166,7 +180,7 @@ def workload(wl):
         "reads_per_launch": int(bench_out.get("reads_per_launch", 0)),
         "counter_groups": PMC_GROUPS,
         "kernels": kernels,
-    }
+    })
     with open(os.path.join(ROOT, "profiles", "%s_%s_hbm_traffic.json" % (ROUND, wl)), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps({k: {"trace_ms": round(v["trace_mean_ms_timed"], 3), "event_ms": v["event_mean_ms"]} for k, v in times["kernels"].items()}))

@@ -87,7 +87,10 @@ def test_hash_join_form_as_selected(mid, e, L, n):
     assert launches >= 1
 
 
-@pytest.mark.parametrize("e,L,n", [(3, 100, 5000), (7, 150, 2500), (5, 125, 1500), (3, 100, 33), (2, 64, 700)])
+@pytest.mark.parametrize("e,L,n", [(3, 100, 5000), (7, 150, 2500), (5, 125, 1500), (3, 100, 33), (2, 64, 700),
+                                   # DP tables of 33-64 and 65-128 columns (take masks of two and four words per row), and beyond
+                                   # what the selection kernel takes (the generic kernel finishes those reads)
+                                   (3, 200, 1200), (3, 300, 1200), (1, 400, 600), (5, 330, 700), (3, 470, 500), (2, 600, 300)])
 def test_dense_form_as_selected(dense, e, L, n):
     _compare(dense, 720 + e, n, L, e, extra=_edge_reads(dense, L))
 
