@@ -201,6 +201,8 @@ struct fem_dev {
   uint32_t *d_summary = nullptr;  // bucket summaries (femk::SeedParams::summary), built for sparse indexes only
   // dense indexes: occurrence table in 32-bit global coordinates + its sequence tables (fem_seed_dense.hip.h)
   uint32_t *d_occ32 = nullptr, *d_goff = nullptr, *d_blkseq = nullptr;
+  uint32_t list_shift = 0;        // != 0: d_occ32 is the strided table (bucket h at h << list_shift, fem_seed_dense.hip.h); 0: compact
+  bool no_strided = false;        // FEM_NO_STRIDED=1: keep the compact 32-bit table (test hook / A-B)
   uint32_t *d_freq11 = nullptr;  // saturated byte frequencies per 11-mer (fem_seed_select.hip.h), 64 MiB
   // banks of sequences, each with 32-bit coordinates of its own (fem_seed_dense.hip.h); 1 = the whole reference in one
   uint32_t n_banks = 1, bank_first[5] = {0, 0, 0, 0, 0};
@@ -250,8 +252,8 @@ namespace {
 // Test / measurement switches of the library are read only when FEM_TESTING=1 (tests/conftest.py sets it): a production
 // process does not steer kernels through its environment.
 bool testing_switch(const char *name) {
-  static const bool testing = [] { const char *v = getenv("FEM_TESTING"); return v && v[0] == '1'; }();
-  if (!testing) return false;
+  const char *t = getenv("FEM_TESTING");  // (read every time: a process may open a plain handle first and a test handle later)
+  if (!(t && t[0] == '1')) return false;
   const char *v = getenv(name);
   return v && v[0] == '1';
 }
@@ -727,7 +729,7 @@ int launch_batch(fem_dev *h, Slot &s) {
       if ((rc = dev_realloc(h, &s.d_sel, &s.sel_cap, want_sel))) return rc;
       if ((rc = dev_realloc(h, &s.d_sel_hdr, &s.sel_hdr_cap, (size_t)s.n_reads))) return rc;
       femk::SeedParams fp = sp;
-      fp.occ32 = h->d_occ32, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
+      fp.occ32 = h->d_occ32, fp.list_shift = h->list_shift, fp.goff = h->d_goff, fp.blkseq = h->d_blkseq;
       fp.freq11 = h->d_freq11, fp.sel = s.d_sel, fp.sel_hdr = s.d_sel_hdr;
       fp.n_banks = h->n_banks, fp.bank_lo = h->d_bank_lo, fp.n_buckets = (uint32_t)(h->n_lookup - 1);
       fp.blk_stride = (femk::kDenseRemap >> femk::kDenseBlkShift) + 1u;
@@ -879,7 +881,7 @@ int refresh_dense(fem_dev *h) {
   for (void *p : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)h->d_bank_lo})
     if (p) (void)hipFree(p);
   h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr, h->d_bank_lo = nullptr;
-  h->n_banks = 1;
+  h->n_banks = 1, h->list_shift = 0;
   if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
   const uint64_t n_buckets = h->n_lookup - 1;
   if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
@@ -928,13 +930,26 @@ int refresh_dense(fem_dev *h) {
     for (void *q : {(void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq, (void *)h->d_freq11, (void *)h->d_bank_lo, (void *)d_bad})
       if (q) (void)hipFree(q);
     h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr, h->d_bank_lo = nullptr;
-    h->n_banks = 1;
+    h->n_banks = 1, h->list_shift = 0;
     (void)hipGetLastError();  // (clears the out-of-memory error)
     return FEM_OK;
   };
+  // One coordinate space: the STRIDED 32-bit table (fem_seed_dense.hip.h: 512 bytes per bucket, lists on line boundaries, found
+  // by the hash alone).  Where it does not fit, and for references in banks (whose lists are cut at bank_lo), the compact one.
+  uint32_t list_shift = 0;
+  if (n_banks == 1 && !h->no_strided) {
+    const size_t words = ((size_t)n_buckets << femk::kDenseListShift) + 256;
+    if (hipMalloc((void **)&h->d_occ32, words * sizeof(uint32_t)) == hipSuccess && hipMemset(h->d_occ32, 0, words * sizeof(uint32_t)) == hipSuccess) {
+      list_shift = femk::kDenseListShift;
+    } else {
+      if (h->d_occ32) (void)hipFree(h->d_occ32);
+      h->d_occ32 = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   if (hipMalloc((void **)&h->d_goff, goff.size() * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void **)&h->d_blkseq, blkseq.size() * sizeof(uint32_t)) != hipSuccess ||
-      hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)) != hipSuccess ||
+      (!list_shift && hipMalloc((void **)&h->d_occ32, (h->n_occ + 256) * sizeof(uint32_t)) != hipSuccess) ||
       hipMalloc((void **)&h->d_freq11, (size_t)femk::kX11 * 4u * sizeof(uint32_t)) != hipSuccess ||
       (n_banks > 1 && hipMalloc((void **)&h->d_bank_lo, (size_t)(n_banks - 1) * n_buckets * sizeof(uint32_t)) != hipSuccess) ||
       hipMalloc((void **)&d_bad, sizeof(uint32_t)) != hipSuccess)
@@ -948,8 +963,12 @@ int refresh_dense(fem_dev *h) {
   femk::BankFirst bf{};
   bf.n = n_banks;
   for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) bf.first[b] = bank_first[b];
-  hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq, bf,
-                     h->d_occ32, d_bad);
+  if (list_shift)
+    hipLaunchKernelGGL(femk::dense_occ32_strided_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->d_lookup, (uint32_t)n_buckets, h->d_goff,
+                       h->n_seq, h->d_occ32, d_bad);
+  else
+    hipLaunchKernelGGL(femk::dense_occ32_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->n_occ, h->d_goff, h->n_seq, bf,
+                       h->d_occ32, d_bad);
   uint32_t bad = 0;
   if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) {
     (void)decline();
@@ -961,7 +980,7 @@ int refresh_dense(fem_dev *h) {
   for (uint32_t b = 1; b < n_banks; ++b)  // where bank b's part of every list starts
     hipLaunchKernelGGL(femk::bank_split_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_occ, h->d_lookup, (uint32_t)n_buckets, bank_first[b],
                        h->d_bank_lo + (size_t)(b - 1) * n_buckets);
-  h->n_banks = n_banks;
+  h->n_banks = n_banks, h->list_shift = list_shift;
   for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) h->bank_first[b] = bank_first[b];
   // byte frequencies per 11-mer for seed_select_kernel (fem_seed_select.hip.h)
   hipLaunchKernelGGL(femk::freq11_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_lookup, h->d_freq11);
@@ -1093,6 +1112,7 @@ int fem_dev_open(int device, fem_dev **out) {
     h->force_hash = testing_switch("FEM_FORCE_HASH");
     h->force_dense = testing_switch("FEM_FORCE_DENSE");
     h->no_dense = testing_switch("FEM_NO_DENSE");
+    h->no_strided = testing_switch("FEM_NO_STRIDED");
     h->tiny_buffers = testing_switch("FEM_TEST_TINY_BUFFERS");
     if (const char *bl = getenv("FEM_TEST_BANK_BASES")) h->bank_limit = strtoull(bl, nullptr, 10);
     if (const char *bs = getenv("FEM_TEST_BANK_SEQS")) h->bank_seqs = (uint32_t)strtoul(bs, nullptr, 10);

@@ -84,6 +84,9 @@ struct SeedParams {
   // seed_join_kernel (fem_seed_dense.hip.h): the occurrence table in 32-bit global coordinates, the coordinate of
   // each sequence's first base (n_seq + 1 entries) and, per 2^20 coordinates, the last sequence starting at or before
   const uint32_t *occ32;
+  // != 0: occ32 is the STRIDED table — bucket h's first (up to) 2^list_shift entries at occ32[h << list_shift], every list on a
+  // line boundary, no lookup[h] to find it (fem_seed_dense.hip.h); 0: the compact table, bucket h's list at occ32[lookup[h]]
+  uint32_t list_shift;
   const uint32_t *goff;
   const uint32_t *blkseq;
   // seed_select_kernel -> seed_join_kernel (fem_seed_select.hip.h): saturated byte frequencies per 11-mer; per read and

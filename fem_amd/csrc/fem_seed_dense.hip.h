@@ -75,6 +75,48 @@ __global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32
   }
 }
 
+// THE STRIDED TABLE (round 4; references in one coordinate space): bucket h's first (up to) kDenseMaxList entries at
+// out[h * kDenseMaxList ...] in the same 32-bit coordinates — 512 bytes per bucket, 8.6 GB at k = 12 whatever the reference
+// (the compact table is 4 bytes per entry: 4 GB at 3 Gbp) out of 288 GB.  What it buys: a list starts on a 128-byte line
+// (60 entries: two fabric requests instead of 2.56 on average) and the selection finds it by the hash alone — no lookup[h]
+// read for the 6 R selected seeds of a read (30 of its 76 L2 misses).  seed_join_kernel does not know the difference: it is
+// handed occ32 = this table and list bases h << 7.  Entries beyond the 128th are not stored: such a read goes to the generic
+// kernel (which reads the 64-bit table) as before.  Blocks of 256 buckets: their entries are one contiguous stretch of occ.
+constexpr uint32_t kDenseListShift = 7;
+static_assert((1u << kDenseListShift) == kDenseMaxList, "a strided slot holds exactly the lists the join takes");
+__global__ void __launch_bounds__(256) dense_occ32_strided_kernel(const uint64_t *occ, const uint32_t *lookup, uint32_t n_buckets, const uint32_t *goff,
+                                                                  uint32_t n_seq, uint32_t *out, uint32_t *bad) {
+  __shared__ uint32_t lk[257];
+  for (uint32_t h0 = blockIdx.x * 256u; h0 < n_buckets; h0 += gridDim.x * 256u) {
+    const uint32_t nb = n_buckets - h0 < 256u ? n_buckets - h0 : 256u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= nb; i += 256u) lk[i] = lookup[h0 + i];
+    __syncthreads();
+    const uint32_t lo = lk[0], hi = lk[nb];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) {
+      uint32_t a = 0, b = nb;  // the bucket of entry i: the last one whose list starts at or before i
+      while (b - a > 1u) {
+        const uint32_t m = (a + b) >> 1;
+        if (lk[m] <= i) a = m; else b = m;
+      }
+      const uint32_t rank = i - lk[a];
+      if (rank >= kDenseMaxList) continue;
+      const uint64_t o = occ[i];
+      const uint32_t seq = (uint32_t)(o >> 32), pos = (uint32_t)o;
+      uint32_t v;
+      if (seq >= n_seq) {
+        v = kDenseSent;
+        *bad = 1u;
+      } else if (pos < kDenseNear) {
+        v = kDenseRemap | (seq << 10) | pos;
+      } else {
+        v = goff[seq] + pos;
+      }
+      out[((size_t)(h0 + a) << kDenseListShift) + rank] = v;
+    }
+  }
+}
+
 // out[h] = index in occ of bucket h's first entry whose sequence is >= first_seq (lookup[h + 1] if none): where the
 // bank starting at that sequence begins in the list.  One thread per bucket, binary search (the list ascends).
 __global__ void bank_split_kernel(const uint64_t *occ, const uint32_t *lookup, uint32_t n_buckets, uint32_t first_seq, uint32_t *out) {

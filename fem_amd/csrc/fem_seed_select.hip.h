@@ -398,7 +398,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
               const uint32_t hf = stream_window(fw, base + j) >> 8;
               uint32_t h = hf;
               if (strand) h = rc_hash(hf, has_n ? stream_window(nw, base + j) >> 8 : 0u);
-              lo[t] = p.lookup[h], hs[t] = h;
+              // where the seed's list starts: by the hash alone in the strided table (no read), lookup[h] in the compact one
+              lo[t] = !BANKED && p.list_shift ? h << p.list_shift : p.lookup[h], hs[t] = h;
             }
             too_long |= f > kSelMaxList;
           }

@@ -8,7 +8,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fast+generic", "hash+generic", "dense+generic", "generic-only", "tiny-buffers",
+@pytest.fixture(scope="module", params=["fast+generic", "hash+generic", "dense+generic", "dense-compact+generic", "generic-only", "tiny-buffers",
                                         "tiny-buffers+hash", "tiny-buffers+dense"])
 def dev(request):
     # The library picks the seed kernel by itself: seed_fast_kernel<R, false> (lists in lanes) for sparse
@@ -20,6 +20,8 @@ def dev(request):
     os.environ["FEM_FORCE_GENERIC"] = "1" if request.param == "generic-only" else "0"
     os.environ["FEM_FORCE_HASH"] = "1" if "hash" in request.param else "0"
     os.environ["FEM_FORCE_DENSE"] = "1" if "dense" in request.param else "0"
+    # "dense-compact": the compact 32-bit occurrence table (lists at lookup[h]) instead of the strided one (lists at h << 7)
+    os.environ["FEM_NO_STRIDED"] = "1" if "compact" in request.param else "0"
     # "tiny-buffers": candidate arrays, slow-read queue and arena start far too small, so every fixture goes through
     # the overflow flags, the growth of the buffers and the re-run of the batch in fem_dev_sync
     os.environ["FEM_TEST_TINY_BUFFERS"] = "1" if "tiny" in request.param else "0"
@@ -27,6 +29,7 @@ def dev(request):
     os.environ.pop("FEM_FORCE_GENERIC")
     os.environ.pop("FEM_FORCE_HASH")
     os.environ.pop("FEM_FORCE_DENSE")
+    os.environ.pop("FEM_NO_STRIDED")
     os.environ.pop("FEM_TEST_TINY_BUFFERS")
     yield d
     d.close()
