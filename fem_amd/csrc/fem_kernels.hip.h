@@ -26,6 +26,7 @@ constexpr uint32_t kFlagTooLarge = 4u;       // a single group exceeds 2^31 entr
 constexpr uint32_t kInvalidMeta = 0xFFFFFFFFu;  // padding slot in the candidate arrays (skipped by verify_kernel)
 // bit 31 of a candidate's meta word: it belongs to a full group of 8 of its (read, strand) list, which the reference
 // sends through the 16-bit SSE lanes (src/align.c:12-13); batches hold < 2^30 reads, so the bit is free
+constexpr int kMaxR = 10;  // e <= 7, a <= 2
 constexpr uint32_t kMeta16 = 0x80000000u;
 constexpr uint32_t kSlotChunk = 256u;           // candidate slots a wave reserves per atomic on the shared cursor
 constexpr uint32_t kFlagQueueOverflow = 8u;     // slow-read queue too small
@@ -422,6 +423,167 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
   return nA;
 }
 
+// ---------------------------------------------------------------------------
+// The same for a strand whose lists went to the global arena (they did not fit the wave's LDS: repeats, where a seed has
+// hundreds of occurrences and a strand hundreds of candidates).  Same results as strand_lists<true>, organised so that
+// nothing walks a long list with one lane (round 4: a read of a 1000-copy repeat cost ~1.2 ms of a wave):
+//   * the staged runs are merged ONCE into sorted order (rank of an element = its place in its run + R - 1 binary
+//     searches; ties by run, then by place: the order of the reference's merges, src/filter.c:91-110) — the
+//     additional-q-gram filter is then what the reference states, x[i + a] <= x[i] + e on the sorted multiset
+//     (src/filter.c:118-131), and its survivors come out sorted: no second round of searches;
+//   * merge_kvec_t_uint64_t's greedy pass (src/filter.c:45-78; keep x iff x > last kept + e) by CHAINS: in the merged
+//     order an element more than e above its predecessor is kept whatever came before (last kept <= predecessor) and
+//     starts a chain; only inside a chain — consecutive gaps <= e — does the rule look back, and the chain's first
+//     lane walks it.  Chains are a handful of elements (the values of one place's seeds), so all lanes work.
+// Buffers (arena slices of the caller): X, F >= the group's staged entries, A, B >= all groups' entries.
+// ---------------------------------------------------------------------------
+__device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, uint32_t *rb, const Bufs &b, uint64_t **result, Prof &prof) {
+  const uint32_t ln = lane_id();
+  const uint64_t lt_mask = (1ull << ln) - 1ull;
+  const int R = p.R;
+  const uint64_t e64 = (uint64_t)p.e;
+  uint64_t *A = b.A, *B = b.B;
+  uint32_t nA = 0;
+  for (int si = 0; si < p.step; ++si) {
+    const Picked *pk = picked + si * R;
+    // ---- stage the R shifted runs (as strand_lists) ----
+    uint32_t n = 0;
+    bool too_big = false;
+    if (ln == 0) rb[0] = 0;
+    for (int t = 0; t < R; ++t) {
+      const uint32_t start = pk[t].start, lo = pk[t].lo, freq = pk[t].freq;
+      uint64_t max_u = 0;
+      const bool last = (t == R - 1);
+      if (last) {  // the last seed is merged only while the list has elements, and only up to its maximum (src/filter.c:85)
+        if (n == 0) {
+          if (ln == 0) rb[t + 1] = n;
+          continue;
+        }
+        wave_sync_global();
+        for (int u = 0; u < R - 1; ++u) {
+          const uint32_t hi_ = rb[u + 1], lo_ = rb[u];
+          if (hi_ > lo_ && hi_ <= b.xcap) {
+            const uint64_t v = b.X[hi_ - 1];
+            max_u = v > max_u ? v : max_u;
+          }
+        }
+      }
+      for (uint32_t i0 = 0; i0 < freq; i0 += kWave) {
+        const uint32_t i = i0 + ln;
+        bool ok = i < freq;
+        uint64_t v = 0;
+        if (ok) {
+          const uint64_t o = p.occ[(uint64_t)lo + i];
+          ok = (uint32_t)o >= start;  // src/filter.c:89,106
+          v = o - start;
+          if (last) ok = ok && (v <= max_u);
+        }
+        const uint64_t m = __ballot(ok);
+        const uint32_t pos = n + __popcll(m & lt_mask);
+        if (ok && pos < b.xcap) b.X[pos] = v;
+        n += __popcll(m);
+        if (n > 0x7fffffffu) too_big = true;
+      }
+      if (ln == 0) rb[t + 1] = n;
+    }
+    if (too_big) return 0xFFFFFFFEu;
+    if (n > b.xcap || n > b.fcap) return 0xFFFFFFFFu;
+    STAMP(prof, 4);
+    if (n <= (uint32_t)p.a) continue;  // fewer than a + 1 values: nothing passes the filter
+    wave_sync_global();
+    // ---- the merged order: F[rank] = value.  (The R - 1 binary searches of an element in lockstep — one probe of every
+    //      other run per round — were tried: the arrays cost more registers than the overlapped loads gave, 26.6 -> 32.6 ms
+    //      per 50 k repeat reads.) ----
+    for (int t = 0; t < R; ++t) {
+      const uint32_t r_lo = rb[t], r_hi = rb[t + 1];
+      for (uint32_t i0 = r_lo; i0 < r_hi; i0 += kWave) {
+        const uint32_t i = i0 + ln;
+        if (i < r_hi) {
+          const uint64_t v = b.X[i];
+          uint32_t rank = i - r_lo;
+          for (int u = 0; u < R; ++u) {
+            const uint32_t u_lo = rb[u], u_hi = rb[u + 1];
+            if (u == t || u_lo == u_hi) continue;
+            const uint32_t j = (u < t) ? upper_bound_u64(b.X, u_lo, u_hi, v) : lower_bound_u64(b.X, u_lo, u_hi, v);
+            rank += j - u_lo;
+          }
+          b.F[rank] = v;
+        }
+      }
+    }
+    wave_sync_global();
+    // ---- additional_qgram_filter on the sorted multiset (src/filter.c:118-131): survivors, still sorted, back into X ----
+    uint32_t nF = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += kWave) {
+      const uint32_t k = k0 + ln;
+      bool pass = false;
+      uint64_t v = 0;
+      if (k + (uint32_t)p.a < n) {
+        v = b.F[k];
+        pass = b.F[k + (uint32_t)p.a] <= v + e64;
+      }
+      const uint64_t m = __ballot(pass);
+      if (pass) b.X[nF + __popcll(m & lt_mask)] = v;
+      nF += __popcll(m);
+    }
+    STAMP(prof, 5);
+    if (nF == 0) continue;  // greedy(merge(cand, {})) == cand
+    wave_sync_global();
+    // ---- merge with the candidates so far (A first unless X is smaller or equal: src/filter.c:52-60) into B ----
+    const uint32_t nM = nA + nF;
+    if (nM > b.ccap) return 0xFFFFFFFFu;
+    for (uint32_t i0 = 0; i0 < nA; i0 += kWave) {
+      const uint32_t i = i0 + ln;
+      if (i < nA) {
+        const uint64_t v = A[i];
+        B[i + upper_bound_u64(b.X, 0u, nF, v)] = v;  // (an equal value of X goes first)
+      }
+    }
+    for (uint32_t j0 = 0; j0 < nF; j0 += kWave) {
+      const uint32_t j = j0 + ln;
+      if (j < nF) {
+        const uint64_t v = b.X[j];
+        B[j + lower_bound_u64(A, 0u, nA, v)] = v;
+      }
+    }
+    wave_sync_global();
+    // ---- the greedy pass by chains; the keep flags are bytes over F (dead by now: 8 (fcap) >= 3 fcap >= nM bytes) ----
+    uint8_t *keep = (uint8_t *)b.F;
+    for (uint32_t k0 = 0; k0 < nM; k0 += kWave) {
+      const uint32_t k = k0 + ln;
+      if (k < nM) {
+        const uint64_t v = B[k];
+        if (k == 0 || v - B[k - 1] > e64) {  // a chain starts here: kept, and this lane walks it
+          keep[k] = 1;
+          uint64_t last = v, cur = v;
+          for (uint32_t j = k + 1; j < nM; ++j) {
+            const uint64_t nx = B[j];
+            if (nx - cur > e64) break;  // (the next chain's first element: its own lane's)
+            const bool kp = nx > last + e64;
+            keep[j] = kp ? 1 : 0;
+            last = kp ? nx : last;
+            cur = nx;
+          }
+        }
+      }
+    }
+    wave_sync_global();
+    uint32_t nB = 0;
+    for (uint32_t k0 = 0; k0 < nM; k0 += kWave) {
+      const uint32_t k = k0 + ln;
+      const bool kp = k < nM && keep[k] != 0;
+      const uint64_t m = __ballot(kp);
+      if (kp) A[nB + __popcll(m & lt_mask)] = B[k];  // (A's old content lives on in B)
+      nB += __popcll(m);
+    }
+    nA = nB;
+    wave_sync_global();
+    STAMP(prof, 6);
+  }
+  *result = A;
+  return nA;
+}
+
 // Candidate slots are handed out from one global cursor.  One returning atomic per (read, strand) on a single
 // address tops out near 90 M/s on this chip, so each wave reserves kSlotChunk slots at a time and fills them
 // locally; what is left of a chunk when the wave moves on is padded with kInvalidMeta.
@@ -670,7 +832,6 @@ __device__ bool strand_small(const SeedParams &p, const Picked *pk /* [step][R] 
 // rank sort; otherwise the caller uses the one-lane-per-group form.
 // Returns M[R][C-1] of group ln (lanes < 2*step).
 // ---------------------------------------------------------------------------
-constexpr int kMaxR = 10;  // e <= 7, a <= 2
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_min_step(uint32_t x, uint32_t inf) {
@@ -1043,7 +1204,7 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
           g.B = g.A + pre_wide + 2;
           g.xcap = pre_max + 1u, g.fcap = pre_max + 1u;
           g.ccap = pre_wide > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pre_wide + 1u;
-          uint32_t n2 = strand_lists<true>(p, pk, rb, g, &list, prof);
+          uint32_t n2 = strand_lists_big(p, pk, rb, g, &list, prof);
           if (n2 < 0xFFFFFFFEu) {
             clip_and_emit<true>(p, read, strand, L, list, n2, list == g.A ? g.B : g.A, cand_sum, chunk);
           } else {
