@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include <malloc.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 
 #include <algorithm>
@@ -261,7 +262,11 @@ int map_main(int argc, char **argv) {
   char *ref_path = nullptr, *index_path = nullptr, *read_path = nullptr, *out_path = nullptr;
   fem_params params{12, 3, 2, 1};  // src/FEM_map.c:67-70: k and step are fixed, whatever the index header says
   int n_threads = 1, n_gpus = 1;
-  uint64_t batch_reads = 250000;  // (8 M reads, FASTQ -> SAM: 250 k per batch 17-22 Mreads/s, 1 M per batch 9-14: the pipeline fills sooner)
+  // reads per batch: 250 k fills the pipeline soonest on small inputs; a batch costs three host round trips on its way through
+  // the tail, which 1 M-read batches amortise on large ones (16 M reads of C2 to /dev/null: 105 -> 116 Mreads/s, 8 M of C3:
+  // 71 -> 81; round 4) — chosen by the size of the read file unless --batch says otherwise
+  uint64_t batch_reads = 250000;
+  bool batch_given = false;
   const char *short_opt = "ha:f:e:t:o:r:i:b:";
   static struct option long_opt[] = {{"help", no_argument, nullptr, 'h'},       {"ref", required_argument, nullptr, 'r'},
                                      {"index", required_argument, nullptr, 'i'}, {"read1", required_argument, nullptr, 'b'},
@@ -277,7 +282,7 @@ int map_main(int argc, char **argv) {
       case 't': n_threads = atoi(optarg); break;
       case 'a': params.a = atoi(optarg); break;
       case 'G': n_gpus = atoi(optarg); break;
-      case 'B': batch_reads = strtoull(optarg, nullptr, 10); break;
+      case 'B': batch_reads = strtoull(optarg, nullptr, 10), batch_given = true; break;
       case 'f':
         if (strcmp(optarg, "v") != 0 && strcmp(optarg, "g") != 0) {  // parsed and ignored (src/FEM_map.c:108-118)
           fprintf(stderr, "%s\n", "Wrong name of seeding algorithm!");
@@ -347,6 +352,10 @@ int map_main(int argc, char **argv) {
   // fem_dev_commit_stage_packed: no host work per base beyond the parse itself) (FEM_PACK_BASES=0: always as characters).
   const char *pk = getenv("FEM_PACK_BASES");
   const bool pack_bases = !host_tail && !(pk && pk[0] == '0');
+  if (!batch_given) {
+    struct stat st;
+    if (stat(read_path, &st) == 0 && st.st_size >= (off_t)(1ll << 30)) batch_reads = 1000000;  // (plain FASTQ of >= ~4 M reads)
+  }
   const uint64_t batch_bytes = batch_reads * 250ull;  // header + bases + '+' + qualities of a ~100 bp record
   // a FASTQ window of batch_bytes characters holds fewer than batch_bytes / 2 bases; records under 32 bytes are unusual
   // (the reader asks for larger buffers when a batch needs them)
@@ -568,7 +577,7 @@ int map_main(int argc, char **argv) {
       // of the next one (FEM_LINGER_US).
       double linger = 300e-6;
       if (const char *lg = getenv("FEM_LINGER_US")) linger = std::max(0, atoi(lg)) * 1e-6;
-      size_t max_flight = 2;
+      size_t max_flight = 3;  // (2 until round 4; with 1 M-read batches a third in flight is worth 1-2 %)
       if (const char *fl = getenv("FEM_FLIGHT")) max_flight = (size_t)std::max(1, std::min(n_slots - 1, atoi(fl)));
       auto retire = [&] {
         BatchBuf *b = flight.front();
