@@ -46,10 +46,12 @@ namespace femk {
 #define FEM_JOIN_OPT_HI 12
 #endif
 constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
-// Chunks whose LDS steps are issued together at R >= 7 (see join_read): one — with the 80 registers of six waves per SIMD
-// five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134)
+// Chunks whose LDS steps are issued together at R >= 7 (see join_read).  Round 3: one — with the 80 registers of six waves per
+// SIMD five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134).  Round 4,
+// after the diet freed registers: three fit the same 80 (C5 join, ms per 2.5 M reads: 1: 13.66, 2: 13.63, 3: 13.44, 4: 13.45,
+// 5: 13.48, 9: 13.75).
 #ifndef FEM_JOIN_BATCH_HI
-#define FEM_JOIN_BATCH_HI 1
+#define FEM_JOIN_BATCH_HI 3
 #endif
 
 constexpr uint32_t join_bitmap_words(int R) { return join_slots(R) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
