@@ -423,6 +423,23 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
   return nA;
 }
 
+// Two-level search in a sorted stretch x[lo, hi) of the global arena whose every 2^sh-th element (x[lo + (k << sh)], k < cnt)
+// is kept in LDS as s[k]: the sample decides the piece, the piece is at most 2^sh elements of one or two cache lines.
+// (A plain binary search over 1 000 arena entries is ten dependent L2 round trips per element.)
+template <bool UPPER>
+__device__ __forceinline__ uint32_t sampled_bound_u64(const uint64_t *x, uint32_t lo, uint32_t hi, const uint64_t *s, uint32_t cnt, uint32_t sh,
+                                                      uint64_t key) {
+  const uint32_t k = UPPER ? upper_bound_u64(s, 0u, cnt, key) : lower_bound_u64(s, 0u, cnt, key);
+  if (k == 0) return lo;  // x[lo] itself is beyond the key (or the stretch is empty)
+  const uint32_t lo2 = lo + ((k - 1u) << sh) + 1u, end = lo + (k << sh);
+  const uint32_t hi2 = end < hi ? end : hi;
+  return UPPER ? upper_bound_u64(x, lo2, hi2, key) : lower_bound_u64(x, lo2, hi2, key);
+}
+#ifndef FEM_SAMPLE_MIN
+#define FEM_SAMPLE_MIN 256u
+#endif
+constexpr uint32_t kSampleMin = FEM_SAMPLE_MIN;  // stretches shorter than this are searched plainly (tests build it with 4)
+
 // ---------------------------------------------------------------------------
 // The same for a strand whose lists went to the global arena (they did not fit the wave's LDS: repeats, where a seed has
 // hundreds of occurrences and a strand hundreds of candidates).  Same results as strand_lists<true>, organised so that
@@ -435,10 +452,15 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
 //     order an element more than e above its predecessor is kept whatever came before (last kept <= predecessor) and
 //     starts a chain; only inside a chain — consecutive gaps <= e — does the rule look back, and the chain's first
 //     lane walks it.  Chains are a handful of elements (the values of one place's seeds), so all lanes work.
+//   * every binary search goes through an LDS sample of the stretch it searches (sampled_bound_u64): `smp` is the wave's
+//     LDS list space, unused on this path (smp_cap 64-bit entries).
 // Buffers (arena slices of the caller): X, F >= the group's staged entries, A, B >= all groups' entries.
 // ---------------------------------------------------------------------------
-__device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, uint32_t *rb, const Bufs &b, uint64_t **result, Prof &prof) {
+__device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, uint32_t *rb, const Bufs &b, uint64_t *smp, uint32_t smp_cap,
+                                     uint64_t **result, Prof &prof) {
   const uint32_t ln = lane_id();
+  const uint32_t cap_s = smp_cap > 64u ? smp_cap - 16u : 0u;  // samples; behind them the runs' sample offsets (kMaxR + 1 words)
+  uint32_t *s_off = (uint32_t *)(smp + cap_s);
   const uint64_t lt_mask = (1ull << ln) - 1ull;
   const int R = p.R;
   const uint64_t e64 = (uint64_t)p.e;
@@ -494,6 +516,26 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
     // ---- the merged order: F[rank] = value.  (The R - 1 binary searches of an element in lockstep — one probe of every
     //      other run per round — were tried: the arrays cost more registers than the overlapped loads gave, 26.6 -> 32.6 ms
     //      per 50 k repeat reads.) ----
+    const bool sampled = n >= kSampleMin && cap_s != 0u;
+    uint32_t sh = 2;
+    if (sampled) {  // every 2^sh-th element of every run into LDS: at most (n >> sh) + R samples
+      while ((n >> sh) + (uint32_t)R > cap_s) ++sh;
+      if (ln == 0) {
+        uint32_t o = 0;
+        for (int t = 0; t < R; ++t) {
+          const uint32_t len = rb[t + 1] - rb[t];
+          s_off[t] = o;
+          o += len ? ((len - 1u) >> sh) + 1u : 0u;
+        }
+        s_off[R] = o;
+      }
+      wave_sync_lds();
+      for (int t = 0; t < R; ++t) {
+        const uint32_t o = s_off[t], cnt = s_off[t + 1] - o, r_lo = rb[t];
+        for (uint32_t k = ln; k < cnt; k += kWave) smp[o + k] = b.X[r_lo + (k << sh)];
+      }
+      wave_sync_lds();
+    }
     for (int t = 0; t < R; ++t) {
       const uint32_t r_lo = rb[t], r_hi = rb[t + 1];
       for (uint32_t i0 = r_lo; i0 < r_hi; i0 += kWave) {
@@ -504,7 +546,13 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
           for (int u = 0; u < R; ++u) {
             const uint32_t u_lo = rb[u], u_hi = rb[u + 1];
             if (u == t || u_lo == u_hi) continue;
-            const uint32_t j = (u < t) ? upper_bound_u64(b.X, u_lo, u_hi, v) : lower_bound_u64(b.X, u_lo, u_hi, v);
+            uint32_t j;
+            if (sampled) {
+              const uint32_t o = s_off[u], cnt = s_off[u + 1] - o;
+              j = (u < t) ? sampled_bound_u64<true>(b.X, u_lo, u_hi, smp + o, cnt, sh, v) : sampled_bound_u64<false>(b.X, u_lo, u_hi, smp + o, cnt, sh, v);
+            } else {
+              j = (u < t) ? upper_bound_u64(b.X, u_lo, u_hi, v) : lower_bound_u64(b.X, u_lo, u_hi, v);
+            }
             rank += j - u_lo;
           }
           b.F[rank] = v;
@@ -532,18 +580,30 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
     // ---- merge with the candidates so far (A first unless X is smaller or equal: src/filter.c:52-60) into B ----
     const uint32_t nM = nA + nF;
     if (nM > b.ccap) return 0xFFFFFFFFu;
+    const bool sampled2 = nA != 0u && nM >= kSampleMin && cap_s != 0u;
+    uint32_t sh2 = 2, cX = 0, cA = 0;
+    if (sampled2) {  // samples of the survivors, then of the candidates so far
+      while ((nM >> sh2) + 2u > cap_s) ++sh2;
+      cX = ((nF - 1u) >> sh2) + 1u, cA = ((nA - 1u) >> sh2) + 1u;
+      wave_sync_lds();  // (the ranks above are done with their samples)
+      for (uint32_t k = ln; k < cX; k += kWave) smp[k] = b.X[k << sh2];
+      for (uint32_t k = ln; k < cA; k += kWave) smp[cX + k] = A[k << sh2];
+      wave_sync_lds();
+    }
     for (uint32_t i0 = 0; i0 < nA; i0 += kWave) {
       const uint32_t i = i0 + ln;
       if (i < nA) {
         const uint64_t v = A[i];
-        B[i + upper_bound_u64(b.X, 0u, nF, v)] = v;  // (an equal value of X goes first)
+        const uint32_t at = sampled2 ? sampled_bound_u64<true>(b.X, 0u, nF, smp, cX, sh2, v) : upper_bound_u64(b.X, 0u, nF, v);
+        B[i + at] = v;  // (an equal value of X goes first)
       }
     }
     for (uint32_t j0 = 0; j0 < nF; j0 += kWave) {
       const uint32_t j = j0 + ln;
       if (j < nF) {
         const uint64_t v = b.X[j];
-        B[j + lower_bound_u64(A, 0u, nA, v)] = v;
+        const uint32_t at = sampled2 ? sampled_bound_u64<false>(A, 0u, nA, smp + cX, cA, sh2, v) : lower_bound_u64(A, 0u, nA, v);
+        B[j + at] = v;
       }
     }
     wave_sync_global();
@@ -1204,7 +1264,8 @@ __global__ void __launch_bounds__(256) seed_filter_kernel(SeedParams p) {
           g.B = g.A + pre_wide + 2;
           g.xcap = pre_max + 1u, g.fcap = pre_max + 1u;
           g.ccap = pre_wide > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pre_wide + 1u;
-          uint32_t n2 = strand_lists_big(p, pk, rb, g, &list, prof);
+          // (the wave's LDS list space X, F, A, B — one contiguous piece, make_layout — holds the searches' samples there)
+          uint32_t n2 = strand_lists_big(p, pk, rb, g, lds.X, p.lay.xcap + p.lay.fcap + 2u * p.lay.ccap, &list, prof);
           if (n2 < 0xFFFFFFFEu) {
             clip_and_emit<true>(p, read, strand, L, list, n2, list == g.A ? g.B : g.A, cand_sum, chunk);
           } else {
