@@ -424,11 +424,14 @@ __device__ uint32_t strand_lists(const SeedParams &p, const Picked *picked /* [s
 }
 
 // Two-level search in a sorted stretch x[lo, hi) of the global arena whose every 2^sh-th element (x[lo + (k << sh)], k < cnt)
-// is kept in LDS as s[k]: the sample decides the piece, the piece is at most 2^sh elements of one or two cache lines.
+// is kept in LDS as s[k]: the sample decides the piece, the piece is at most 2^sh elements of one or two cache lines (sh = 0:
+// the whole stretch is in LDS and the arena is not read at all).
 // (A plain binary search over 1 000 arena entries is ten dependent L2 round trips per element.)
+typedef const __attribute__((address_space(3))) uint64_t *LdsU64;  // (a pointer that went through a call is "flat" to the compiler otherwise)
 template <bool UPPER>
-__device__ __forceinline__ uint32_t sampled_bound_u64(const uint64_t *x, uint32_t lo, uint32_t hi, const uint64_t *s, uint32_t cnt, uint32_t sh,
+__device__ __forceinline__ uint32_t sampled_bound_u64(const uint64_t *x, uint32_t lo, uint32_t hi, const uint64_t *s_flat, uint32_t cnt, uint32_t sh,
                                                       uint64_t key) {
+  const LdsU64 s = (LdsU64)s_flat;
   const uint32_t k = UPPER ? upper_bound_u64(s, 0u, cnt, key) : lower_bound_u64(s, 0u, cnt, key);
   if (k == 0) return lo;  // x[lo] itself is beyond the key (or the stretch is empty)
   const uint32_t lo2 = lo + ((k - 1u) << sh) + 1u, end = lo + (k << sh);
@@ -517,8 +520,8 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
     //      other run per round — were tried: the arrays cost more registers than the overlapped loads gave, 26.6 -> 32.6 ms
     //      per 50 k repeat reads.) ----
     const bool sampled = n >= kSampleMin && cap_s != 0u;
-    uint32_t sh = 2;
-    if (sampled) {  // every 2^sh-th element of every run into LDS: at most (n >> sh) + R samples
+    uint32_t sh = 0;
+    if (sampled) {  // every 2^sh-th element of every run into LDS: at most (n >> sh) + R samples (all of them where they fit)
       while ((n >> sh) + (uint32_t)R > cap_s) ++sh;
       if (ln == 0) {
         uint32_t o = 0;
@@ -581,7 +584,7 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
     const uint32_t nM = nA + nF;
     if (nM > b.ccap) return 0xFFFFFFFFu;
     const bool sampled2 = nA != 0u && nM >= kSampleMin && cap_s != 0u;
-    uint32_t sh2 = 2, cX = 0, cA = 0;
+    uint32_t sh2 = 0, cX = 0, cA = 0;
     if (sampled2) {  // samples of the survivors, then of the candidates so far
       while ((nM >> sh2) + 2u > cap_s) ++sh2;
       cX = ((nF - 1u) >> sh2) + 1u, cA = ((nA - 1u) >> sh2) + 1u;
