@@ -212,7 +212,6 @@ struct fem_dev {
   int select_occ_blocks = 0, join_occ_blocks = 0;
   uint64_t select_occ_key = ~0ull, join_occ_key = ~0ull;
   // reference
-  uint8_t *d_ref = nullptr;      // base codes
   // bit q of the codes, one bit per base (verify_kernel's windows); [3]: the uploaded character is not one of "ACGTN"
   uint8_t *d_planes = nullptr;  // femk::plane_window
   uint8_t *d_ref_raw = nullptr;  // the characters as uploaded (the traceback and MD compare and print them)
@@ -882,7 +881,7 @@ int refresh_dense(fem_dev *h) {
     if (p) (void)hipFree(p);
   h->d_occ32 = nullptr, h->d_goff = nullptr, h->d_blkseq = nullptr, h->d_freq11 = nullptr, h->d_bank_lo = nullptr;
   h->n_banks = 1, h->list_shift = 0;
-  if (!h->d_occ || !h->d_ref || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
+  if (!h->d_occ || !h->d_ref_raw || h->no_dense || h->k != femk::kK || h->step != femk::kStep || h->n_occ == 0) return FEM_OK;
   const uint64_t n_buckets = h->n_lookup - 1;
   if (!h->force_dense && (double)h->n_occ < kDenseMinAvgBucket * (double)n_buckets) return FEM_OK;
   // Coordinates: goff[seq] + pos, a gap between sequences; where the next sequence would pass the 32-bit limit a new BANK
@@ -1150,7 +1149,7 @@ int fem_dev_close(fem_dev *h) {
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
-  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off,
+  for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_planes, (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
                   (void *)h->d_freq11, (void *)h->d_bank_lo})
     if (p) (void)hipFree(p);
@@ -1184,6 +1183,30 @@ int fem_dev_upload_index(fem_dev *h, int32_t k, int32_t step, const uint32_t *lo
   return rc ? rc : refresh_dense(h);
 }
 
+namespace {
+// The reference as base codes 0..4 (what the bit planes and the index build are made from) in a buffer of its own, from the
+// resident characters.  A temporary: nothing on the mapping path reads it, so it is not kept (3 GB at 3 Gbp).
+int make_codes(fem_dev *h, uint8_t **out) {
+  *out = nullptr;
+  uint8_t *codes = nullptr;
+  const uint64_t total = h->ref_bytes;
+  HIP_TRY(h, hipMalloc((void **)&codes, total + 128));
+  hipError_t e = hipMemcpy(codes, h->d_ref_raw, total, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipMemset(codes + total, 4, 128);
+  if (e == hipSuccess && total) {
+    hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, codes, total);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(codes);
+    HIP_TRY(h, e);
+  }
+  *out = codes;
+  return FEM_OK;
+}
+}  // namespace
+
 int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq, const uint32_t *seq_len) {
   if (!h || !seq || !seq_len || n_seq == 0) return FEM_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1194,43 +1217,43 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
     h->seq_off[i] = total;
     total += seq_len[i];
   }
-  for (void *p : {(void *)h->d_ref, (void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_planes})
+  for (void *p : {(void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_planes})
     if (p) (void)hipFree(p);
-  h->d_ref = nullptr, h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
+  h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr;
   h->d_planes = nullptr;
+  h->ref_bytes = 0, h->n_seq = 0;
   // 64 bytes of slack so that 4-byte window reads at the very end stay inside the allocation
-  HIP_TRY(h, hipMalloc((void **)&h->d_ref, total + 128));
   HIP_TRY(h, hipMalloc((void **)&h->d_ref_raw, total + 128));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_off, n_seq * sizeof(uint64_t)));
   HIP_TRY(h, hipMalloc((void **)&h->d_seq_len, n_seq * sizeof(uint32_t)));
-  HIP_TRY(h, hipMemset(h->d_ref + total, 4, 128));
   for (uint32_t i = 0; i < n_seq; ++i)
-    if (seq_len[i]) HIP_TRY(h, hipMemcpy(h->d_ref + h->seq_off[i], seq[i], seq_len[i], hipMemcpyHostToDevice));
+    if (seq_len[i]) HIP_TRY(h, hipMemcpy(h->d_ref_raw + h->seq_off[i], seq[i], seq_len[i], hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_off, h->seq_off.data(), n_seq * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seq_len, h->seq_len.data(), n_seq * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIP_TRY(h, hipMemcpy(h->d_ref_raw, h->d_ref, total, hipMemcpyDeviceToDevice));
   HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 128));
-  if (total) {
-    hipLaunchKernelGGL(femk::ref_encode_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, total);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipDeviceSynchronize());
-  }
-  {  // bit planes of the codes, 64 bases of slack (code 4) included
-    const uint64_t n_pb = (total + 64 + 7) / 8;
-    HIP_TRY(h, hipMalloc((void **)&h->d_planes, femk::plane_bytes(n_pb)));
-    HIP_TRY(h, hipMemset(h->d_planes, 0, femk::plane_bytes(n_pb)));
-    hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, h->d_ref, h->d_ref_raw, n_pb, h->d_planes);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipDeviceSynchronize());
-  }
   h->ref_bytes = total, h->n_seq = n_seq;
+  {  // bit planes of the codes, 64 bases of slack (code 4) included; the codes themselves are not kept
+    uint8_t *codes = nullptr;
+    int rc = make_codes(h, &codes);
+    if (rc) return rc;
+    const uint64_t n_pb = (total + 64 + 7) / 8;
+    hipError_t e = hipMalloc((void **)&h->d_planes, femk::plane_bytes(n_pb));
+    if (e == hipSuccess) e = hipMemset(h->d_planes, 0, femk::plane_bytes(n_pb));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(femk::ref_planes_kernel, dim3((uint32_t)h->n_cu * 8u), dim3(256), 0, 0, codes, h->d_ref_raw, n_pb, h->d_planes);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    (void)hipFree(codes);
+    HIP_TRY(h, e);
+  }
   return refresh_dense(h);
 }
 
 int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_out, uint64_t *occ_out, uint64_t occ_cap,
                         uint64_t *n_occ_out) {
   if (!h) return FEM_ERR_INVALID;
-  if (!h->d_ref) return fail(h, FEM_ERR_STATE, "upload the reference before building the index");
+  if (!h->d_ref_raw) return fail(h, FEM_ERR_STATE, "upload the reference before building the index");
   if (k < 1 || k > 16 || step < 1) return fail(h, FEM_ERR_INVALID, "k must be 1..16 and step >= 1");
   HIP_TRY(h, hipSetDevice(h->device));
   if (h->d_lookup) (void)hipFree(h->d_lookup);
@@ -1238,7 +1261,11 @@ int fem_dev_build_index(fem_dev *h, int32_t k, int32_t step, uint32_t *lookup_ou
   h->d_lookup = nullptr, h->d_occ = nullptr;
   uint64_t n_occ = 0;
   std::string err;
-  int rc = femix::build_index(h->d_ref, h->seq_off, h->seq_len, k, step, h->n_cu, &h->d_lookup, &h->d_occ, &n_occ, &err);
+  uint8_t *codes = nullptr;  // (base codes of the reference: made for the build, not kept)
+  int rc = make_codes(h, &codes);
+  if (rc) return rc;
+  rc = femix::build_index(codes, h->seq_off, h->seq_len, k, step, h->n_cu, &h->d_lookup, &h->d_occ, &n_occ, &err);
+  (void)hipFree(codes);
   if (rc != FEM_OK) return fail(h, rc, err);
   h->n_lookup = (1ull << (2 * k)) + 1, h->n_occ = n_occ, h->k = k, h->step = step;
   if ((rc = refresh_summary(h))) return rc;
@@ -1467,7 +1494,7 @@ int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
   if (!params_ok(p)) return fail(h, FEM_ERR_INVALID, "parameters out of range (k 1..16, step 1..16, e 0..7, a 0..2)");
-  if (!h->d_lookup || !h->d_ref) return fail(h, FEM_ERR_STATE, "index and reference must be uploaded first");
+  if (!h->d_lookup || !h->d_ref_raw) return fail(h, FEM_ERR_STATE, "index and reference must be uploaded first");
   if (p->k != h->k) return fail(h, FEM_ERR_INVALID, "k differs from the uploaded index");
   Slot &s = h->slot[slot];
   if (!s.staged) return fail(h, FEM_ERR_STATE, "no reads staged in this slot");
