@@ -42,10 +42,13 @@ constexpr uint32_t kDenseVLimit = 0xEFFFF800u; // v < this <=> the lane holds a 
 constexpr uint32_t kDenseBlkShift = 20;        // blkseq[] granularity: first sequence at or before a 1 Mi block
 constexpr uint32_t kDenseMaxList = 128u;       // entries of one seed's list the join takes (two chunks)
 
-// Flagged values one (strand, group) unit may have before the read goes to the generic kernel: chance flags grow like
-// 3 n^2 / slots, and at R >= 7 (n ~ 470) the 32 Ki-slot bitmap gives ~20 of them: two per lane there, one otherwise.
+// Flagged values one (strand, group) unit may have before the read goes to the generic kernel: one per lane.  Chance flags
+// grow like 3 n^2 / slots: ~6 per unit at R = 5, ~20 at R >= 7 (n ~ 470), where rounds 3-4 took two per lane
+// (FEM_DENSE_FLAGS_HI=128).  Round 4, last change: one per lane there too — the second row's code and registers cost every
+// read of C5 more (join 13.46 -> 12.88 ms per 2.5 M reads) than the 0.4 % of reads that now go to the generic kernel (units of
+// several long lists: 0.46 ms): 168.2 -> 170.5 Mreads/s.
 #ifndef FEM_DENSE_FLAGS_HI
-#define FEM_DENSE_FLAGS_HI 128u
+#define FEM_DENSE_FLAGS_HI 64u
 #endif
 constexpr uint32_t dense_flag_cap(int R) { return R >= 7 ? FEM_DENSE_FLAGS_HI : 64u; }
 
