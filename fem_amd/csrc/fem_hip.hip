@@ -399,8 +399,12 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   l.smax = max_len >= (uint32_t)p.k ? max_len - (uint32_t)p.k + 1u : 1u;
   // a phase group's DP takes at most kSelMaxCols columns: groups of more than kSelMaxCols - 1 + 4 R seeds go to the generic kernel
   const uint32_t g_max = std::min<uint32_t>((l.smax + 2u) / 3u, femk::kSelMaxCols - 1u + 4u * R);
-  l.gstride = ((g_max + 3u) & ~3u) + 4u;  // (entries of 16 bits)
-  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 3100u / (6u * 2u * l.gstride)));
+  // one array of 16-bit frequencies per strand, in seed order (group g's seed c at 3 c + g): even, and an odd number of
+  // 32-bit words, so that the rows of the DP's lanes spread over the LDS banks
+  l.gstride = 3u * g_max + 2u;
+  l.gstride += l.gstride & 1u;
+  if (!((l.gstride >> 1) & 1u)) l.gstride += 2u;
+  l.nb = std::max<uint32_t>(1u, std::min<uint32_t>(femk::kReadBlock, 3100u / (2u * 2u * l.gstride)));
   l.strm_words = (l.nb * max_len + 15u) / 16u + 2u;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) {
@@ -411,7 +415,7 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
   l.rb = take((femk::kReadBlock + 2u) * 8u);
   l.rinfo = take(4u * femk::kReadBlock * 4u);
   l.strm = take(2u * l.strm_words * 4u);
-  l.fq = take(l.nb * 6u * l.gstride * 2u + 256u);  // (+ what an idle lane of the last group reads past its array)
+  l.fq = take(l.nb * 2u * l.gstride * 2u + 256u);  // (+ what an idle lane of the last strand reads past its array)
   l.wave_bytes = o;
   return l;
 }
@@ -454,14 +458,18 @@ int select_blocks_per_cu_r(bool banked, int block, uint32_t lds) {
   return e == hipSuccess ? nb : 0;
 }
 typedef void (*JoinKernel)(femk::SeedParams);
-JoinKernel join_kernel(int R, bool banked = false) {
-  static const JoinKernel k[2][femk::kMaxR] = {
+// which = 0: the compact table, 1: references in banks (compact, cut at bank_lo), 2: the strided table with its pads
+JoinKernel join_kernel(int R, int which) {
+  static const JoinKernel k[3][femk::kMaxR] = {
       {femk::seed_join_kernel_r1, femk::seed_join_kernel_r2, femk::seed_join_kernel_r3, femk::seed_join_kernel_r4, femk::seed_join_kernel_r5,
        femk::seed_join_kernel_r6, femk::seed_join_kernel_r7, femk::seed_join_kernel_r8, femk::seed_join_kernel_r9, femk::seed_join_kernel_r10},
       {femk::seed_join_banked_kernel_r1, femk::seed_join_banked_kernel_r2, femk::seed_join_banked_kernel_r3, femk::seed_join_banked_kernel_r4,
        femk::seed_join_banked_kernel_r5, femk::seed_join_banked_kernel_r6, femk::seed_join_banked_kernel_r7, femk::seed_join_banked_kernel_r8,
-       femk::seed_join_banked_kernel_r9, femk::seed_join_banked_kernel_r10}};
-  return k[banked ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR) - 1];
+       femk::seed_join_banked_kernel_r9, femk::seed_join_banked_kernel_r10},
+      {femk::seed_join_padded_kernel_r1, femk::seed_join_padded_kernel_r2, femk::seed_join_padded_kernel_r3, femk::seed_join_padded_kernel_r4,
+       femk::seed_join_padded_kernel_r5, femk::seed_join_padded_kernel_r6, femk::seed_join_padded_kernel_r7, femk::seed_join_padded_kernel_r8,
+       femk::seed_join_padded_kernel_r9, femk::seed_join_padded_kernel_r10}};
+  return k[which][std::min(std::max(R, 1), femk::kMaxR) - 1];
 }
 
 #define FEM_DENSE_SWITCH(R, CALL)      \
@@ -478,20 +486,21 @@ JoinKernel join_kernel(int R, bool banked = false) {
     default: CALL(10); break;          \
   }
 template <int R>
-uint32_t kernel_regs_r(bool join, bool banked) {
+uint32_t kernel_regs_r(bool join, int which) {
   hipFuncAttributes a{};
-  const void *f = join ? (const void *)join_kernel(R, banked)
+  const bool banked = which == 1;
+  const void *f = join ? (const void *)join_kernel(R, which)
                        : banked ? (const void *)femk::seed_select_kernel<R, true> : (const void *)femk::seed_select_kernel<R>;
   return hipFuncGetAttributes(&a, f) == hipSuccess && a.numRegs > 0 ? (uint32_t)a.numRegs : 128u;
 }
 // vector registers per lane of seed_join_kernel<R> / seed_select_kernel<R>
 // (handles of several GPUs launch from their own threads: the cache is atomic; every thread would store the same value)
-uint32_t kernel_regs(int R, bool join, bool banked = false) {
-  static std::atomic<uint32_t> cache[2][2][femk::kMaxR + 1] = {};
-  std::atomic<uint32_t> &slot = cache[banked ? 1 : 0][join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
+uint32_t kernel_regs(int R, bool join, int which = 0) {
+  static std::atomic<uint32_t> cache[3][2][femk::kMaxR + 1] = {};
+  std::atomic<uint32_t> &slot = cache[which][join ? 1 : 0][std::min(std::max(R, 1), femk::kMaxR)];
   uint32_t c = slot.load(std::memory_order_relaxed);
   if (c) return c;
-#define FEM_CALL(r) c = kernel_regs_r<r>(join, banked)
+#define FEM_CALL(r) c = kernel_regs_r<r>(join, which)
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
   slot.store(c, std::memory_order_relaxed);
@@ -509,12 +518,12 @@ void launch_select(int R, bool banked, dim3 grid, dim3 block, uint32_t lds, hipS
   FEM_DENSE_SWITCH(R, FEM_CALL)
 #undef FEM_CALL
 }
-int join_blocks_per_cu(int R, bool banked, int block, uint32_t lds) {
+int join_blocks_per_cu(int R, int which, int block, uint32_t lds) {
   int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, join_kernel(R, banked), block, lds) == hipSuccess ? nb : 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, join_kernel(R, which), block, lds) == hipSuccess ? nb : 0;
 }
-void launch_join(int R, bool banked, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
-  hipLaunchKernelGGL(join_kernel(R, banked), grid, block, lds, st, sp);
+void launch_join(int R, int which, dim3 grid, dim3 block, uint32_t lds, hipStream_t st, const femk::SeedParams &sp) {
+  hipLaunchKernelGGL(join_kernel(R, which), grid, block, lds, st, sp);
 }
 
 template <int R>
@@ -762,20 +771,21 @@ int launch_batch(fem_dev *h, Slot &s) {
         const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / fp.lay.wave_bytes));
         fp.lay.picked = wpb * fp.lay.wave_bytes;
         const uint32_t lds_bytes = wpb * fp.lay.wave_bytes + 64u * 8u;
-        const uint64_t key = ((uint64_t)banked << 48) | ((uint64_t)R << 40) | lds_bytes;
-        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, banked, (int)(64u * wpb), lds_bytes);
+        const int which = banked ? 1 : h->list_shift ? 2 : 0;  // (join_kernel)
+        const uint64_t key = ((uint64_t)which << 48) | ((uint64_t)R << 40) | lds_bytes;
+        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, which, (int)(64u * wpb), lds_bytes);
         uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
         if (overlap) {
           // leave one block of the next batch's seed_select_kernel room on every CU: registers (512 per lane and SIMD,
           // handed out in eights), LDS (160 KB) and wave slots (8 per SIMD) of both kernels together
-          const uint32_t vj = (kernel_regs(R, true, banked) + 7u) & ~7u, vs = (kernel_regs(R, false, banked) + 7u) & ~7u;
+          const uint32_t vj = (kernel_regs(R, true, which) + 7u) & ~7u, vs = (kernel_regs(R, false, banked ? 1 : 0) + 7u) & ~7u;
           const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
           const uint32_t lj = (lds_bytes + 511u) & ~511u, ls = (select_lds + 511u) & ~511u;  // (LDS is handed out in pieces of 512 bytes)
           while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lj + ls > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
         }
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
         fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
-        rc = timed(0, s.stream, [&] { launch_join(R, banked, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
+        rc = timed(0, s.stream, [&] { launch_join(R, which, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
         if (rc) return rc;
       }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the two queued
@@ -938,7 +948,12 @@ int refresh_dense(fem_dev *h) {
   uint32_t list_shift = 0;
   if (n_banks == 1 && !h->no_strided) {
     const size_t words = ((size_t)n_buckets << femk::kDenseListShift) + 256;
-    if (hipMalloc((void **)&h->d_occ32, words * sizeof(uint32_t)) == hipSuccess && hipMemset(h->d_occ32, 0, words * sizeof(uint32_t)) == hipSuccess) {
+    bool ok = hipMalloc((void **)&h->d_occ32, words * sizeof(uint32_t)) == hipSuccess;
+    if (ok) {  // every slot reads "pad" (fem_seed_dense.hip.h) until dense_occ32_strided_kernel writes a bucket's entries over its first ones
+      hipLaunchKernelGGL(femk::dense_pad_kernel, dim3((uint32_t)h->n_cu * 16u), dim3(256), 0, 0, (uint4 *)h->d_occ32, (uint64_t)(words / 4));
+      ok = hipGetLastError() == hipSuccess;
+    }
+    if (ok) {
       list_shift = femk::kDenseListShift;
     } else {
       if (h->d_occ32) (void)hipFree(h->d_occ32);

@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
 // kept0/kept1; false = hand the read to the generic kernel.  `bitmap` is all-zero (but for its guard word) on entry
 // and on exit.
 // ---------------------------------------------------------------------------------------------------------
-template <int R, bool BANKED = false>
+template <int R, bool BANKED = false, bool PADDED = false>
 __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, uint32_t s_freq, uint32_t *bitmap,
                           uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */,
                           uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1, uint32_t seq_base = 0u /* first sequence of the bank */) {
@@ -81,7 +81,9 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   constexpr uint32_t kPeriodBits = kSlotBits + 3u;   // values this many bits apart share a slot
   constexpr uint32_t kFlagCap = dense_flag_cap(R);   // flagged values one unit may have (one or two per lane)
   constexpr int kOpt = R <= 6 ? FEM_JOIN_OPT : FEM_JOIN_OPT_HI;
-  constexpr bool kOptPairs = (kOpt & 1) != 0, kOptSent = (kOpt & 2) != 0, kOptLong = (kOpt & 4) != 0, kOptHit = (kOpt & 8) != 0;
+  // (PADDED — the strided table with its pads, fem_seed_dense.hip.h: lanes behind a list's end hold a sentinel of their own by
+  //  the load itself, so the forms of bit 2 cost nothing: no lane constant, the masks of valid lanes are scalar bit fields)
+  constexpr bool kOptPairs = (kOpt & 1) != 0, kOptSent = (kOpt & 2) != 0 || (PADDED && R <= 6), kOptLong = (kOpt & 4) != 0, kOptHit = (kOpt & 8) != 0;
   constexpr bool kSecondProbe = true;  // weed the chance flags out before the exact filter ...
   constexpr uint32_t kProbeMin = kOptPairs ? 16u : 8u;  // ... when there are more flagged values than this (what the all-pairs filter takes)
   constexpr uint32_t kFlgStride = kFlagCap + 1u;     // the entry behind a group's array takes the overflow writes
@@ -99,7 +101,8 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   const uint32_t s_sf = pack_sf(s_start, s_freq);
   const uint64_t s_addr = (uint64_t)(uintptr_t)(occ32 + s_lo);
   const uint32_t s_alo = (uint32_t)s_addr, s_ahi = (uint32_t)(s_addr >> 32);
-  const uint32_t lane4 = ln * 4u;
+  uint32_t lane4 = ln * 4u;
+  if (PADDED) asm("" : "+v"(lane4));  // (opaque: base + lane4 stays "scalar base + 32-bit lane offset", one global_load with an SGPR pair, not a 64-bit vector add per load)
   // Sentinels of a lane's own (kOptSent).  Slots repeat every 2^kPeriodBits positions; within one unit no two lanes
   // without an entry may land in one slot (a "second value of a slot" costs its marks): a lane behind a list's end holds
   // sent_a - start (lanes 2304 apart — starts are below 1024 and, within a unit, at least 12 apart; 2304 = 9 words of the
@@ -130,7 +133,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t last4 = nxt_sf[t] >> 24;
-      nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(base[t] + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
+      if (PADDED)
+        nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(base[t] + lane4);  // lanes behind the list's end: the table's pads
+      else
+        nxt[t] = *(const __attribute__((address_space(1))) uint32_t *)(base[t] + (lane4 < last4 ? lane4 : last4));  // lanes behind the list's end: its last entry again
     }
   };
   auto prefetch = [&](uint32_t u) { prefetch_of(s_sf, s_alo, s_ahi, u); };
@@ -165,6 +171,15 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     const uint32_t *w = word_of(qm, 5u);
     return __builtin_amdgcn_alignbit(w[1], w[0], qm & 31u);
   };
+  // The same window with the three slots at the TOP of the word (bit 29: slot - 1, 30: own, 31: slot + 1): a lane's own slot is
+  // always present, so "a neighbouring slot is present" is ONE unsigned compare, x >= kNearTop.  (Values in the table's first
+  // 30 slots read the guard word there and are always flagged: 0.1 % of them.)
+  constexpr uint32_t kNearTop = 0x60000000u;
+  auto window_top = [&](uint32_t v) -> uint32_t {
+    const uint32_t qs = (v >> 3) - 30u;
+    const uint32_t *w = word_of(qs, 5u);
+    return __builtin_amdgcn_alignbit(w[1], w[0], qs & 31u);
+  };
   prefetch(0);
   uint32_t cmin = 0xFFFFFFFFu, cmax = 0u;  // per lane: smallest / largest surviving value of this strand it has seen
   uint64_t pm0 = 0, pm1 = 0, pm2 = 0;      // survivors of the strand's groups (lanes of flg[g])
@@ -176,6 +191,11 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     // ---- the unit's runs as wave-uniform scalars ----
     uint32_t f[R], st[R];
     uint32_t n_g = 0, f_max = 0;
+    auto smax = [](uint32_t a_, uint32_t b_) -> uint32_t {  // (wave-uniform operands: as a ternary the compiler builds v_max3 + v_readfirstlane of it)
+      uint32_t m;
+      asm("s_max_u32 %0, %1, %2" : "=s"(m) : "s"(a_), "s"(b_) : "scc");
+      return m;
+    };
     // (banks: U has entries in a higher bank — the last run is merged whole, also where this bank holds nothing else)
     const bool keep_all = BANKED && (nxt_sf[R - 1] & kSelKeepAll) != 0u;
 #pragma unroll
@@ -183,7 +203,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
       const uint32_t sf = nxt_sf[t];
       f[t] = (sf >> 16) & 0xFFu, st[t] = sf & (BANKED ? kSelKeepAll - 1u : 0xFFFFu);
       n_g += f[t];
-      f_max = f[t] > f_max ? f[t] : f_max;
+      f_max = t == 0 ? f[0] : smax(f[t], f_max);
     }
     uint32_t val[R];
 #pragma unroll
@@ -209,7 +229,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
           if (kOptLong && f[t] <= (uint32_t)kWave) continue;  // (wave-uniform: only the runs that have a second chunk)
           const uint32_t last4 = f[t] > (uint32_t)kWave ? (f[t] - 1u) * 4u : 0u;
           const uint32_t at4 = lane4 + 4u * (uint32_t)kWave;
-          hv[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
+          if (PADDED)
+            hv[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base(u * R + t) + at4);
+          else
+            hv[t] = *(const __attribute__((address_space(1))) uint32_t *)(run_base(u * R + t) + (at4 < last4 ? at4 : last4));
         }
       }
       bool remap;
@@ -275,17 +298,27 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
           // top) instead of the list's last entry again; which lanes hold entries stays behind as a scalar mask
 #pragma unroll
           for (int t = 0; t < R; ++t) {
-            const bool in = ln < f[t];
-            vm[t] = __builtin_amdgcn_ballot_w64(in);  // (the compare's own result: no instruction)
-            val[t] = (in ? val[t] : sent_a) - st[t];
+            if (PADDED) {
+              vm[t] = __builtin_amdgcn_ballot_w64(ln < f[t]);  // (one v_cmp into a scalar pair; as scalar arithmetic on f it is six instructions)
+              val[t] -= st[t];
+            } else {
+              const bool in = ln < f[t];
+              vm[t] = __builtin_amdgcn_ballot_w64(in);  // (the compare's own result: no instruction)
+              val[t] = (in ? val[t] : sent_a) - st[t];
+            }
           }
         } else {
 #pragma unroll
-          for (int t = 0; t < R; ++t) val[t] = ln < f[t] ? val[t] - st[t] : kDenseSent;
+          for (int t = 0; t < R; ++t) val[t] = PADDED ? val[t] - st[t] : ln < f[t] ? val[t] - st[t] : kDenseSent;  // (pads: sentinels already; the inserts test)
         }
         if (long_lists) {
 #pragma unroll
-          for (int t = 0; t < R; ++t) hv[t] = ln + (uint32_t)kWave < f[t] ? hv[t] - st[t] : kDenseSent;
+          for (int t = 0; t < R; ++t) {
+            if (PADDED && (!kOptLong || f[t] > (uint32_t)kWave))
+              hv[t] -= st[t];  // (pads: "no entry" already)
+            else
+              hv[t] = ln + (uint32_t)kWave < f[t] ? hv[t] - st[t] : kDenseSent;
+          }
 #pragma unroll
           for (int t = 0; t < R - 1; ++t) {
             const uint32_t l_lo = (uint32_t)__builtin_amdgcn_readlane((int)val[t], (int)((f[t] - 1u) & 63u));
@@ -324,7 +357,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         // cut from the top — stores its sentinel at the place the next flagged value will take, or behind the last one,
         // where the exact filter reads it as "no value" (it lies above every coordinate).
         auto flag_chunk = [&](uint32_t v, uint32_t xw, uint64_t valid, bool exact) {
-          bool near = (xw & 5u) != 0u;
+          bool near = xw >= kNearTop;
           if (exact) near = near && v < kDenseVLimit;
           const uint64_t m = exact ? __builtin_amdgcn_ballot_w64(near) : __builtin_amdgcn_ballot_w64(near) & valid;
           if (!exact && m == 0) return;  // (wave-uniform)
@@ -365,7 +398,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
             for (int q = 0; q < kBatch; ++q)
               if (t0 + q < R) {
                 if (second && kOptLong && f[t0 + q] <= (uint32_t)kWave) continue;
-                x[q] = window(vals[t0 + q]);
+                x[q] = window_top(vals[t0 + q]);
               }
 #pragma unroll
             for (int q = 0; q < kBatch; ++q)
@@ -557,7 +590,7 @@ constexpr int join_waves(int R) { return R <= 6 ? FEM_JOIN_WAVES_LO : FEM_JOIN_W
 // registers): 6 x 72 + 80 = 512 per lane and SIMD.  (amdgpu_num_vgpr is not honoured by this compiler; the budget follows
 // from the waves per SIMD asked for, and that attribute wants a literal: one kernel per R instead of a template.)
 
-template <int R, bool BANKED = false>
+template <int R, bool BANKED = false, bool PADDED = false>
 __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *smem) {
   constexpr uint32_t kSeeds = (uint32_t)(kStep * R);
   static_assert(2 * kStep * R <= kWave, "both strands' seeds must fit the lanes of one wave");
@@ -705,7 +738,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
       const uint32_t s_lo = sel.x, s_start = sel.y & 0xFFFFu, s_freq = sel.y >> 16;
       // ---- lists -> candidates, one strand after the other ----
       uint32_t kept0 = 0, kept1 = 0;
-      if (!join_read<R>(p, s_start, s_lo, s_freq, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
+      if (!join_read<R, false, PADDED>(p, s_start, s_lo, s_freq, bitmap, flg, scatter, cand_lds, kept0, kept1)) {
         queue_slow(read);
         continue;
       }
@@ -793,6 +826,10 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
   __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_JOIN_WAVES_HI, 8))) seed_join_banked_kernel_r##R(SeedParams p) { /* references in banks */ \
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R, true>(p, smem);                                                                                            \
+  }                                                                                                                              \
+  __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) seed_join_padded_kernel_r##R(SeedParams p) { /* the strided table with pads */ \
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
+    seed_join_body<R, false, true>(p, smem);                                                                                     \
   }
 FEM_JOIN_KERNEL(1, FEM_JOIN_WAVES_LO)
 FEM_JOIN_KERNEL(2, FEM_JOIN_WAVES_LO)

@@ -97,9 +97,11 @@ __device__ __forceinline__ uint32_t rc_hash(uint32_t hf, uint32_t nm) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The seed-selection DP of one phase group in one lane (src/filter.c:3-28).  F = the group's frequencies, 16 bits per
-// seed; ncols = C - 1 of this lane's group (0: idle lane), maxcols = the largest in the wave.  Column c (0-based)
-// of row r (0-based) uses seed c + 4 r.  take[r] receives the take bits: column c at bit iters - 1 - c.
+// The seed-selection DP of one phase group in one lane (src/filter.c:3-28).  F = the frequencies of the strand's seeds from
+// the group's first one on, 16 bits per seed, in read order: the group's seed g sits at F[3 g] (round 5: one linear array
+// per strand — round 4 kept an array per phase group, and the lanes that fill them paid a division by three per seed);
+// ncols = C - 1 of this lane's group (0: idle lane), maxcols = the largest in the wave.  Column c (0-based) of row r
+// (0-based) uses the group's seed c + 4 r.  take[r] receives the take bits: column c at bit iters - 1 - c.
 // ---------------------------------------------------------------------------------------------------------
 template <int R, int W>
 __device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uint32_t maxcols, uint32_t inf, uint32_t (&take)[R][W],
@@ -114,7 +116,7 @@ __device__ __forceinline__ void select_dp(const uint16_t *F, uint32_t ncols, uin
   for (uint32_t c = 0; c < maxcols; ++c) {
     uint32_t f[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) f[r] = F[c + 4u * (uint32_t)r];  // (one address, R immediate offsets)
+    for (int r = 0; r < R; ++r) f[r] = F[3u * c + 12u * (uint32_t)r];  // (one address, R immediate offsets)
     const bool in = c < ncols;
     uint32_t up = 0;  // M[0][c] = 0
 #pragma unroll
@@ -149,7 +151,7 @@ __device__ __forceinline__ int first_set_from(const uint32_t (&m)[W], uint32_t f
 #define FEM_SELECT_WAVES 6
 #endif
 #ifndef FEM_SELECT_UNROLL
-#define FEM_SELECT_UNROLL 4
+#define FEM_SELECT_UNROLL 2
 #endif
 
 template <int R, bool BANKED = false>
@@ -161,11 +163,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
   uint64_t *boff = (uint64_t *)(wbase + p.lay.rb);    // offsets of the block's reads (kReadBlock + 1)
   uint32_t *fw = (uint32_t *)(wbase + p.lay.strm);    // the sub-block's bases, 2 bits each (N as A), 16 per big-endian word
   uint32_t *nw = fw + p.lay.strm_words;               // ... and its N marks (3 = not one of ACGT)
-  uint16_t *fq = (uint16_t *)(wbase + p.lay.fq);      // [read][strand][phase][gstride] frequencies, 16 bits per seed
+  uint16_t *fq = (uint16_t *)(wbase + p.lay.fq);      // [read][strand][sstride] frequencies, 16 bits per seed, in the strand's seed order
   uint32_t *r_base = (uint32_t *)(wbase + p.lay.rinfo), *r_len = r_base + kReadBlock, *r_flag = r_len + kReadBlock,
            *r_pre = r_flag + kReadBlock;              // per read of the sub-block
   constexpr uint32_t kOk0 = 1u, kOk1 = 2u, kShape = 4u, kSlow = 8u;
-  const uint32_t gstride = p.lay.gstride, nb = p.lay.nb;
+  const uint32_t sstride = p.lay.gstride, nb = p.lay.nb;  // (elements per strand: even, rows on 4-byte boundaries)
   const uint32_t inf = p.inf32;
   SlotChunk qchunk;
 
@@ -265,62 +267,76 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         }
         wave_sync_lds();
       }
-      // ---- frequencies of every seed on both strands: lane (read i, seed j), one freq11 dword each ----
+      // ---- frequencies of every seed on both strands: lane (read i, seeds 2 q and 2 q + 1) — the two share eleven bases X,
+      //      so their freq11 dwords sit in one 16-byte entry (one sector): one place in the stream, one window of it, two
+      //      loads; the four bytes they bring (seed 2 q and 2 q + 1 on the forward strand, their reverse complements =
+      //      seeds S - 1 - 2 q and S - 2 - 2 q of the reverse strand) go out as one aligned 32-bit store and two 16-bit ones.
+      //      (Round 4: a lane per seed, the place worked out twice — before the load and behind it —, and a division by
+      //      three per store for the per-group arrays: 122 of the kernel's 253 vector instructions per read.) ----
       const uint32_t SP = wave_max_u32(my_S);
       if (SP != 0) {
-        const uint32_t magic = 0xFFFFFFFFu / SP + 1u;  // w / SP = umulhi(w, magic) for w * SP < 2^32
-        const uint32_t total = cnt * SP;
+        const uint32_t SPp = (SP + 1u) >> 1;             // pairs per read
+        const uint32_t magic = 0xFFFFFFFFu / SPp + 1u;   // w / SPp = umulhi(w, magic) for w * SPp < 2^32
+        const uint32_t total = cnt * SPp;
         constexpr int U = FEM_SELECT_UNROLL;
-        // U rounds of loads are issued before the first one is used.  The kernel is bound by the rate of table sectors
-        // the fabric delivers (57 G/s) whatever its occupancy — one block per CU takes the 3.3 ms per 2.5 M reads of C3
-        // that five take, U = 4 what U = 24 takes — and shares the chip with seed_join_kernel: it is built to be small
-        // (80 registers, 3 KB of LDS per wave).  Nothing but the table word is kept across the two halves: place, hash
-        // and gates are worked out again.
-        auto place = [&](uint32_t w, uint32_t &i_c, uint32_t &j, uint32_t &S) -> bool {
-          const uint32_t i = __umulhi(w, magic);
-          j = w - __umul24(i, SP);
-          i_c = i < cnt ? i : 0u;
-          const uint32_t fl = r_flag[i_c];
-          S = r_len[i_c] - (uint32_t)(kK - 1);
-          return w < total && (fl & kShape) && !(fl & kSlow) && j < S;
-        };
+        constexpr uint32_t kActBit = 1u << 25, kTwoBit = 1u << 24;
+        // U rounds of loads are issued before the first one is used; a round's place (read | first seed << 4 | S << 14 | flags)
+        // waits in one register.  The kernel shares the chip with seed_join_kernel: it is built to be small.
         for (uint32_t w0 = 0; w0 < total; w0 += (uint32_t)(U * kWave)) {
-          uint32_t d[U];
+          uint32_t d0[U], d1[U], where[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            uint32_t i_c, j, S;
-            const bool act = place(w0 + (uint32_t)(u * kWave) + ln, i_c, j, S);
-            const uint32_t hf = stream_window(fw, act ? r_base[i_c] + j : 0u) >> 8;
-            // even j: the seed's last eleven bases + its first base; odd j: its first eleven + its last
-            const uint32_t at = (j & 1u) ? hf : (((hf & (kX11 - 1u)) << 2) | (hf >> 22));
-            d[u] = p.freq11[act ? at : 0u];
+            const uint32_t w = w0 + (uint32_t)(u * kWave) + ln;
+            const uint32_t i = __umulhi(w, magic);
+            const uint32_t j = (w - __umul24(i, SPp)) << 1;
+            const uint32_t i_c = i < cnt ? i : 0u;
+            const uint32_t fl = r_flag[i_c];
+            const uint32_t S = r_len[i_c] - (uint32_t)(kK - 1);
+            const bool act = w < total && (fl & kShape) && !(fl & kSlow) && j < S;
+            const bool two = act && j + 1u < S;
+            const uint32_t win = stream_window(fw, act ? r_base[i_c] + j : 0u);  // bases j .. j + 15: both seeds
+            const uint32_t hf0 = win >> 8;
+            // seed j: its last eleven bases X + its first base; seed j + 1 = X . its last base: the hash itself
+            const uint32_t at0 = ((hf0 & (kX11 - 1u)) << 2) | (hf0 >> 22), at1 = (win >> 6) & kHashMask;
+            d0[u] = p.freq11[act ? at0 : 0u];
+            d1[u] = p.freq11[two ? at1 : 0u];
+            where[u] = i_c | (j << 4) | (S << 14) | (two ? kTwoBit : 0u) | (act ? kActBit : 0u);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            uint32_t i, j, S;
-            if (place(w0 + (uint32_t)(u * kWave) + ln, i, j, S)) {
-              const uint32_t sh = (j & 1u) * 16u;
-              uint32_t f_fwd = (d[u] >> sh) & 255u;
-              uint32_t f_rev = (d[u] >> (sh + 8u)) & 255u;
-              bool rev_own = false;
-              uint32_t hf = 0, nm = 0;
-              if (has_n || f_fwd == 255u || f_rev == 255u) {
-                const uint32_t pos = r_base[i] + j;
-                hf = stream_window(fw, pos) >> 8;
-                if (has_n) nm = stream_window(nw, pos) >> 8;
-                rev_own = nm != 0u;  // the reverse strand counts N as A after complementing: its own hash
+            if (where[u] & kActBit) {
+              const uint32_t i = where[u] & 15u, j = (where[u] >> 4) & 1023u, S = (where[u] >> 14) & 1023u;
+              const bool two = (where[u] & kTwoBit) != 0u;
+              // bytes: f(seed j), f(its reverse complement), f(seed j + 1), f(its reverse complement)
+              uint32_t x = (d0[u] & 0x0000FFFFu) | (d1[u] & 0xFFFF0000u);
+              if (!two) x &= 0x0000FFFFu;
+              uint32_t ffwd = x & 0x00FF00FFu, frev = (x >> 8) & 0x00FF00FFu;  // (seed j | seed j + 1 << 16)
+              const uint32_t is255 = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;  // some byte reads 255
+              if (has_n || is255 != 0u) {
+                // rare: "255 or more" is looked up exactly; the reverse strand counts N as A after complementing (its own hash)
+                uint32_t f2[2] = {0u, 0u}, r2[2] = {0u, 0u};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  if (q == 1 && !two) continue;
+                  uint32_t f_fwd = (x >> (16 * q)) & 255u, f_rev = (x >> (16 * q + 8)) & 255u;
+                  const uint32_t pos = r_base[i] + j + (uint32_t)q;
+                  const uint32_t hf = stream_window(fw, pos) >> 8;
+                  const uint32_t nm = has_n ? stream_window(nw, pos) >> 8 : 0u;
+                  if (f_fwd == 255u) f_fwd = p.lookup[hf + 1u] - p.lookup[hf];
+                  if (nm != 0u || f_rev == 255u) {
+                    const uint32_t hr = rc_hash(hf, nm);
+                    f_rev = p.lookup[hr + 1u] - p.lookup[hr];
+                  }
+                  if (f_fwd >= 0xFFFFu || f_rev >= 0xFFFFu) atomicOr(&r_flag[i], kSlow);  // (16 bits do not hold it: generic kernel)
+                  f2[q] = f_fwd < 0xFFFFu ? f_fwd : 0xFFFFu, r2[q] = f_rev < 0xFFFFu ? f_rev : 0xFFFFu;
+                }
+                ffwd = f2[0] | (f2[1] << 16), frev = r2[0] | (r2[1] << 16);
               }
-              if (f_fwd == 255u) f_fwd = p.lookup[hf + 1u] - p.lookup[hf];  // "255 or more": the exact count
-              if (rev_own || f_rev == 255u) {
-                const uint32_t hr = rc_hash(hf, nm);
-                f_rev = p.lookup[hr + 1u] - p.lookup[hr];
-              }
+              uint16_t *row_f = fq + __umul24(i, 2u * sstride), *row_r = row_f + sstride;
+              *(uint32_t *)(row_f + j) = ffwd;  // (j is even; without a second seed a zero lands behind the strand's last one)
               const uint32_t jr = S - 1u - j;
-              const uint32_t gi = div3_small(j), gr = div3_small(jr);
-              uint16_t *row = fq + __umul24(i, 6u * gstride);
-              row[__umul24(j - times3(gi), gstride) + gi] = (uint16_t)(f_fwd < 0xFFFFu ? f_fwd : 0xFFFFu);
-              row[__umul24(3u + jr - times3(gr), gstride) + gr] = (uint16_t)(f_rev < 0xFFFFu ? f_rev : 0xFFFFu);
-              if (f_fwd >= 0xFFFFu || f_rev >= 0xFFFFu) atomicOr(&r_flag[i], kSlow);  // (16 bits do not hold it: generic kernel)
+              row_r[jr] = (uint16_t)frev;
+              if (two) row_r[jr - 1u] = (uint16_t)(frev >> 16);
             }
           }
         }
@@ -338,7 +354,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
         const bool valid = read_ok && ((fl >> strand) & 1u);
         const uint32_t ncols = valid ? div3_small(S - si) - (uint32_t)(R * kLg) + 1u : 0u;
         const uint32_t maxcols = wave_max_u32(ncols);
-        const uint16_t *F = fq + __umul24(__umul24(i_c, 6u) + u, gstride);
+        const uint16_t *F = fq + __umul24(i_c * 2u + strand, sstride) + si;
         uint32_t key[R];  // frequency << 14 | traceback order << 10 | start, per selected seed
 #pragma unroll
         for (int t = 0; t < R; ++t) key[t] = (uint32_t)t << 10;  // a seed that was never taken is all zero (see below)
@@ -364,8 +380,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
                   alive = false;
                 } else {
                   col -= at - (int)shift;
-                  const uint32_t idx = (uint32_t)col + (uint32_t)(4 * r);
-                  key[t] = ((uint32_t)F[idx] << 14) | ((uint32_t)t << 10) | (si + times3(idx));  // (65 534 << 14 fits)
+                  const uint32_t idx3 = times3((uint32_t)col + (uint32_t)(4 * r));
+                  key[t] = ((uint32_t)F[idx3] << 14) | ((uint32_t)t << 10) | (si + idx3);  // (65 534 << 14 fits)
                 }
               }
             }
@@ -392,7 +408,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
 #pragma unroll
           for (int t = 0; t < R; ++t) {
             const uint32_t f = key[t] >> 14, sidx = key[t] & 1023u;
-            lo[t] = 0, hs[t] = 0;
+            // (a seed that was never taken, or whose bucket is empty: in the strided table its "list" is the stretch of pads
+            //  behind the last bucket — seed_join_kernel reads a run's first chunk whatever its length)
+            lo[t] = !BANKED && p.list_shift ? p.n_buckets << p.list_shift : 0u, hs[t] = 0;
             if (f != 0u) {
               const uint32_t j = strand ? S - 1u - sidx : sidx;
               const uint32_t hf = stream_window(fw, base + j) >> 8;
