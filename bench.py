@@ -197,16 +197,24 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             kept[sl] = (r.cand_begin[:2 * n_chk].copy(), r.cand_count[:2 * n_chk].copy(), r.cand.copy(), r.ed.copy(), r.end.copy())
         return r.stats
 
-    def pipeline(n):
+    trace = []  # FEM_BENCH_TRACE=1: (what, step, seconds) of every submit / retire of the timed region (fill and drain made visible)
+
+    def pipeline(n, traced=False):
         tot = np.zeros(5, dtype=np.uint64)
         last = None
         for i in range(n):
             if i >= DEPTH:
                 last = retire(i - DEPTH)
+                if traced:
+                    trace.append(("retire", i - DEPTH, time.perf_counter()))
                 tot += last
             submit(i)
+            if traced:
+                trace.append(("submit", i, time.perf_counter()))
         for i in range(max(0, n - DEPTH), n):
             last = retire(i)
+            if traced:
+                trace.append(("retire", i, time.perf_counter()))
             tot += last
         return tot, last
 
@@ -227,7 +235,12 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         fence()
         host_s[0] = host_s[1] = 0.0
         t_start = time.perf_counter()
-        job_r, last_r = pipeline(steps)
+        job_r, last_r = pipeline(steps, traced=os.environ.get("FEM_BENCH_TRACE") == "1" and rep == 0)
+        if trace:
+            t_ret = [t - t_start for w_, _, t in trace if w_ == "retire"]
+            log("%s trace: retire times (ms) %s" % (key, " ".join("%.2f" % (1e3 * t) for t in t_ret)))
+            log("%s trace: steady step %.3f ms (retires %d..%d)" % (key, 1e3 * (t_ret[-DEPTH - 1] - t_ret[DEPTH]) / max(1, len(t_ret) - 2 * DEPTH - 1), DEPTH, len(t_ret) - DEPTH - 1))
+            trace.clear()
         if rk.dist:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
             job_r = reduce_stats(job_r, device=red_dev)
         fence()

@@ -44,7 +44,9 @@ constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 
 struct TimedLaunch {
   int kernel;
   hipEvent_t start, stop;
+  bool counts = true;  // false: a further part of a launch that is already counted (a batch mapped in parts, launch_batch)
 };
+constexpr int kMaxParts = 4;
 
 struct Slot {
   hipStream_t stream = nullptr;
@@ -83,6 +85,13 @@ struct Slot {
   uint64_t prefetched_reads2 = 0, prefetched_cand = 0, last_n_cand = 0;
   uint64_t h2d_bytes = 0;                 // what the last staging sent over the link
   bool sent_packed = false;
+  // A batch committed to an IDLE device is sent and mapped in `parts` pieces (reads [part_begin[q], part_begin[q + 1])), so that
+  // the join of its first piece starts after a quarter of the copy and a quarter of the selection (launch_batch): the fill of
+  // the pipeline.  ev_part[q]: piece q's characters are in HBM; ev_sel[q]: its selection is done.
+  int parts = 1;
+  uint32_t part_begin[kMaxParts + 1] = {0, 0, 0, 0, 0};
+  hipEvent_t ev_part[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_sel[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_zeroed = nullptr;
   // outputs on the device
   uint64_t *d_cand = nullptr;
   uint32_t *d_meta = nullptr;
@@ -120,7 +129,8 @@ struct Slot {
 // ctr[4] | arena_ctr[2] | stats[4]
 constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
 // ... and, in a cache line of its own behind them, the work cursor of seed_fast_kernel
-constexpr size_t kCtlWorkCursor = 128, kCtlWorkCursor2 = 192, kCtlAlloc = 256;  // (seed_select_kernel / seed_join_kernel)
+constexpr size_t kCtlWorkCursor = 128, kCtlWorkCursor2 = 192, kCtlPartStride = 128, kCtlAlloc = 1024;  // (seed_select_kernel / seed_join_kernel; one pair per part)
+static_assert(kCtlWorkCursor2 + (kMaxParts - 1) * kCtlPartStride + 64 <= kCtlAlloc, "control block layout");
 static_assert(kCtlBytes <= kCtlWorkCursor, "control block layout");
 
 }  // namespace
@@ -244,6 +254,18 @@ struct fem_dev {
   hipEvent_t ev_select_done = nullptr;
   bool have_select_done = false;
   bool no_overlap = false;
+  // The batches' H2D copies go one after the other (each waits for the previous one's): four batches committed at once —
+  // the start of every job — used to share the link, and the first one's kernels started when all four had arrived.
+  hipEvent_t ev_h2d_done = nullptr;
+  bool have_h2d_done = false;
+  hipStream_t side_stream = nullptr;  // the selections of a batch mapped in parts (beside the joins on the slot's stream)
+  bool no_parts = false;              // FEM_NO_PARTS=1 (measurement hook)
+  int max_parts = 2;                  // parts of a batch that meets an idle device (FEM_PARTS, measurement hook): two halves —
+                                      // every further launch of the join costs ~0.35 ms of ramp and tail, what a finer first part saves
+  // FEM_TIMELINE=1 (with FEM_TESTING=1 and timing on): every timed launch and copy is printed with its start and end in ms since
+  // the last fem_dev_reset_timing — the pipeline's fill and drain made visible (ids >= kTimedKernels: 20 H2D + unpack, 21 D2H)
+  bool timeline = false, have_epoch = false;
+  hipEvent_t ev_epoch = nullptr;
 };
 
 namespace {
@@ -568,12 +590,38 @@ hipEvent_t get_event(fem_dev *h) {
   return e;
 }
 
+// (timeline only) events around a copy on `st`
+struct Span {
+  fem_dev *h;
+  Slot &s;
+  hipStream_t st;
+  TimedLaunch t;
+  bool on;
+  Span(fem_dev *h_, Slot &s_, int id, hipStream_t st_) : h(h_), s(s_), st(st_), t{id, nullptr, nullptr, false}, on(h_->timing && h_->timeline) {
+    if (on) {
+      t.start = get_event(h), t.stop = get_event(h);
+      (void)hipEventRecord(t.start, st);
+    }
+  }
+  ~Span() {
+    if (on) {
+      (void)hipEventRecord(t.stop, st);
+      s.pending.push_back(t);
+    }
+  }
+};
+
 void drain_timing(fem_dev *h, Slot &s) {
   for (auto &t : s.pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && t.kernel < kTimedKernels) {
       h->t_ms[t.kernel] += ms;
-      h->t_n[t.kernel] += 1;
+      h->t_n[t.kernel] += t.counts ? 1 : 0;
+    }
+    if (h->timeline && h->have_epoch) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, h->ev_epoch, t.start) == hipSuccess && hipEventElapsedTime(&b, h->ev_epoch, t.stop) == hipSuccess)
+        fprintf(stderr, "TL slot %d id %2d  %9.3f %9.3f  (%.3f)\n", (int)(&s - h->slot), t.kernel, a, b, b - a);
     }
     h->event_pool.push_back(t.start);
     h->event_pool.push_back(t.stop);
@@ -648,13 +696,51 @@ int grow_candidates(fem_dev *h, Slot &s, uint64_t want) {
   return FEM_OK;
 }
 
+// The link is handed from one batch's copy to the next: call before and after a slot's H2D copies.
+int h2d_begin(fem_dev *h, Slot &s) {
+  if (h->have_h2d_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_h2d_done, 0));
+  return FEM_OK;
+}
+int h2d_end(fem_dev *h, Slot &s) {
+  HIP_TRY(h, hipEventRecord(h->ev_h2d_done, s.stream));
+  h->have_h2d_done = true;
+  return FEM_OK;
+}
+// No batch's kernels are pending on the device: the batch being committed starts a pipeline (it is sent and mapped in parts)
+bool device_idle(fem_dev *h) {
+  return (!h->have_kernels_done || hipEventQuery(h->ev_kernels_done) == hipSuccess) &&
+         (!h->have_select_done || hipEventQuery(h->ev_select_done) == hipSuccess);
+}
+constexpr uint64_t kPartMinReads = 1u << 16;  // a part is at least this many reads
+
 // Enqueue the two kernels of one batch on the slot's stream (asynchronous).
 int launch_batch(fem_dev *h, Slot &s) {
   const fem_params &p = s.params;
   uint32_t *d_ctr = (uint32_t *)s.d_ctl;
   unsigned long long *d_arena_ctr = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t));
   unsigned long long *d_stats = (unsigned long long *)(s.d_ctl + 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t));
-  HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlAlloc, s.stream));
+  // A batch that meets an IDLE device (the start of a job) is mapped in parts on a dense index — see below; its counters are
+  // then zeroed on the side stream, ahead of the slot's stream, which may still be busy with the rest of the batch's copy.
+  int parts = 1;
+  uint32_t part_begin[kMaxParts + 1] = {0, 0, 0, 0, 0};
+  const bool copied_in_parts = s.parts > 1;
+  {
+    const int R_ = p.e + 1 + p.a;
+    const bool dense_overlap = !h->force_generic && p.k == femk::kK && p.step == femk::kStep && R_ >= 1 && R_ <= femk::kMaxR && h->d_occ32 &&
+                               h->d_freq11 && !h->no_overlap;
+    if (dense_overlap && !h->no_parts && s.n_reads >= 2 * kPartMinReads && (copied_in_parts || device_idle(h))) {
+      parts = copied_in_parts ? s.parts : (int)std::min<uint64_t>((uint64_t)h->max_parts, s.n_reads / kPartMinReads);
+      for (int q = 0; q <= parts; ++q)
+        part_begin[q] = copied_in_parts ? s.part_begin[q] : q == parts ? (uint32_t)s.n_reads : (uint32_t)((s.n_reads * q / parts) & ~63ull);
+    }
+    s.parts = 1;  // (consumed: the slot's batch mapped again starts from the device's state then)
+  }
+  if (parts > 1) {
+    if (h->have_select_done) HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_select_done, 0));
+    HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlAlloc, h->side_stream));
+  } else {
+    HIP_TRY(h, hipMemsetAsync(s.d_ctl, 0, kCtlAlloc, s.stream));
+  }
 
   femk::SeedParams sp{};
   sp.bases = s.bases();
@@ -693,8 +779,8 @@ int launch_batch(fem_dev *h, Slot &s) {
   };
   if (sp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
 
-  auto timed = [&](int id, hipStream_t st, auto &&launch) -> int {
-    TimedLaunch t{id, nullptr, nullptr};
+  auto timed = [&](int id, hipStream_t st, auto &&launch, bool counts = true) -> int {
+    TimedLaunch t{id, nullptr, nullptr, counts};
     if (h->timing) {
       t.start = get_event(h), t.stop = get_event(h);
       HIP_TRY(h, hipEventRecord(t.start, st));
@@ -742,51 +828,78 @@ int launch_batch(fem_dev *h, Slot &s) {
       fp.n_banks = h->n_banks, fp.bank_lo = h->d_bank_lo, fp.n_buckets = (uint32_t)(h->n_lookup - 1);
       fp.blk_stride = (femk::kDenseRemap >> femk::kDenseBlkShift) + 1u;
       for (uint32_t b = 0; b <= femk::kDenseMaxBanks; ++b) fp.bank_first[b] = h->bank_first[b];
-      fp.read_begin = 0, fp.n_reads = (uint32_t)s.n_reads;
-      const uint64_t blocks_of_reads = (s.n_reads + femk::kReadBlock - 1) / femk::kReadBlock;
+      // A batch committed to an idle device (enqueue_packed: s.parts > 1) is mapped in parts: part q's selection on the side
+      // stream as soon as its characters are in HBM, its join on the slot's stream behind its selection — beside the selection
+      // of part q + 1.  Any other batch is one part, selection and join on the slot's stream as before.
       uint32_t select_lds = 0, select_threads = 256;
+      fp.lay = make_layout_select(p, max_len);
+      if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
+      const femk::SeedLayout lay_select = fp.lay;
+      femk::SeedLayout lay_join = make_layout_join(p, banked);
+      const uint32_t wpb_s = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / lay_select.wave_bytes));
+      const uint32_t wpb_j = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / lay_join.wave_bytes));
+      lay_join.picked = wpb_j * lay_join.wave_bytes;
+      const uint32_t lds_j = wpb_j * lay_join.wave_bytes + 64u * 8u;
+      const int which = banked ? 1 : h->list_shift ? 2 : 0;  // (join_kernel)
+      uint64_t per_cu_s, per_cu_j;
       {
-        fp.lay = make_layout_select(p, max_len);
-        if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
-        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / fp.lay.wave_bytes));
-        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes;
+        const uint32_t lds_bytes = wpb_s * lay_select.wave_bytes;
         const uint64_t key = ((uint64_t)banked << 48) | ((uint64_t)R << 40) | lds_bytes;
-        if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, banked, (int)(64u * wpb), lds_bytes);
-        uint64_t per_cu = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
-        if (overlap) per_cu = 1;  // (3.3 ms per 2.5 M reads of C3 with one block per CU as with five: sectors per second, not waves)
-        select_lds = lds_bytes, select_threads = 64u * wpb;
-        if (overlap && h->have_select_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_select_done, 0));
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
-        fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor);
-        rc = timed(8, s.stream, [&] { launch_select(R, banked, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
-        if (rc) return rc;
-        if (overlap) {
-          HIP_TRY(h, hipEventRecord(h->ev_select_done, s.stream));
-          h->have_select_done = true;
-          if (h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
-        }
+        if (h->select_occ_key != key) h->select_occ_key = key, h->select_occ_blocks = select_blocks_per_cu(R, banked, (int)(64u * wpb_s), lds_bytes);
+        per_cu_s = h->select_occ_blocks > 0 ? (uint64_t)h->select_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        if (overlap) per_cu_s = 1;  // (3.3 ms per 2.5 M reads of C3 with one block per CU as with five: sectors per second, not waves)
+        select_lds = lds_bytes, select_threads = 64u * wpb_s;
       }
       {
-        fp.lay = make_layout_join(p, banked);
-        const uint32_t wpb = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / fp.lay.wave_bytes));
-        fp.lay.picked = wpb * fp.lay.wave_bytes;
-        const uint32_t lds_bytes = wpb * fp.lay.wave_bytes + 64u * 8u;
-        const int which = banked ? 1 : h->list_shift ? 2 : 0;  // (join_kernel)
-        const uint64_t key = ((uint64_t)which << 48) | ((uint64_t)R << 40) | lds_bytes;
-        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, which, (int)(64u * wpb), lds_bytes);
-        uint64_t per_cu = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_bytes);
+        const uint64_t key = ((uint64_t)which << 48) | ((uint64_t)R << 40) | lds_j;
+        if (h->join_occ_key != key) h->join_occ_key = key, h->join_occ_blocks = join_blocks_per_cu(R, which, (int)(64u * wpb_j), lds_j);
+        per_cu_j = h->join_occ_blocks > 0 ? (uint64_t)h->join_occ_blocks : std::max<uint64_t>(1, 160u * 1024u / lds_j);
         if (overlap) {
           // leave one block of the next batch's seed_select_kernel room on every CU: registers (512 per lane and SIMD,
           // handed out in eights), LDS (160 KB) and wave slots (8 per SIMD) of both kernels together
           const uint32_t vj = (kernel_regs(R, true, which) + 7u) & ~7u, vs = (kernel_regs(R, false, banked ? 1 : 0) + 7u) & ~7u;
-          const uint32_t wj = 64u * wpb / 256u ? 64u * wpb / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
-          const uint32_t lj = (lds_bytes + 511u) & ~511u, ls = (select_lds + 511u) & ~511u;  // (LDS is handed out in pieces of 512 bytes)
-          while (per_cu > 1 && (per_cu * wj * vj + ws * vs > 512u || per_cu * lj + ls > 160u * 1024u || per_cu * wj + ws > 8u)) --per_cu;
+          const uint32_t wj = 64u * wpb_j / 256u ? 64u * wpb_j / 256u : 1u, ws = select_threads / 256u ? select_threads / 256u : 1u;  // waves per SIMD and block
+          const uint32_t lj = (lds_j + 511u) & ~511u, ls = (select_lds + 511u) & ~511u;  // (LDS is handed out in pieces of 512 bytes)
+          while (per_cu_j > 1 && (per_cu_j * wj * vj + ws * vs > 512u || per_cu_j * lj + ls > 160u * 1024u || per_cu_j * wj + ws > 8u)) --per_cu_j;
         }
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb - 1) / wpb, (uint64_t)h->n_cu * per_cu));
-        fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2);
-        rc = timed(0, s.stream, [&] { launch_join(R, which, dim3(grid), dim3(64u * wpb), lds_bytes, s.stream, fp); });
-        if (rc) return rc;
+      }
+      if (parts > 1 && !copied_in_parts) {  // (the copy went whole, on the slot's stream: the side stream starts behind it)
+        HIP_TRY(h, hipEventRecord(s.ev_zeroed, s.stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->side_stream, s.ev_zeroed, 0));
+      }
+      for (int q = 0; q < parts; ++q) {
+        const uint32_t r_lo = parts > 1 ? part_begin[q] : 0u, r_hi = parts > 1 ? part_begin[q + 1] : (uint32_t)s.n_reads;
+        const uint64_t blocks_of_reads = ((uint64_t)(r_hi - r_lo) + femk::kReadBlock - 1) / femk::kReadBlock;
+        fp.read_begin = r_lo, fp.n_reads = r_hi;
+        hipStream_t st_sel = parts > 1 ? h->side_stream : s.stream;
+        {
+          fp.lay = lay_select;
+          if (parts > 1) {
+            if (copied_in_parts) HIP_TRY(h, hipStreamWaitEvent(st_sel, s.ev_part[q], 0));
+          } else if (overlap && h->have_select_done) {
+            HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_select_done, 0));
+          }
+          const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb_s - 1) / wpb_s, (uint64_t)h->n_cu * per_cu_s));
+          fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor + (size_t)q * kCtlPartStride);
+          rc = timed(8, st_sel, [&] { launch_select(R, banked, dim3(grid), dim3(64u * wpb_s), select_lds, st_sel, fp); }, q == 0);
+          if (rc) return rc;
+          if (parts > 1) {
+            HIP_TRY(h, hipEventRecord(s.ev_sel[q], st_sel));
+            HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_sel[q], 0));
+          }
+          if (overlap && q + 1 == parts) {
+            HIP_TRY(h, hipEventRecord(h->ev_select_done, st_sel));
+            h->have_select_done = true;
+          }
+          if (overlap && q == 0 && h->have_kernels_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_kernels_done, 0));
+        }
+        {
+          fp.lay = lay_join;
+          const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((blocks_of_reads + wpb_j - 1) / wpb_j, (uint64_t)h->n_cu * per_cu_j));
+          fp.work_cursor = (uint32_t *)(s.d_ctl + kCtlWorkCursor2 + (size_t)q * kCtlPartStride);
+          rc = timed(0, s.stream, [&] { launch_join(R, which, dim3(grid), dim3(64u * wpb_j), lds_j, s.stream, fp); }, q == 0);
+          if (rc) return rc;
+        }
       }
       sp.work_queue = s.d_slow;  // the generic kernel finishes what the two queued
     } else if (use_fast) {
@@ -846,6 +959,7 @@ int launch_batch(fem_dev *h, Slot &s) {
   // (only behind fem_dev_stage_reads, whose caller packs the next batch in the meantime; a caller of the zero-copy form is
   // idle until it fetches, and the extra traffic next to its four-times-larger H2D cost 5 % there)
   if (s.prefetch_results && s.staged_by_copy && !no_prefetch) {
+    Span span(h, s, 21, s.stream);
     const size_t n2 = (size_t)s.n_reads * 2;
     if (n2 && s.h_begin && n2 <= s.h_per_read_cap) {
       HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
@@ -1043,12 +1157,30 @@ int enqueue_packed(fem_dev *h, Slot &s, uint64_t n, uint32_t len, uint64_t n_exc
   if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n + 1))) return rc;
   if ((rc = dev_realloc(h, &s.d_exc_bits, &s.exc_bits_cap, (size_t)n / 32 + 2))) return rc;
-  if (total) HIP_TRY(h, hipMemcpyAsync(s.d_packed, s.h_bases, total, hipMemcpyHostToDevice, s.stream));
-  if (n) {
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
-    hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed, n, len, bpr, s.bases());
-  }
+  // parts: only where nothing is pending on the device (the start of a job), for batches without exceptions (their scatter
+  // follows the whole batch) and of some size
+  s.parts = 1;
+  if (!h->no_parts && !h->no_overlap && n_exc == 0 && n >= 2 * kPartMinReads && device_idle(h))
+    s.parts = (int)std::min<uint64_t>((uint64_t)h->max_parts, n / kPartMinReads);
+  for (int q = 0; q <= s.parts; ++q) s.part_begin[q] = q == s.parts ? (uint32_t)n : (uint32_t)((n * q / s.parts) & ~63ull);
   HIP_TRY(h, hipMemsetAsync(s.d_exc_bits, 0, ((size_t)n / 32 + 1) * sizeof(uint32_t), s.stream));
+  hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
+                     s.stream, s.d_off, n, len);
+  if ((rc = h2d_begin(h, s))) return rc;
+  for (int q = 0; q < s.parts; ++q) {
+    const uint64_t r0 = s.part_begin[q], r1 = s.part_begin[q + 1];
+    // (the last part takes the codes' padding and the exceptions along)
+    const uint64_t b0 = r0 * bpr, b1 = q + 1 == s.parts ? total : r1 * bpr;
+    Span span(h, s, 20, s.stream);
+    if (b1 > b0) HIP_TRY(h, hipMemcpyAsync(s.d_packed + b0, s.h_bases + b0, b1 - b0, hipMemcpyHostToDevice, s.stream));
+    if (r1 > r0) {
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(((r1 - r0) * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
+      hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed + b0, r1 - r0, len, bpr,
+                         s.bases() + r0 * len);
+    }
+    if (s.parts > 1) HIP_TRY(h, hipEventRecord(s.ev_part[q], s.stream));
+  }
+  if ((rc = h2d_end(h, s))) return rc;
   if (n_exc) {
     const dim3 g((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u));
     hipLaunchKernelGGL(femk::scatter_chars_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes),
@@ -1057,8 +1189,6 @@ int enqueue_packed(fem_dev *h, Slot &s, uint64_t n, uint32_t len, uint64_t n_exc
                        s.d_exc_bits);
   }
   s.packed_bpr = bpr;
-  hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
-                     s.stream, s.d_off, n, len);
   HIP_TRY(h, hipGetLastError());
   s.n_reads = n, s.n_bases = n_bases, s.max_len = len;
   s.staged = true, s.mapped = false, s.synced = false;
@@ -1113,15 +1243,28 @@ int fem_dev_open(int device, fem_dev **out) {
       return FEM_ERR_HIP;
     }
   }
-  if (hipEventCreateWithFlags(&h->ev_kernels_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_select_done, hipEventDisableTiming) != hipSuccess) {
-    delete h;
+  bool ok_ev = hipEventCreateWithFlags(&h->ev_kernels_done, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&h->ev_select_done, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&h->ev_h2d_done, hipEventDisableTiming) == hipSuccess &&
+               hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok_ev && i < kSlots; ++i) {
+    Slot &sl = h->slot[i];
+    ok_ev = hipEventCreateWithFlags(&sl.ev_zeroed, hipEventDisableTiming) == hipSuccess;
+    for (int q = 0; ok_ev && q < kMaxParts; ++q)
+      ok_ev = hipEventCreateWithFlags(&sl.ev_part[q], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sl.ev_sel[q], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok_ev) {
+    (void)fem_dev_close(h);
     return FEM_ERR_HIP;
   }
   // Kernel-choice and buffer-size overrides exist for the parity tests and for A/B measurements only: a production process
   // does not look at its environment for them unless FEM_TESTING=1 says so.
   if (testing_switch("FEM_TESTING")) {
     h->no_overlap = testing_switch("FEM_NO_OVERLAP");
+    h->no_parts = testing_switch("FEM_NO_PARTS");
+    if (const char *mp = getenv("FEM_PARTS")) h->max_parts = std::min(kMaxParts, std::max(1, atoi(mp)));
+    h->timeline = testing_switch("FEM_TIMELINE");
     h->force_generic = testing_switch("FEM_FORCE_GENERIC");
     h->force_hash = testing_switch("FEM_FORCE_HASH");
     h->force_dense = testing_switch("FEM_FORCE_DENSE");
@@ -1164,6 +1307,17 @@ int fem_dev_close(fem_dev *h) {
   for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
   if (h->ev_kernels_done) (void)hipEventDestroy(h->ev_kernels_done);
   if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
+  if (h->ev_h2d_done) (void)hipEventDestroy(h->ev_h2d_done);
+  if (h->ev_epoch) (void)hipEventDestroy(h->ev_epoch);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  for (int i = 0; i < kSlots; ++i) {
+    Slot &sl = h->slot[i];
+    if (sl.ev_zeroed) (void)hipEventDestroy(sl.ev_zeroed);
+    for (int q = 0; q < kMaxParts; ++q) {
+      if (sl.ev_part[q]) (void)hipEventDestroy(sl.ev_part[q]);
+      if (sl.ev_sel[q]) (void)hipEventDestroy(sl.ev_sel[q]);
+    }
+  }
   for (void *p : {(void *)h->d_lookup, (void *)h->d_occ, (void *)h->d_ref_raw, (void *)h->d_seq_off,
                   (void *)h->d_seq_len, (void *)h->d_summary, (void *)h->d_planes, (void *)h->d_occ32, (void *)h->d_goff, (void *)h->d_blkseq,
                   (void *)h->d_freq11, (void *)h->d_bank_lo})
@@ -1337,8 +1491,11 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
   HIP_TRY(h, hipSetDevice(h->device));
   if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if ((rc = h2d_begin(h, s))) return rc;
   if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), s.h_bases, n_bases, hipMemcpyHostToDevice, s.stream));
   if (n_reads) HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  if ((rc = h2d_end(h, s))) return rc;
+  s.parts = 1;
   s.n_reads = n_reads, s.n_bases = n_bases, s.max_len = max_len;
   s.staged = true, s.mapped = false, s.synced = false;
   s.h2d_bytes = n_bases + (n_reads ? (n_reads + 1) * sizeof(uint64_t) : 0), s.sent_packed = false, s.staged_by_copy = false;
@@ -1357,7 +1514,10 @@ int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_
   HIP_TRY(h, hipSetDevice(h->device));
   if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if ((rc = h2d_begin(h, s))) return rc;
   if (n_bases) HIP_TRY(h, hipMemcpyAsync(s.bases(), s.h_bases, n_bases, hipMemcpyHostToDevice, s.stream));
+  if ((rc = h2d_end(h, s))) return rc;
+  s.parts = 1;
   hipLaunchKernelGGL(femk::uniform_offsets_kernel, dim3((uint32_t)std::min<uint64_t>((n_reads + 256) / 256, (uint64_t)h->n_cu * 8u)), dim3(256), 0,
                      s.stream, s.d_off, n_reads, read_len);
   HIP_TRY(h, hipGetLastError());
@@ -1823,6 +1983,12 @@ int fem_dev_set_timing(fem_dev *h, int on) {
 int fem_dev_reset_timing(fem_dev *h) {
   if (!h) return FEM_ERR_INVALID;
   for (int i = 0; i < kTimedKernels; ++i) h->t_ms[i] = 0, h->t_n[i] = 0;
+  if (h->timeline) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->ev_epoch) HIP_TRY(h, hipEventCreate(&h->ev_epoch));
+    HIP_TRY(h, hipEventRecord(h->ev_epoch, h->side_stream));
+    h->have_epoch = true;
+  }
   return FEM_OK;
 }
 

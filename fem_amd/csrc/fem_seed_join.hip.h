@@ -45,6 +45,11 @@ namespace femk {
 #ifndef FEM_JOIN_OPT_HI
 #define FEM_JOIN_OPT_HI 12
 #endif
+// Attribution builds (results WRONG, instruction counts and times only; scratch/abl_join.sh): bit 1 no flagged values kept,
+// 2 no exact filter, 4 no marks, 8 bitmap not cleared, 16 no emission, 32 units skipped whole, 64 no insert / window / flag
+#ifndef FEM_JOIN_ABL
+#define FEM_JOIN_ABL 0
+#endif
 constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
 // Chunks whose LDS steps are issued together at R >= 7 (see join_read).  Round 3: one — with the 80 registers of six waves per
 // SIMD five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134).  Round 4,
@@ -160,6 +165,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     return lds_or_rtn(word_of(v, 8u), bit) & bit;
   };
   auto mark = [&](uint32_t v, uint32_t hit) {  // second value of a slot: both neighbours "present"
+    if (FEM_JOIN_ABL & 4) {
+      asm volatile("" ::"v"(hit));
+      return;
+    }
     if (hit) {
       const uint32_t qm = (v >> 3) - 1u, qp = (v >> 3) + 1u;
       lds_or(word_of(qm, 5u), 1u << (qm & 31u));
@@ -211,7 +220,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
     if (u + 1u < kUnits) prefetch(u + 1u);
     // fewer than a+1 occurrences: nothing can pass the filter; no list but the last seed's: it is merged only while
     // the list has elements (src/filter.c:85)
-    const bool skip = n_g <= (uint32_t)p.a || (n_g == f[R - 1] && !keep_all);
+    const bool skip = (FEM_JOIN_ABL & 32) || n_g <= (uint32_t)p.a || (n_g == f[R - 1] && !keep_all);
     uint32_t n_flag = 0;
     uint32_t *flg_g = flg + g * kFlgStride;
     if (kOptPairs) {  // behind the unit's flagged values the array reads "no value": the all-pairs filter compares whole rows
@@ -357,6 +366,10 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         // cut from the top — stores its sentinel at the place the next flagged value will take, or behind the last one,
         // where the exact filter reads it as "no value" (it lies above every coordinate).
         auto flag_chunk = [&](uint32_t v, uint32_t xw, uint64_t valid, bool exact) {
+          if (FEM_JOIN_ABL & 1) {
+            asm volatile("" ::"v"(xw), "v"(v));
+            return;
+          }
           bool near = xw >= kNearTop;
           if (exact) near = near && v < kDenseVLimit;
           const uint64_t m = exact ? __builtin_amdgcn_ballot_w64(near) : __builtin_amdgcn_ballot_w64(near) & valid;
@@ -408,13 +421,18 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
               }
           }
         };
+        if (FEM_JOIN_ABL & 64) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) asm volatile("" ::"v"(val[t]), "v"(hv[t]));
+        } else {
         insert_all(val, !kOptSent, false);
         if (long_lists) insert_all(hv, true, true);
         wave_sync_lds();
         if (!kOptSent || __builtin_expect(remap, 0)) flag_all(val, false, true); else flag_all(val, false, false);
         if (long_lists) flag_all(hv, true, true);  // (second chunks keep the compare against the sentinel: they are the exception)
         wave_sync_lds();
-        {  // leave the bitmap clean: every lane clears its 16-byte pieces (the guard word sits behind them)
+        }
+        if (!(FEM_JOIN_ABL & 8)) {  // leave the bitmap clean: every lane clears its 16-byte pieces (the guard word sits behind them)
           uint4 *b4 = (uint4 *)bitmap;
 #pragma unroll
           for (uint32_t k = 0; k < kWords / 4u / (uint32_t)kWave; ++k) b4[k * (uint32_t)kWave + ln] = make_uint4(0u, 0u, 0u, 0u);
@@ -468,7 +486,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
         wave_sync_lds();
       }
     }
-    if (n_flag > (uint32_t)p.a) {
+    if (!(FEM_JOIN_ABL & 2) && n_flag > (uint32_t)p.a) {
       // ---- exact window filter on the flagged values: v stays iff a+1 of them lie in [v, v+e] (itself included) ----
       const bool have = ln < n_flag;
       uint32_t fv;
@@ -742,6 +760,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
         queue_slow(read);
         continue;
       }
+      if (FEM_JOIN_ABL & 16) kept0 = kept1 = 0;
       pre_sum += (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, (int)rb);
       // ---- back to (sequence, position), remove_out_ranged_candidates (src/filter.c:133-144), hand-over ----
 #pragma unroll 1
