@@ -1061,7 +1061,7 @@ int refresh_dense(fem_dev *h) {
   // by the hash alone).  Where it does not fit, and for references in banks (whose lists are cut at bank_lo), the compact one.
   uint32_t list_shift = 0;
   if (n_banks == 1 && !h->no_strided) {
-    const size_t words = ((size_t)n_buckets << femk::kDenseListShift) + 256;
+    const size_t words = ((size_t)n_buckets + femk::kDensePadBuckets) << femk::kDenseListShift;
     bool ok = hipMalloc((void **)&h->d_occ32, words * sizeof(uint32_t)) == hipSuccess;
     if (ok) {  // every slot reads "pad" (fem_seed_dense.hip.h) until dense_occ32_strided_kernel writes a bucket's entries over its first ones
       hipLaunchKernelGGL(femk::dense_pad_kernel, dim3((uint32_t)h->n_cu * 16u), dim3(256), 0, 0, (uint4 *)h->d_occ32, (uint64_t)(words / 4));

@@ -1395,8 +1395,9 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   // fetched one per step (16 columns = microseconds apart at eight waves per SIMD) every chunk missed the L1 again
   // (1.26 -> 1.14 ms at C2).  Eight chunks at once cost three waves per SIMD and were slower.
   constexpr int kStageChunks = 4;
+  // (16 KB exactly, the block sums laid over it at the end)
   __shared__ uint4 stage[kStageChunks][256];
-  __shared__ uint32_t part[2][4];
+  uint32_t(*part)[4] = (uint32_t(*)[4]) & stage[0][0];
   uint32_t mappings = 0, mapped = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const uint32_t meta = p.cand_meta[i];
@@ -1496,6 +1497,7 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   // one pair of atomics per block (same-address atomics complete at ~10 ns each: a pair per wave had cost more than the
   // verification itself)
   for (int d = 32; d >= 1; d >>= 1) mappings += __shfl_xor(mappings, d), mapped += __shfl_xor(mapped, d);
+  __syncthreads();  // (every wave is through with its staged chunks)
   if (lane_id() == 0) part[0][threadIdx.x >> 6] = mappings, part[1][threadIdx.x >> 6] = mapped;
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -39,12 +39,18 @@ constexpr uint32_t kDenseMaxSeq = 1u << 18;
 constexpr uint32_t kDenseLimit = 0xDFFFF000u;  // global coordinates stay below this (round 5: 0xEFFFF000 before; the room above is the pads')
 constexpr uint32_t kDenseSent = 0xEFFFFFFFu;   // "no entry" in a lane: still above kDenseVLimit after the start is subtracted
 constexpr uint32_t kDenseVLimit = 0xDFFFF800u; // v < this <=> the lane holds a real entry
-// PADS of the strided table (round 5): behind a bucket's f entries its slots j = f .. 127 hold kDensePadBase + j * kDensePadStride — above
-// every coordinate (also once a seed's start, < 1 024, is subtracted), below kDenseRemap, and such that within one unit of
-// the join no two lanes without an entry land in one slot of its bitmap (starts within a unit are at least 12 apart) nor
-// consecutive lanes in one LDS bank (2 304 = 9 words of the bitmap): what sent_a of seed_join_kernel was in round 4, but
-// it now comes with the load — no clamped lane offset, no compare, no select per chunk.
+// PADS of the strided table (round 5): behind bucket h's f entries its slots j = f .. 127 hold
+// kDensePadBase + j * kDensePadStride + pad_shift(h) — above every coordinate (also once a seed's start, < 1 024, is
+// subtracted), below kDenseRemap, consecutive lanes in different LDS banks (2 304 = 9 words of the join's bitmap).  What
+// sent_a of seed_join_kernel was in round 4, but it comes with the load: no clamped lane offset, no compare, no select per
+// chunk.  The join does not ask which lanes hold entries at all: a pad is a value like any other that can pair with no REAL
+// value (they lie 2^28 below), and whatever survives the filter is tested for being a coordinate.  pad_shift — a multiple
+// of 36 below the lane stride, by a hash of the bucket — keeps the pads of a unit's runs (different buckets, starts 12 or
+// more apart) out of each other's neighbouring slots but for chance: without it the same lane's pads of two runs sat 12
+// to 24 positions apart and flagged each other in every unit.
 constexpr uint32_t kDensePadBase = 0xE0001000u, kDensePadStride = 2304u;
+constexpr uint32_t kDensePadBuckets = 16u;  // buckets of nothing but pads behind the table: run t of a unit whose seed has no list reads bucket n_buckets + t
+__host__ __device__ inline uint32_t dense_pad_shift(uint32_t h) { return ((h * 0x9E3779B1u) >> 26) * 36u; }
 constexpr uint32_t kDenseBlkShift = 20;        // blkseq[] granularity: first sequence at or before a 1 Mi block
 constexpr uint32_t kDenseMaxList = 128u;       // entries of one seed's list the join takes (two chunks)
 
@@ -93,14 +99,15 @@ __global__ void dense_occ32_kernel(const uint64_t *occ, uint64_t n, const uint32
 // kernel (which reads the 64-bit table) as before.  Blocks of 256 buckets: their entries are one contiguous stretch of occ.
 constexpr uint32_t kDenseListShift = 7;
 static_assert((1u << kDenseListShift) == kDenseMaxList, "a strided slot holds exactly the lists the join takes");
-static_assert(kDensePadBase - kDenseNear >= kDenseVLimit && kDensePadBase + kDenseMaxList * kDensePadStride < kDenseRemap, "pads between the coordinates and the remapped entries");
+static_assert(kDensePadBase - kDenseNear >= kDenseVLimit && kDensePadBase + kDenseMaxList * kDensePadStride + 64u * 36u < kDenseRemap, "pads between the coordinates and the remapped entries");
+static_assert(63u * 36u < kDensePadStride, "the shift stays inside a lane's stride");
 // every slot of the strided table reads "pad" before the entries are written over it
 __global__ void __launch_bounds__(256) dense_pad_kernel(uint4 *out, uint64_t n_quads) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += stride) {
     const uint32_t j = ((uint32_t)i * 4u) & (kDenseMaxList - 1u);
-    out[i] = make_uint4(kDensePadBase + j * kDensePadStride, kDensePadBase + (j + 1u) * kDensePadStride, kDensePadBase + (j + 2u) * kDensePadStride,
-                        kDensePadBase + (j + 3u) * kDensePadStride);
+    const uint32_t b = kDensePadBase + dense_pad_shift((uint32_t)(i >> (kDenseListShift - 2u)));
+    out[i] = make_uint4(b + j * kDensePadStride, b + (j + 1u) * kDensePadStride, b + (j + 2u) * kDensePadStride, b + (j + 3u) * kDensePadStride);
   }
 }
 __global__ void __launch_bounds__(256) dense_occ32_strided_kernel(const uint64_t *occ, const uint32_t *lookup, uint32_t n_buckets, const uint32_t *goff,

@@ -409,8 +409,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEM_SE
           for (int t = 0; t < R; ++t) {
             const uint32_t f = key[t] >> 14, sidx = key[t] & 1023u;
             // (a seed that was never taken, or whose bucket is empty: in the strided table its "list" is the stretch of pads
-            //  behind the last bucket — seed_join_kernel reads a run's first chunk whatever its length)
-            lo[t] = !BANKED && p.list_shift ? p.n_buckets << p.list_shift : 0u, hs[t] = 0;
+            //  behind the last bucket, one bucket of them per run — seed_join_kernel reads a run's first chunk whatever its length)
+            lo[t] = !BANKED && p.list_shift ? (p.n_buckets + (uint32_t)t) << p.list_shift : 0u, hs[t] = 0;
             if (f != 0u) {
               const uint32_t j = strand ? S - 1u - sidx : sidx;
               const uint32_t hf = stream_window(fw, base + j) >> 8;
