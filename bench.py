@@ -157,6 +157,10 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         torch.cuda.synchronize()
 
     d2h_bytes = [0]
+    # fem_dev_fetch_packed (11.4 instead of 30.8 bytes per read home at C2) where the index is sparse: C2 1 015-1 029 -> 1 078-1 092
+    # Mreads/s.  On a dense index its packing kernel has to sit in the chain of the batches' kernels (0.07 ms, and the join
+    # behind it starts 0.1 ms later): C3 322-327 -> 317-318, so C3 / C5 fetch the plain form.  FEM_BENCH_FETCH=plain|packed forces one.
+    packed_fetch = {"plain": False, "packed": True}.get(os.environ.get("FEM_BENCH_FETCH", ""), key == "c2")
     form = ["packed_commit"]
     host_s = [0.0, 0.0]  # seconds this rank's thread spent in the staging call (enqueueing; packing in the stage_reads form) / waiting in the fetch
     seen = [[] for _ in range(N_SLOTS)]  # the five counters of every batch retired, per slot
@@ -188,13 +192,24 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             seen[sl].append(st.copy())
             return st
         t_in = time.perf_counter()
+        if form[0] == "packed_commit" and packed_fetch:
+            # fem_dev_fetch_packed: one byte per strand, one offset per 256 strands, 11 bytes per candidate and none per padding
+            # slot (include/fem_hip.h) — packed on the device and sent home behind the batch's kernels
+            r = dev.fetch_packed(slot=sl, copy=False)
+            host_s[1] += time.perf_counter() - t_in
+            d2h_bytes[0] = r.d2h_bytes
+            seen[sl].append(r.stats.copy())
+            if keep.pop(sl, False):
+                n_chk = min(batch, CHECK_READS)
+                kept[sl] = ("packed", r.count[:2 * n_chk].copy(), r.seg_begin[:(2 * n_chk + 255) // 256].copy(), r.cand.copy(), r.ed.copy(), r.end.copy())
+            return r.stats
         r = dev.fetch(slot=sl, copy=False)  # waits; the per-candidate outcome is (or comes) in pinned host memory
         host_s[1] += time.perf_counter() - t_in
         d2h_bytes[0] = 16 * r.n_reads + 11 * r.n_candidates
         seen[sl].append(r.stats.copy())
         if keep.pop(sl, False):
             n_chk = min(batch, CHECK_READS)
-            kept[sl] = (r.cand_begin[:2 * n_chk].copy(), r.cand_count[:2 * n_chk].copy(), r.cand.copy(), r.ed.copy(), r.end.copy())
+            kept[sl] = ("plain", r.cand_begin[:2 * n_chk].copy(), r.cand_count[:2 * n_chk].copy(), r.cand.copy(), r.ed.copy(), r.end.copy())
         return r.stats
 
     trace = []  # FEM_BENCH_TRACE=1: (what, step, seconds) of every submit / retire of the timed region (fill and drain made visible)
@@ -253,6 +268,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         if rep == 0:
             job, last_stats = job_r, last_r
             host_first = (host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps)
+            d2h_timed = d2h_bytes[0]  # (of the timed steps' form; the comparison forms below fetch the plain arrays)
     dev.set_timing(False)
     elapsed, kt = runs[0]
 
@@ -412,7 +428,8 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
                    "max": round(max(values), 3), "values": [round(v, 3) for v in values]},
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
-        "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_bytes[0],
+        "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_timed,
+        "fetch_form": "fem_dev_fetch_packed" if packed_fetch else "fem_dev_fetch",
         "stage_reads_mreads": None if stage_reads_rate is None else round(stage_reads_rate, 3),
         "zero_copy_ascii_mreads": None if zero_copy is None else round(zero_copy, 3), "zero_copy_h2d_bytes_per_step": int(h2d_zero_copy),
         "priming_steps": priming, "pipeline_check": pipe_check,
@@ -488,7 +505,17 @@ def check_prefix_against_oracle(fo, ref, idx, w, data, pipe_check, threads):
     if kept is None:
         return None
     text, off, lens = data
-    cand_begin, cand_count, cand, ed, end = kept
+    if kept[0] == "packed":  # fem_batch_packed: counts per strand, where each segment of 256 strands starts
+        _, count8, seg_begin, cand, ed, end = kept
+        assert not np.any(count8 == 255)
+        n_seg = len(seg_begin)
+        pad = np.zeros(n_seg * 256, dtype=np.int64)
+        pad[:len(count8)] = count8
+        within = np.cumsum(pad.reshape(n_seg, 256), axis=1) - pad.reshape(n_seg, 256)
+        cand_begin = (seg_begin.astype(np.int64)[:, None] + within).reshape(-1)[:len(count8)]
+        cand_count = count8.astype(np.uint32)
+    else:
+        _, cand_begin, cand_count, cand, ed, end = kept
     n_chk = len(cand_begin) // 2
     bases, offsets = host.synth_reads(w["seed"], text, off, lens, n_chk, w["L"], w["e"], first_read=pipe_check["_first_read"], threads=threads)
     want = fo.map_reads(ref, idx, fo.ReadBatch.from_arrays(bases, offsets), e=w["e"], a=1, threads=threads, stages=fo.STAGE_SEED | fo.STAGE_VERIFY)
@@ -746,7 +773,7 @@ def main():
         "roofline_by_workload": {k_: {"dominant_kernel": v_["roofline"], "step": v_["roofline_step"]} for k_, v_ in results.items()},
         "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
                                                            "reads_per_step_per_gpu", "kernel_ms_per_launch", "kernel_ms_alone", "counters_last_step_per_gpu",
-                                                           "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step",
+                                                           "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step", "fetch_form",
                                                            "stage_reads_mreads", "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps",
                                                            "host_ms_per_step", "spread", "pipeline_check")}
                                  for k_, v_ in results.items()},

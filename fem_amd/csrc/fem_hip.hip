@@ -40,7 +40,7 @@ constexpr uint32_t kMaxReadLen = 1024;
 constexpr size_t kFrontPad = 16;  // kernels fetch a reverse-strand chunk from up to 15 bytes in front of a read
 constexpr uint32_t kXcapSmall = 512, kFcap = 128, kCcap = 128;
 
-constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 verify, 2 generic seed, 3-5 tail, 6 unused (the count kernel of rounds 1-2), 7 SAM text, 8 seed selection
+constexpr int kTimedKernels = 10;  // fem_dev_kernel_time ids: 0 seed (join), 1 verify, 2 generic seed, 3-5 tail, 6 pack_results_kernel (round 5; the count kernel of rounds 1-2 before), 7 SAM text, 8 seed selection
 struct TimedLaunch {
   int kernel;
   hipEvent_t start, stop;
@@ -92,6 +92,7 @@ struct Slot {
   uint32_t part_begin[kMaxParts + 1] = {0, 0, 0, 0, 0};
   hipEvent_t ev_part[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_sel[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_zeroed = nullptr;
+  hipEvent_t ev_results = nullptr, ev_home = nullptr;  // the batch's results are final on the device / have arrived on the host
   // outputs on the device
   uint64_t *d_cand = nullptr;
   uint32_t *d_meta = nullptr;
@@ -117,6 +118,24 @@ struct Slot {
   uint8_t *h_ed = nullptr;
   int16_t *h_end = nullptr;
   size_t h_cand_cap = 0;
+  // the outcome in the form that crosses the link (fem_dev_fetch_packed; pack_results_kernel): on the device, pinned on the host
+  uint8_t *d_count8 = nullptr, *d_ped = nullptr;
+  uint32_t *d_seg = nullptr;
+  uint64_t *d_pcand = nullptr;
+  int16_t *d_pend = nullptr;
+  uint2 *d_big = nullptr;
+  size_t count8_cap = 0, seg_cap = 0, pcand_cap = 0;
+  uint8_t *h_count8 = nullptr, *h_ped = nullptr;
+  uint32_t *h_seg = nullptr;
+  uint64_t *h_pcand = nullptr;
+  int16_t *h_pend = nullptr;
+  uint2 *h_big = nullptr;
+  size_t h_count8_cap = 0, h_seg_cap = 0, h_pcand_cap = 0;
+  bool want_packed = false;    // the slot's last fetch was fem_dev_fetch_packed: launch_batch packs and sends home behind the kernels
+  bool packed_enqueued = false;  // pack_results_kernel ran (or is queued) for the slot's current batch
+  uint64_t packed_home = 0, last_n_packed = 0;  // packed candidates copied home behind the kernels / of the slot's previous batch
+  bool packed_per_read_home = false;
+  uint32_t n_packed = 0, n_big = 0;
   // state of the last launch
   fem_params params{};
   bool mapped = false, synced = false;
@@ -126,8 +145,10 @@ struct Slot {
   femt::Tail *tail = nullptr;  // device mapping tail (fem_dev_fetch_records), created on first use
 };
 
-// ctr[4] | arena_ctr[2] | stats[4]
-constexpr size_t kCtlBytes = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);
+// ctr[4] | arena_ctr[2] | stats[4] | pack cursor[2]
+constexpr size_t kCtlPackCursor = 4 * sizeof(uint32_t) + 2 * sizeof(uint64_t) + 4 * sizeof(uint64_t);  // pack_results_kernel: packed candidates, big[] entries
+constexpr size_t kCtlBytes = kCtlPackCursor + 2 * sizeof(uint32_t);
+constexpr uint32_t kBigCap = 4096;  // strands with 255 candidates and more that a packed result lists (beyond: fetch the plain form)
 // ... and, in a cache line of its own behind them, the work cursor of seed_fast_kernel
 constexpr size_t kCtlWorkCursor = 128, kCtlWorkCursor2 = 192, kCtlPartStride = 128, kCtlAlloc = 1024;  // (seed_select_kernel / seed_join_kernel; one pair per part)
 static_assert(kCtlWorkCursor2 + (kMaxParts - 1) * kCtlPartStride + 64 <= kCtlAlloc, "control block layout");
@@ -713,6 +734,95 @@ bool device_idle(fem_dev *h) {
 }
 constexpr uint64_t kPartMinReads = 1u << 16;  // a part is at least this many reads
 
+// The stream a slot's results go home on: its own.  (Tried: one stream for every slot's results behind an event of the slot's
+// stream — consistent 0.63 ms per 32 MB where a slot's own stream takes 0.6 to 1.5 beside the next batch's H2D copy, but the
+// calls that enqueue the copies then kept the host until the batch's kernels were through: 326 -> 284 Mreads/s.  Ten streams
+// timed one by one all copy at 54 GB/s: the slow copies are the link shared with the other direction, not a slow engine.)
+hipStream_t d2h_begin(fem_dev *h, Slot &s) {
+  (void)h;
+  return s.stream;
+}
+// ... and the slot's stream (what fem_dev_sync waits for) continues behind them.
+int d2h_end(fem_dev *h, Slot &s, hipStream_t st) {
+  if (st == s.stream) return FEM_OK;
+  HIP_TRY(h, hipEventRecord(s.ev_home, st));
+  HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_home, 0));
+  return FEM_OK;
+}
+
+// pack_results_kernel behind the slot's verification, and (send_home) the packed arrays' copies behind it: the per-strand
+// bytes and the segment table whole, the per-candidate arrays up to what the slot's previous batch needed (the rest at fetch).
+int enqueue_pack(fem_dev *h, Slot &s, bool kernel, bool send_home) {
+  const size_t n2 = (size_t)s.n_reads * 2, n_seg = (n2 + 255) / 256;
+  int rc;
+  if ((rc = dev_realloc(h, &s.d_count8, &s.count8_cap, n2 + 16))) return rc;
+  if ((rc = dev_realloc(h, &s.d_seg, &s.seg_cap, n_seg + 4))) return rc;
+  if (s.pcand_cap < s.cand_cap || !s.d_pcand) {
+    for (void *q : {(void *)s.d_pcand, (void *)s.d_ped, (void *)s.d_pend})
+      if (q) (void)hipFree(q);
+    s.d_pcand = nullptr, s.d_ped = nullptr, s.d_pend = nullptr, s.pcand_cap = 0;
+    HIP_TRY(h, hipMalloc((void **)&s.d_pcand, (size_t)s.cand_cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc((void **)&s.d_ped, (size_t)s.cand_cap * sizeof(uint8_t)));
+    HIP_TRY(h, hipMalloc((void **)&s.d_pend, (size_t)s.cand_cap * sizeof(int16_t)));
+    s.pcand_cap = s.cand_cap;
+  }
+  if (!s.d_big) HIP_TRY(h, hipMalloc((void **)&s.d_big, kBigCap * sizeof(uint2)));
+  if (n2 + 16 > s.h_count8_cap || !s.h_count8) {
+    if (s.h_count8) (void)hipHostFree(s.h_count8);
+    s.h_count8 = nullptr, s.h_count8_cap = 0;
+    if ((rc = pinned_realloc(h, &s.h_count8, &s.h_count8_cap, n2 + 16))) return rc;
+  }
+  if (n_seg + 4 > s.h_seg_cap || !s.h_seg) {
+    if (s.h_seg) (void)hipHostFree(s.h_seg);
+    s.h_seg = nullptr, s.h_seg_cap = 0;
+    if ((rc = pinned_realloc(h, &s.h_seg, &s.h_seg_cap, n_seg + 4))) return rc;
+  }
+  if (!s.h_big) {
+    size_t c = 0;
+    if ((rc = pinned_realloc(h, &s.h_big, &c, (size_t)kBigCap))) return rc;
+  }
+  if (kernel) {
+  femk::PackParams pp{};
+  pp.cand_begin = s.d_begin, pp.cand_count = s.d_count, pp.cand = s.d_cand, pp.ed = s.d_ed, pp.end = s.d_end;
+  pp.ctr = (const uint32_t *)s.d_ctl, pp.n_strands = (uint32_t)n2;
+  pp.count8 = s.d_count8, pp.seg_begin = s.d_seg, pp.pcand = s.d_pcand, pp.ped = s.d_ped, pp.pend = s.d_pend, pp.pcap = (uint32_t)s.pcand_cap;
+  pp.cursor = (uint32_t *)(s.d_ctl + kCtlPackCursor), pp.big = s.d_big, pp.big_cap = kBigCap;
+  const uint32_t grid = (uint32_t)std::max<size_t>(1, (n_seg + femk::kPackSegs - 1) / femk::kPackSegs);  // (a block per sixteen segments)
+  {
+    TimedLaunch t{6, nullptr, nullptr, true};  // (kernel id 6: pack_results_kernel)
+    if (h->timing) {
+      t.start = get_event(h), t.stop = get_event(h);
+      HIP_TRY(h, hipEventRecord(t.start, s.stream));
+    }
+    hipLaunchKernelGGL(femk::pack_results_kernel, dim3(grid), dim3(256), 0, s.stream, pp);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) {
+      HIP_TRY(h, hipEventRecord(t.stop, s.stream));
+      s.pending.push_back(t);
+    }
+  }
+  s.packed_enqueued = true;
+  }
+  if (send_home) {
+    hipStream_t st = d2h_begin(h, s);
+    {
+      Span span(h, s, 21, st);
+      HIP_TRY(h, hipMemcpyAsync(s.h_count8, s.d_count8, n2, hipMemcpyDeviceToHost, st));
+      HIP_TRY(h, hipMemcpyAsync(s.h_seg, s.d_seg, n_seg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      s.packed_per_read_home = true;
+      const size_t guess = std::min<size_t>({(size_t)(s.last_n_packed + s.last_n_packed / 32 + 1024), s.h_pcand_cap, s.pcand_cap});
+      if (s.last_n_packed && s.h_pcand && guess) {
+        HIP_TRY(h, hipMemcpyAsync(s.h_pcand, s.d_pcand, guess * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(s.h_ped, s.d_ped, guess * sizeof(uint8_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(s.h_pend, s.d_pend, guess * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        s.packed_home = guess;
+      }
+    }
+    if ((rc = d2h_end(h, s, st))) return rc;
+  }
+  return FEM_OK;
+}
+
 // Enqueue the two kernels of one batch on the slot's stream (asynchronous).
 int launch_batch(fem_dev *h, Slot &s) {
   const fem_params &p = s.params;
@@ -950,29 +1060,41 @@ int launch_batch(fem_dev *h, Slot &s) {
     }
     rc = timed(1, s.stream, [&] { hipLaunchKernelGGL(femk::verify_kernel, dim3(vgrid), dim3(256), 0, s.stream, vp); });
     if (rc) return rc;
+    s.packed_enqueued = false, s.packed_home = 0, s.packed_per_read_home = false;
+    // (the packing inside the chain of the batches' kernels, 0.07 ms: beside the next batch's join — three kernels starting at
+    //  once — it cost that join 0.6 ms; on a sparse index, where nothing runs beside the seed kernel, it goes behind the chain)
+    if (s.want_packed && split_dense && (rc = enqueue_pack(h, s, true, false))) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_kernels_done, s.stream));
     h->have_kernels_done = true;
+    if (s.want_packed && (rc = enqueue_pack(h, s, !split_dense, true))) return rc;
+  } else {
+    s.packed_enqueued = false, s.packed_home = 0, s.packed_per_read_home = false;
   }
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   s.prefetched_reads2 = 0, s.prefetched_cand = 0;
   static const bool no_prefetch = testing_switch("FEM_NO_PREFETCH");
   // (only behind fem_dev_stage_reads, whose caller packs the next batch in the meantime; a caller of the zero-copy form is
   // idle until it fetches, and the extra traffic next to its four-times-larger H2D cost 5 % there)
-  if (s.prefetch_results && s.staged_by_copy && !no_prefetch) {
-    Span span(h, s, 21, s.stream);
-    const size_t n2 = (size_t)s.n_reads * 2;
-    if (n2 && s.h_begin && n2 <= s.h_per_read_cap) {
-      HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
-      HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d_count, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
-      s.prefetched_reads2 = n2;
+  if (s.prefetch_results && !s.want_packed && s.staged_by_copy && !no_prefetch) {
+    hipStream_t st = d2h_begin(h, s);
+    {
+      Span span(h, s, 21, st);
+      const size_t n2 = (size_t)s.n_reads * 2;
+      if (n2 && s.h_begin && n2 <= s.h_per_read_cap) {
+        HIP_TRY(h, hipMemcpyAsync(s.h_begin, s.d_begin, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d_count, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        s.prefetched_reads2 = n2;
+      }
+      const size_t guess = std::min<size_t>({(size_t)(s.last_n_cand + s.last_n_cand / 32 + 1024), s.h_cand_cap, (size_t)s.cand_cap});
+      if (s.last_n_cand && s.h_cand && guess) {
+        HIP_TRY(h, hipMemcpyAsync(s.h_cand, s.d_cand, guess * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(s.h_ed, s.d_ed, guess * sizeof(uint8_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(s.h_end, s.d_end, guess * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        s.prefetched_cand = guess;
+      }
     }
-    const size_t guess = std::min<size_t>({(size_t)(s.last_n_cand + s.last_n_cand / 32 + 1024), s.h_cand_cap, (size_t)s.cand_cap});
-    if (s.last_n_cand && s.h_cand && guess) {
-      HIP_TRY(h, hipMemcpyAsync(s.h_cand, s.d_cand, guess * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
-      HIP_TRY(h, hipMemcpyAsync(s.h_ed, s.d_ed, guess * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
-      HIP_TRY(h, hipMemcpyAsync(s.h_end, s.d_end, guess * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
-      s.prefetched_cand = guess;
-    }
+    int rc2 = d2h_end(h, s, st);
+    if (rc2) return rc2;
   }
   s.mapped = true;
   s.synced = false;
@@ -1173,6 +1295,9 @@ int enqueue_packed(fem_dev *h, Slot &s, uint64_t n, uint32_t len, uint64_t n_exc
     const uint64_t b0 = r0 * bpr, b1 = q + 1 == s.parts ? total : r1 * bpr;
     Span span(h, s, 20, s.stream);
     if (b1 > b0) HIP_TRY(h, hipMemcpyAsync(s.d_packed + b0, s.h_bases + b0, b1 - b0, hipMemcpyHostToDevice, s.stream));
+    // (the link goes to the next batch's copy as soon as this batch's last byte is over — not behind the expansion kernel,
+    //  which waits for a free wave slot beside the running kernels: that chained C2's batches at 2.0 ms apiece)
+    if (q + 1 == s.parts && (rc = h2d_end(h, s))) return rc;
     if (r1 > r0) {
       const uint32_t grid = (uint32_t)std::min<uint64_t>(((r1 - r0) * bpr + 255) / 256, (uint64_t)h->n_cu * 16u);
       hipLaunchKernelGGL(femk::unpack_reads_kernel, dim3(grid), dim3(256), 0, s.stream, (const uint8_t *)s.d_packed + b0, r1 - r0, len, bpr,
@@ -1180,7 +1305,6 @@ int enqueue_packed(fem_dev *h, Slot &s, uint64_t n, uint32_t len, uint64_t n_exc
     }
     if (s.parts > 1) HIP_TRY(h, hipEventRecord(s.ev_part[q], s.stream));
   }
-  if ((rc = h2d_end(h, s))) return rc;
   if (n_exc) {
     const dim3 g((uint32_t)std::min<uint64_t>((n_exc + 255) / 256, (uint64_t)h->n_cu * 4u));
     hipLaunchKernelGGL(femk::scatter_chars_kernel, g, dim3(256), 0, s.stream, (const uint32_t *)(s.d_packed + code_bytes),
@@ -1249,7 +1373,9 @@ int fem_dev_open(int device, fem_dev **out) {
                hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; ok_ev && i < kSlots; ++i) {
     Slot &sl = h->slot[i];
-    ok_ev = hipEventCreateWithFlags(&sl.ev_zeroed, hipEventDisableTiming) == hipSuccess;
+    ok_ev = hipEventCreateWithFlags(&sl.ev_zeroed, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&sl.ev_results, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&sl.ev_home, hipEventDisableTiming) == hipSuccess;
     for (int q = 0; ok_ev && q < kMaxParts; ++q)
       ok_ev = hipEventCreateWithFlags(&sl.ev_part[q], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sl.ev_sel[q], hipEventDisableTiming) == hipSuccess;
@@ -1293,10 +1419,11 @@ int fem_dev_close(fem_dev *h) {
     for (void *p : {(void *)s.d_bases_alloc, (void *)s.d_off, (void *)s.d_cand, (void *)s.d_meta, (void *)s.d_ed,
                     (void *)s.d_end, (void *)s.d_begin, (void *)s.d_count, (void *)s.d_nmap, (void *)s.d_ctl,
                     (void *)s.d_arena, (void *)s.d_slow, (void *)s.d_sel, (void *)s.d_sel_hdr, (void *)s.d_packed, (void *)s.d_exc_bits, (void *)s.d_quals, (void *)s.d_names,
-                    (void *)s.d_name_off})
+                    (void *)s.d_name_off, (void *)s.d_count8, (void *)s.d_seg, (void *)s.d_pcand, (void *)s.d_ped, (void *)s.d_pend, (void *)s.d_big})
       if (p) (void)hipFree(p);
     for (void *p : {(void *)s.h_ctl, (void *)s.h_begin, (void *)s.h_count, (void *)s.h_cand, (void *)s.h_ed,
-                    (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off, (void *)s.h_quals, (void *)s.h_names, (void *)s.h_name_off})
+                    (void *)s.h_end, (void *)s.h_bases, (void *)s.h_off, (void *)s.h_quals, (void *)s.h_names, (void *)s.h_name_off,
+                    (void *)s.h_count8, (void *)s.h_seg, (void *)s.h_pcand, (void *)s.h_ped, (void *)s.h_pend, (void *)s.h_big})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     delete s.tail;
@@ -1313,6 +1440,8 @@ int fem_dev_close(fem_dev *h) {
   for (int i = 0; i < kSlots; ++i) {
     Slot &sl = h->slot[i];
     if (sl.ev_zeroed) (void)hipEventDestroy(sl.ev_zeroed);
+    if (sl.ev_results) (void)hipEventDestroy(sl.ev_results);
+    if (sl.ev_home) (void)hipEventDestroy(sl.ev_home);
     for (int q = 0; q < kMaxParts; ++q) {
       if (sl.ev_part[q]) (void)hipEventDestroy(sl.ev_part[q]);
       if (sl.ev_sel[q]) (void)hipEventDestroy(sl.ev_sel[q]);
@@ -1697,6 +1826,7 @@ int fem_dev_sync(fem_dev *h, int slot) {
       return fail(h, FEM_ERR_UNSUPPORTED, "a read selects more than 2^31 occurrence entries in one seed group");
     if (flags == 0) {
       s.n_cand = ctr[0];
+      s.n_packed = ((const uint32_t *)(s.h_ctl + kCtlPackCursor))[0], s.n_big = ((const uint32_t *)(s.h_ctl + kCtlPackCursor))[1];
       s.stats[0] = s.n_reads;
       s.stats[1] = st[3];
       s.stats[2] = st[0];
@@ -1785,11 +1915,66 @@ int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out) {
     HIP_TRY(h, hipMemcpyAsync(s.h_end + c_from, s.d_end + c_from, (nc - c_from) * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
   }
   if ((n2 && !per_read_home) || nc > c_from) HIP_TRY(h, hipStreamSynchronize(s.stream));
-  s.prefetch_results = true, s.last_n_cand = nc;
+  s.prefetch_results = true, s.last_n_cand = nc, s.want_packed = false;
   out->n_reads = s.n_reads;
   out->n_candidates = nc;
   out->cand_begin = s.h_begin, out->cand_count = s.h_count;
   out->cand = s.h_cand, out->ed = s.h_ed, out->end = s.h_end;
+  memcpy(out->stats, s.stats, sizeof s.stats);
+  return FEM_OK;
+}
+
+int fem_dev_fetch_packed(fem_dev *h, int slot, fem_batch_packed *out) {
+  int rc = fem_dev_sync(h, slot);
+  if (rc) return rc;
+  if (!out) return fail(h, FEM_ERR_INVALID, "null result");
+  Slot &s = h->slot[slot];
+  const size_t n2 = (size_t)s.n_reads * 2, n_seg = (n2 + 255) / 256;
+  if (!s.packed_enqueued && s.n_reads) {  // the slot's first packed fetch: pack now; from the next batch on it happens behind the kernels
+    if ((rc = enqueue_pack(h, s, true, false))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    s.n_packed = ((const uint32_t *)(s.h_ctl + kCtlPackCursor))[0], s.n_big = ((const uint32_t *)(s.h_ctl + kCtlPackCursor))[1];
+  }
+  if (s.n_big > kBigCap) return fail(h, FEM_ERR_UNSUPPORTED, "more strands with 255 candidates and more than a packed result lists: use fem_dev_fetch");
+  const size_t np = s.n_reads ? s.n_packed : 0;
+  bool regrown = false;
+  if (np > s.h_pcand_cap || !s.h_pcand) {
+    regrown = true;
+    for (void *q : {(void *)s.h_pcand, (void *)s.h_ped, (void *)s.h_pend})
+      if (q) (void)hipHostFree(q);
+    s.h_pcand = nullptr, s.h_ped = nullptr, s.h_pend = nullptr;
+    size_t c0 = 0, c1 = 0, c2 = 0;
+    const size_t want = std::max<size_t>(np + np / 4, 1024);
+    if ((rc = pinned_realloc(h, &s.h_pcand, &c0, want))) return rc;
+    if ((rc = pinned_realloc(h, &s.h_ped, &c1, want))) return rc;
+    if ((rc = pinned_realloc(h, &s.h_pend, &c2, want))) return rc;
+    s.h_pcand_cap = c0;
+  }
+  bool copied = false;
+  if (n2 && !s.packed_per_read_home) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_count8, s.d_count8, n2, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_seg, s.d_seg, n_seg * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    s.packed_per_read_home = true, copied = true;
+  }
+  const size_t c_from = regrown ? 0 : std::min<size_t>(s.packed_home, np);
+  if (np > c_from) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_pcand + c_from, s.d_pcand + c_from, (np - c_from) * sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_ped + c_from, s.d_ped + c_from, (np - c_from) * sizeof(uint8_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_pend + c_from, s.d_pend + c_from, (np - c_from) * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+    s.packed_home = np, copied = true;
+  }
+  if (s.n_big) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_big, s.d_big, (size_t)s.n_big * sizeof(uint2), hipMemcpyDeviceToHost, s.stream));
+    copied = true;
+  }
+  if (copied) HIP_TRY(h, hipStreamSynchronize(s.stream));
+  s.want_packed = true, s.last_n_packed = np;
+  out->n_reads = s.n_reads;
+  out->n_candidates = np;
+  out->count = s.h_count8, out->seg_begin = s.h_seg;
+  out->cand = s.h_pcand, out->ed = s.h_ped, out->end = s.h_pend;
+  out->big = (const uint32_t *)s.h_big, out->n_big = s.n_big;
   memcpy(out->stats, s.stats, sizeof s.stats);
   return FEM_OK;
 }

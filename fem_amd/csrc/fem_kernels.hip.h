@@ -1507,6 +1507,89 @@ __global__ void __launch_bounds__(256) verify_kernel(VerifyParams p) {
   }
 }
 
+// ---- the batch's outcome in the form that crosses the link (fem_dev_fetch_packed, include/fem_hip.h) ----
+// The seed kernels hand out candidate slots in chunks per wave, so a strand's candidates sit wherever its wave's chunk was
+// (cand_begin / cand_count: 16 bytes per read) between padding slots.  Here every block of 256 strands claims one stretch of
+// the packed arrays (one atomic per block) and lays its strands' candidates into it in strand order: what goes home is one
+// byte per strand (the count; 255 = listed in big[]), one uint32 per 256 strands (where their stretch starts) and 11 bytes
+// per candidate, none per padding slot — 11.4 instead of 30.8 bytes per read at BASELINE config 2 (0.855 candidates per read).
+struct PackParams {
+  const uint32_t *cand_begin, *cand_count;  // 2 n_reads each
+  const uint64_t *cand;
+  const uint8_t *ed;
+  const int16_t *end;
+  const uint32_t *ctr;      // [1] = overflow flags of the seed kernels (the batch is run again: nothing to pack)
+  uint32_t n_strands;
+  uint8_t *count8;
+  uint32_t *seg_begin;      // ceil(n_strands / 256)
+  uint64_t *pcand;
+  uint8_t *ped;
+  int16_t *pend;
+  uint32_t pcap;            // entries the packed arrays hold (>= the candidate slots handed out)
+  uint32_t *cursor;         // [0] packed candidates so far, [1] entries of big[] asked for
+  uint2 *big;               // (strand, count) of the strands with 255 candidates or more
+  uint32_t big_cap;
+};
+constexpr uint32_t kPackSegs = 16;  // segments of 256 strands one block lays out behind ONE claim of the packed arrays
+__global__ void __launch_bounds__(256) pack_results_kernel(PackParams p) {
+  // (A claim per segment was 19 532 atomics on one address per batch of 2.5 M reads — ~10 ns each, one after the other:
+  //  0.23 ms, nine tenths of the kernel.  A block now claims for sixteen segments at once.)
+  if (p.ctr[1] != 0) return;
+  __shared__ uint32_t part[kPackSegs * 4u];  // [segment][wave]: candidates; then their exclusive prefix
+  __shared__ uint32_t block_base;
+  const uint32_t seg0 = blockIdx.x * kPackSegs;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t cnt[kPackSegs], beg[kPackSegs], incl[kPackSegs];
+#pragma unroll
+  for (uint32_t i = 0; i < kPackSegs; ++i) {
+    const uint32_t s = (seg0 + i) * 256u + threadIdx.x;
+    const bool in = s < p.n_strands;
+    cnt[i] = in ? p.cand_count[s] : 0u;
+    beg[i] = in ? p.cand_begin[s] : 0u;
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < kPackSegs; ++i) {
+    uint32_t x = cnt[i];  // inclusive prefix inside the wave
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(x, d);
+      if ((int)lane_id() >= d) x += o;
+    }
+    incl[i] = x;
+    if (lane_id() == 63) part[i * 4u + wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64u) {  // the 64 (segment, wave) sums -> exclusive prefix; one claim for the block
+    const uint32_t v = part[threadIdx.x];
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(x, d);
+      if ((int)threadIdx.x >= d) x += o;
+    }
+    part[threadIdx.x] = x - v;
+    if (threadIdx.x == 63u) block_base = x ? atomicAdd(&p.cursor[0], x) : 0u;
+  }
+  __syncthreads();
+  const uint32_t n_seg = (p.n_strands + 255u) / 256u;
+#pragma unroll
+  for (uint32_t i = 0; i < kPackSegs; ++i) {
+    const uint32_t seg = seg0 + i, s = seg * 256u + threadIdx.x;
+    if (threadIdx.x == 0 && seg < n_seg) p.seg_begin[seg] = block_base + part[i * 4u];
+    if (s >= p.n_strands) continue;
+    const uint32_t c = cnt[i], at = block_base + part[i * 4u + wave] + incl[i] - c;
+    p.count8[s] = (uint8_t)(c < 255u ? c : 255u);
+    if (c >= 255u) {
+      const uint32_t j = atomicAdd(&p.cursor[1], 1u);
+      if (j < p.big_cap) p.big[j] = make_uint2(s, c);
+    }
+    for (uint32_t k = 0; k < c; ++k) {
+      if (at + k >= p.pcap) break;  // (cannot happen: the packed arrays hold every slot handed out)
+      p.pcand[at + k] = p.cand[beg[i] + k];
+      p.ped[at + k] = p.ed[beg[i] + k];
+      p.pend[at + k] = p.end[beg[i] + k];
+    }
+  }
+}
+
 // bit q of code(text[i]) -> bit i of plane q (q = 0..2); plane 3: the character as uploaded is none of "ACGTN" (lower
 // case, IUPAC codes: it then equals no read character the device traceback compares it with).  One thread per byte of
 // the planes (eight bases).

@@ -12,7 +12,7 @@ ABI_SYMBOLS = [
     "fem_dev_open", "fem_dev_close", "fem_strerror", "fem_dev_last_error", "fem_dev_limits",
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
-    "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch",
+    "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch", "fem_dev_fetch_packed",
     "fem_dev_fetch_records", "fem_dev_seed_kernel",
     "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
@@ -38,6 +38,12 @@ class _ReadBatch(C.Structure):
 class _BatchResult(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_candidates", C.c_uint64), ("cand_begin", C.c_void_p),
                 ("cand_count", C.c_void_p), ("cand", C.c_void_p), ("ed", C.c_void_p), ("end", C.c_void_p),
+                ("stats", C.c_uint64 * 5)]
+
+
+class _BatchPacked(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_candidates", C.c_uint64), ("count", C.c_void_p), ("seg_begin", C.c_void_p),
+                ("cand", C.c_void_p), ("ed", C.c_void_p), ("end", C.c_void_p), ("big", C.c_void_p), ("n_big", C.c_uint32),
                 ("stats", C.c_uint64 * 5)]
 
 
@@ -91,6 +97,7 @@ def load_hip():
     L.fem_dev_sync.argtypes = [vp, C.c_int]
     L.fem_dev_fetch_stats.argtypes = [vp, C.c_int, vp]
     L.fem_dev_fetch.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
+    L.fem_dev_fetch_packed.argtypes = [vp, C.c_int, C.POINTER(_BatchPacked)]
     L.fem_dev_fetch_records.argtypes = [vp, C.c_int, C.POINTER(_BatchRecords)]
     L.fem_dev_seed_kernel.restype = C.c_char_p
     L.fem_dev_seed_kernel.argtypes = [vp, C.POINTER(Params)]
@@ -196,6 +203,49 @@ class BatchResult:
         if total:
             starts = np.repeat(self.cand_begin.astype(np.int64) - off[:-1].astype(np.int64), cnt)
             idx = np.arange(total, dtype=np.int64) + starts
+        return off, self.cand[idx], self.ed[idx], self.end[idx]
+
+
+class BatchPacked:
+    """fem_batch_packed (include/fem_hip.h): the outcome in the form that crosses the link — one byte per strand, one offset
+    per 256 strands, the candidates without padding.  copy=False: views of the handle's pinned buffers."""
+
+    def __init__(self, r, copy=True):
+        n2 = 2 * int(r.n_reads)
+        nc = int(r.n_candidates)
+        self.n_reads = int(r.n_reads)
+        self.n_candidates = nc
+        self.count = _copy(r.count, n2, np.uint8, copy)
+        self.seg_begin = _copy(r.seg_begin, (n2 + 255) // 256, np.uint32, copy)
+        self.cand = _copy(r.cand, nc, np.uint64, copy)
+        self.ed = _copy(r.ed, nc, np.uint8, copy)
+        self.end = _copy(r.end, nc, np.int16, copy)
+        self.n_big = int(r.n_big)
+        self.big = _copy(r.big, 2 * self.n_big, np.uint32, True).reshape(-1, 2)
+        self.stats = np.array(list(r.stats), dtype=np.uint64)
+        self.d2h_bytes = n2 + 4 * len(self.seg_begin) + 11 * nc + 8 * self.n_big
+
+    def counts(self):
+        """Candidates per strand, the strands listed in big[] with their real counts."""
+        cnt = self.count.astype(np.int64)
+        for s_, c_ in self.big:
+            cnt[int(s_)] = int(c_)
+        return cnt
+
+    def per_strand(self):
+        """Candidates regrouped in (read, strand) order: offsets[2n+1], cand, ed, end — the layout the oracle uses."""
+        cnt = self.counts()
+        off = np.zeros(len(cnt) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(cnt)
+        total = int(off[-1])
+        idx = np.zeros(total, dtype=np.int64)
+        if total:
+            n_seg = len(self.seg_begin)
+            pad = np.zeros(n_seg * 256, dtype=np.int64)
+            pad[:len(cnt)] = cnt
+            within = np.cumsum(pad.reshape(n_seg, 256), axis=1) - pad.reshape(n_seg, 256)  # exclusive prefix inside a segment
+            begin = (self.seg_begin.astype(np.int64)[:, None] + within).reshape(-1)[:len(cnt)]
+            idx = np.arange(total, dtype=np.int64) + np.repeat(begin - off[:-1].astype(np.int64), cnt)
         return off, self.cand[idx], self.ed[idx], self.end[idx]
 
 
@@ -328,6 +378,12 @@ class Device:
         r = _BatchResult()
         self._check(self._L.fem_dev_fetch(self._h, slot, C.byref(r)))
         return BatchResult(r, copy)
+
+    def fetch_packed(self, slot=0, copy=True):
+        """fem_dev_fetch_packed: the same outcome at a third of the bytes over the link."""
+        r = _BatchPacked()
+        self._check(self._L.fem_dev_fetch_packed(self._h, slot, C.byref(r)))
+        return BatchPacked(r, copy)
 
     def seed_kernel(self, e=3, a=1, k=12, step=3):
         p = Params(k, step, e, a)

@@ -78,6 +78,26 @@ typedef struct {
   uint64_t stats[5];
 } fem_batch_result;
 
+/* The same outcome in the form that crosses the link (round 5): 11.4 instead of 30.8 bytes per read at BASELINE config 2.
+ * The candidate slots of fem_batch_result are handed out in chunks per wavefront (padding between them, 16 bytes of
+ * cand_begin / cand_count per read); here the candidates of strands [256 b, 256 b + 256) (strand s = 2 * read + direction,
+ * as above) lie in strand order from seg_begin[b] on, without padding, and a strand has count[s] of them — count[s] == 255
+ * means "255 or more": its real count is listed in big[] (n_big pairs: strand, count).  A caller walking the batch in read
+ * order — what process_mappings does, src/align.c:56-92 — keeps one running index per segment and never needs an offset
+ * per read.  Same lifetime as fem_batch_result. */
+typedef struct {
+  uint64_t n_reads;
+  uint64_t n_candidates;     /* entries of cand/ed/end: every one belongs to a strand */
+  const uint8_t *count;      /* 2*n_reads */
+  const uint32_t *seg_begin; /* ceil(2*n_reads / 256) */
+  const uint64_t *cand;      /* seq<<32 | (pos - e) */
+  const uint8_t *ed;         /* 0xFF = rejected */
+  const int16_t *end;
+  const uint32_t *big;       /* 2*n_big: (strand, count) */
+  uint32_t n_big;
+  uint64_t stats[5];
+} fem_batch_packed;
+
 /* The records of one batch as process_mappings would hand them to the writer
  * (src/align.c:56-92): each mapped read's Mappings ordered by radix_sort_mapping
  * (src/align.c:53,66; klib semantics, src/ksort.h:101-151), then per Mapping
@@ -197,6 +217,11 @@ int fem_dev_fetch_stats(fem_dev *h, int slot, uint64_t stats[5]);           /* s
  * again (fem_dev_map_staged / fem_dev_map_batch_submit) — behind fem_dev_stage_reads the next batch's arrays are sent
  * home right behind its kernels, so that this call usually finds them there. */
 int fem_dev_fetch(fem_dev *h, int slot, fem_batch_result *out);
+/* The same outcome as fem_batch_packed (above): a third of the bytes over the link.  Once a slot has been fetched this way
+ * its next batches are packed and sent home behind their kernels (as fem_dev_fetch's arrays are behind fem_dev_stage_reads);
+ * fem_dev_fetch on the same batch still works (and switches the slot back).  FEM_ERR_UNSUPPORTED if more than 4 096 strands
+ * of the batch have 255 candidates or more (-a 0 on a large reference): fem_dev_fetch takes any batch. */
+int fem_dev_fetch_packed(fem_dev *h, int slot, fem_batch_packed *out);
 /* sync + the mapping tail on the device (replaces process_mappings, src/map.c:50-54 -> src/align.c:56-92, up to
  * the point where the reference packs a bam1_t): sorted records with CIGAR and MD.  Independent of fem_dev_fetch. */
 int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
