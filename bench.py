@@ -294,7 +294,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     host_stage_reads = None
     if compare_forms:
         # the same pipeline fed by fem_dev_map_batch_submit: caller-owned batches of characters in ordinary host memory, packed
-        # by the library's host threads (round 3's `value`)
+        # by the library's host threads (round 3's `value`; measured at every N since round 5: whole job, slowest rank's clock)
         for s in range(N_SLOTS):
             batches.append(host.synth_reads(w["seed"], text, off, lens, batch, L, e, first_read=lo + s * batch, threads=threads))
         form[0] = "stage_reads"
@@ -305,8 +305,14 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         n_z = max(4, min(steps, 10))
         pipeline(n_z)
         fence()
-        stage_reads_rate = batch * n_z / (time.perf_counter() - tz) / 1e6
+        dt_z = time.perf_counter() - tz
+        if rk.dist:
+            tz_max = torch.tensor([dt_z], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tz_max, op=dist.ReduceOp.MAX)
+            dt_z = float(tz_max.item())
+        stage_reads_rate = rk.world * batch * n_z / dt_z / 1e6
         host_stage_reads = (host_s[0] * 1e3 / n_z, host_s[1] * 1e3 / n_z)
+    if compare_forms == "all":
         # the zero-copy character form (the staging buffers held the packed batches until now)
         form[0] = "acquire_commit"
         for s in range(N_SLOTS):
@@ -320,7 +326,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         fence()
         zero_copy = batch * n_z / (time.perf_counter() - tz) / 1e6
         h2d_zero_copy = dev.stage_info(0)[0]
-        batches.clear()
+    batches.clear()
 
     # the kernels alone on batches already resident in HBM (every slot as staged by the pipeline steps above), the four
     # slots in rotation: as in the pipeline, a batch's seed selection runs beside the previous batch's join
@@ -374,7 +380,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     def roof_of(name, ms, nbytes, what):
         ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "wire_frac": None, "traffic_source": None,
                 "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4), "time_is": what}
 
     roof = roof_of(dominant, dom_ms, bytes_of[dominant] / max(dom_launches, 1.0),
@@ -415,6 +421,8 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
                 for kname, ctr in prof["kernels"].items():
                     if dominant in kname and "hbm_bytes_per_launch" in ctr:
                         roof["traffic"] = int(ctr["hbm_bytes_per_launch"] * (batch / max(dom_launches, 1.0)) / prof["reads_per_launch"])
+                        # what the counters saw on the wires over the same launch time, against the same peak
+                        roof["wire_frac"] = round(roof["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else None
                         roof["traffic_source"] = ("committed profile profiles/%s of these kernel sources (FETCH_SIZE x %.2f + WRITE_SIZE: "
                                                   "calibrated on this kernel's access pattern), rescaled (not measured in this run)"
                                                   % (tname, ctr.get("fetch_factor", 1.0)))
@@ -427,7 +435,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         "spread": {"reps": len(values), "min": round(min(values), 3), "median": round(sorted(values)[len(values) // 2], 3),
                    "max": round(max(values), 3), "values": [round(v, 3) for v in values]},
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
-        "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name,
+        "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name, "index_tables": dev.index_info(),
         "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_timed,
         "fetch_form": "fem_dev_fetch_packed" if packed_fetch else "fem_dev_fetch",
         "stage_reads_mreads": None if stage_reads_rate is None else round(stage_reads_rate, 3),
@@ -528,7 +536,7 @@ def check_prefix_against_oracle(fo, ref, idx, w, data, pipe_check, threads):
     return {"reads": n_chk, "candidates": int(o[-1]), "mappings": int(np.count_nonzero(ed[sel] != 0xFF)), "equal_to_oracle": bool(ok)}
 
 
-def cpu_baseline(w, data, n_sample, dev, threads, label="C2", pipe_check=None):
+def cpu_baseline(w, data, n_sample, dev, threads, label="C2", pipe_check=None, also_check=()):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample of the
     same workload, same stages as the device path (seeding + filter + verification).  Checker, never shipped."""
     import numpy as np
@@ -551,6 +559,9 @@ def cpu_baseline(w, data, n_sample, dev, threads, label="C2", pipe_check=None):
     got = dev.map_batch(bases, offsets, e=e, a=1, slot=1).stats  # the same sample through the device path
     if pipe_check is not None:
         pipe_check["prefix_vs_oracle"] = check_prefix_against_oracle(fo, ref, idx, w, data, pipe_check, threads)
+    for w_other, pc_other in also_check:  # other workloads on the same reference (C5 beside C3): the oracle's index is at hand
+        if pc_other is not None:
+            pc_other["prefix_vs_oracle"] = check_prefix_against_oracle(fo, ref, idx, w_other, data, pc_other, threads)
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "port",
             "sample": "%d reads of the %s workload, seeding+filter+verification, %d threads (every core this process may use)" % (n_sample, label, threads),
             "seconds": round(dt, 3), "index_build_seconds": round(t_index, 2),
@@ -608,6 +619,29 @@ def e2e_cli(w, data, n_reads, threads, label="C2"):
             return {"error": busy}
         sam_bytes = os.path.getsize(sam)
         os.unlink(sam)
+        # what the output directory's file system takes from plain write() calls — one writer (what FEM map has, like the
+        # reference's output queue, src/output_queue.c:60-91) and four — so that the to-file figure can be read against it
+        def write_rate(n_writers, total=min(sam_bytes, 2 << 30)):
+            import threading
+            buf = bytes(8 << 20)
+            paths = [os.path.join(d_out, "ceiling_%d.bin" % i) for i in range(n_writers)]
+            def one(path, nbytes):
+                fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+                left = nbytes
+                while left > 0:
+                    left -= os.write(fd, buf[:min(len(buf), left)])
+                os.close(fd)
+            t0 = time.perf_counter()
+            ts = [threading.Thread(target=one, args=(p_, total // n_writers)) for p_ in paths]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            dt = time.perf_counter() - t0
+            for p_ in paths:
+                os.unlink(p_)
+            return total / dt / 1e9
+        fs_gbs = {"one_writer_gbs": round(write_rate(1), 2), "four_writers_gbs": round(write_rate(4), 2)}
+        fs_gbs["one_writer_as_mreads"] = round(fs_gbs["one_writer_gbs"] * 1e9 / (sam_bytes / n_reads) / 1e6, 1)
+        fs_gbs["what"] = "plain write() of zeros into the SAM file's directory, 8 MiB at a time; as_mreads = at this run's SAM bytes per read"
         # the same run with the SAM text discarded: what the host stages do when no file system is in the way
         null_secs, _, null_busy = run_map("/dev/null")
         return {"value": round(n_reads / secs / 1e6, 3), "unit": "Mreads/s",
@@ -615,6 +649,7 @@ def e2e_cli(w, data, n_reads, threads, label="C2"):
                         "%d reads of %s, -t %d, inputs in %s, SAM file in %s" % (n_reads, label, threads, base or "tmp", d_out),
                 "seconds": secs, "wall_seconds_incl_load": round(wall, 3), "sam_bytes": sam_bytes, "stage_busy": busy,
                 "fem_index_wall_seconds": round(t_ix, 2), "reference_and_index_resident_seconds": load[0],
+                "file_system_write_ceiling": fs_gbs,
                 "to_dev_null": {"value": round(n_reads / null_secs / 1e6, 3) if null_secs else None, "seconds": null_secs,
                                 "stage_busy": null_busy}}
     finally:
@@ -637,8 +672,8 @@ def main():
     ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
                                                                          "the oracle's 3 Gbp index takes ~30 s to build)")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run on C2 (0 = skip)")
-    ap.add_argument("--e2e-reads-c3", type=int, default=8_000_000, help="reads of the end-to-end FEM map run on the headline configuration "
-                                                                        "(3 GB FASTA + 8 GB index file + FASTQ in /dev/shm; 0 = skip)")
+    ap.add_argument("--e2e-reads-c3", type=int, default=16_000_000, help="reads of the end-to-end FEM map run on the headline configuration "
+                                                                        "(3 GB FASTA + 8 GB index file + 4 GB FASTQ in /dev/shm; 0 = skip)")
     ap.add_argument("--profile-replay", type=int, default=0, help="profiling aid: only the resident replay of --workload (kernels on batches "
                                                                      "already in HBM, slots in rotation, no copies in flight), this many steps; "
                                                                      "prints the HIP-event means of exactly those launches")
@@ -708,7 +743,8 @@ def main():
         ref_key3 = (3, tuple(w3["seq_lens"]))
         if cpu_c3[0] is None and not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0 and ref_key3 in data_cache:
             cpu_c3[0] = cpu_baseline(w3, data_cache[ref_key3][:3], args.cpu_sample_c3, dev, threads, label="C3",
-                                     pipe_check=results["c3"]["pipeline_check"])
+                                     pipe_check=results["c3"]["pipeline_check"],
+                                     also_check=[(WORKLOADS["c5"], results["c5"]["pipeline_check"])] if "c5" in results else ())
             cpu_c3[0].update(affinity_cpus=n_aff, cgroup_cpu_quota=quota,
                              device_pipeline_over_cpu=round(results["c3"]["value"] / max(cpu_c3[0]["value"], 1e-9), 1))
         # ... and `FEM index` + `FEM map` end to end on the headline configuration (its own process and handle)
@@ -721,9 +757,9 @@ def main():
     for key in [args.workload] + extras:
         w = WORKLOADS[key]
         ref_key = (w["seed"] if key == "c2" else 3, tuple(w["seq_lens"]))  # c3 and c5 share one reference (seed 3)
-        t0 = time.time()
         if ref_key not in data_cache:
             cpu_c3_now()
+            t0 = time.time()
             data_cache.clear()
             if dev is not None:
                 dev.close()
@@ -743,7 +779,7 @@ def main():
             dev.close()
             return
         res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads,
-                           reps=args.reps if key == args.workload else 1, compare_forms=rk.world == 1 and not args.no_compare)
+                           reps=args.reps, compare_forms=("all" if rk.world == 1 else "stage_reads") if not args.no_compare else None)
         res["index_entries"] = n_occ
         results[key] = res
         log("rank %d %s: pipeline %.1f Mreads/s, kernels only %.1f, %s" % (rk.rank, key, res["value"], res["kernel_only_mreads"], res["kernel_ms_per_launch"]))
@@ -760,6 +796,9 @@ def main():
         "metric": "mapped Mreads/s (100 bp, e=3) at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
         "value": head["value"], "unit": "Mreads/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # (round 4 changed what `value` is fed by — see config.value_is; the round-3 form, the library packing the caller's
+        #  characters on host threads, is pipeline_by_workload.*.stage_reads_mreads, measured at every N)
+        "value_form": "packed_commit", "value_stage_reads_form": head.get("stage_reads_mreads"),
         "dtype": "u32/u64 integer + 32-bit Myers bit-vectors", "data": "synthetic", "spread": head["spread"],
         "config": dict({k_: v_ for k_, v_ in head.items() if k_ not in ("value", "ms_per_step", "steps", "roofline", "roofline_step",
                                                                          "roofline_by_kernel", "spread")},
@@ -771,7 +810,7 @@ def main():
         "roofline_step": dict(head["roofline_step"], workload=args.workload),
         "roofline_by_kernel": head["roofline_by_kernel"],
         "roofline_by_workload": {k_: {"dominant_kernel": v_["roofline"], "step": v_["roofline_step"]} for k_, v_ in results.items()},
-        "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel",
+        "pipeline_by_workload": {k_: {x: v_[x] for x in ("value", "ms_per_step", "steps", "kernel_only_mreads", "seed_kernel", "index_tables",
                                                            "reads_per_step_per_gpu", "kernel_ms_per_launch", "kernel_ms_alone", "counters_last_step_per_gpu",
                                                            "algorithmic_bytes_per_step_per_gpu", "h2d_bytes_per_step", "h2d_packed", "d2h_bytes_per_step", "fetch_form",
                                                            "stage_reads_mreads", "zero_copy_ascii_mreads", "zero_copy_h2d_bytes_per_step", "priming_steps",

@@ -215,6 +215,11 @@ class StagePool {
 }  // namespace
 
 struct fem_dev {
+  // Calls on DIFFERENT slots of one handle may come from different threads (round 5: `FEM map` retires its batches in flight on
+  // a thread each, so that one batch's host round trips — records counted, text sized — do not hold up the next one's): what
+  // the slots share (the kernels' chaining events, the event pool, the timing sums, the error string) is touched under this
+  // lock; a thread waiting for the device does not hold it.
+  std::recursive_mutex mu;
   int device = 0;
   StagePool *stage_pool = nullptr;  // host threads of fem_dev_stage_reads
   uint8_t *d_ref_names = nullptr;   // reference sequence names for the device SAM text
@@ -301,9 +306,13 @@ bool testing_switch(const char *name) {
 }
 
 int fail(fem_dev *h, int rc, const std::string &msg) {
-  if (h) h->err = msg;
+  if (h) {
+    std::lock_guard<std::recursive_mutex> lock(h->mu);
+    h->err = msg;
+  }
   return rc;
 }
+#define FEM_LOCK(h) std::lock_guard<std::recursive_mutex> fem_lock_(h->mu)
 
 #define HIP_TRY(h, expr)                                                                          \
   do {                                                                                            \
@@ -1181,8 +1190,12 @@ int refresh_dense(fem_dev *h) {
   };
   // One coordinate space: the STRIDED 32-bit table (fem_seed_dense.hip.h: 512 bytes per bucket, lists on line boundaries, found
   // by the hash alone).  Where it does not fit, and for references in banks (whose lists are cut at bank_lo), the compact one.
+  // It is 8.6 GB whatever the reference, so it is taken where the compact table is at least an eighth of that (16 entries per
+  // bucket and more: references from ~0.8 Gbp; at 3 Gbp it is 2.1 x the compact table and bought 7 % of the step) — and
+  // wherever FEM_FORCE_DENSE asks for the dense kernels on a small reference (the parity tests of the padded join).
   uint32_t list_shift = 0;
-  if (n_banks == 1 && !h->no_strided) {
+  const bool strided_pays = h->force_dense || h->n_occ >= (n_buckets << 4);
+  if (n_banks == 1 && !h->no_strided && strided_pays) {
     const size_t words = ((size_t)n_buckets + femk::kDensePadBuckets) << femk::kDenseListShift;
     bool ok = hipMalloc((void **)&h->d_occ32, words * sizeof(uint32_t)) == hipSuccess;
     if (ok) {  // every slot reads "pad" (fem_seed_dense.hip.h) until dense_occ32_strided_kernel writes a bucket's entries over its first ones
@@ -1391,6 +1404,8 @@ int fem_dev_open(int device, fem_dev **out) {
     h->no_parts = testing_switch("FEM_NO_PARTS");
     if (const char *mp = getenv("FEM_PARTS")) h->max_parts = std::min(kMaxParts, std::max(1, atoi(mp)));
     h->timeline = testing_switch("FEM_TIMELINE");
+    if (h->timeline && hipEventCreate(&h->ev_epoch) == hipSuccess && hipEventRecord(h->ev_epoch, h->side_stream) == hipSuccess)
+      h->timing = true, h->have_epoch = true;  // (a process that never asks for timing, FEM map, is timed from its handle's opening)
     h->force_generic = testing_switch("FEM_FORCE_GENERIC");
     h->force_hash = testing_switch("FEM_FORCE_HASH");
     h->force_dense = testing_switch("FEM_FORCE_DENSE");
@@ -1531,9 +1546,20 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
   HIP_TRY(h, hipMemset(h->d_ref_raw + total, 'N', 128));
   h->ref_bytes = total, h->n_seq = n_seq;
   {  // bit planes of the codes, 64 bases of slack (code 4) included; the codes themselves are not kept
+    // (a failure from here on must not leave a reference without its planes behind: fem_dev_map_staged and
+    //  fem_dev_build_index test d_ref_raw)
+    auto drop_reference = [&]() {
+      for (void *q : {(void *)h->d_ref_raw, (void *)h->d_seq_off, (void *)h->d_seq_len, (void *)h->d_planes})
+        if (q) (void)hipFree(q);
+      h->d_ref_raw = nullptr, h->d_seq_off = nullptr, h->d_seq_len = nullptr, h->d_planes = nullptr;
+      h->ref_bytes = 0, h->n_seq = 0;
+    };
     uint8_t *codes = nullptr;
     int rc = make_codes(h, &codes);
-    if (rc) return rc;
+    if (rc) {
+      drop_reference();
+      return rc;
+    }
     const uint64_t n_pb = (total + 64 + 7) / 8;
     hipError_t e = hipMalloc((void **)&h->d_planes, femk::plane_bytes(n_pb));
     if (e == hipSuccess) e = hipMemset(h->d_planes, 0, femk::plane_bytes(n_pb));
@@ -1543,6 +1569,7 @@ int fem_dev_upload_reference(fem_dev *h, uint32_t n_seq, const char *const *seq,
       if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     (void)hipFree(codes);
+    if (e != hipSuccess) drop_reference();
     HIP_TRY(h, e);
   }
   return refresh_dense(h);
@@ -1593,6 +1620,7 @@ int fem_dev_fetch_index(fem_dev *h, uint32_t *lookup_out, uint64_t *occ_out, uin
 int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, char **bases, uint64_t **offsets) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   if (!bases || !offsets) return fail(h, FEM_ERR_INVALID, "null output pointer");
   if (n_reads_cap > 0x3FFFFFF0ull) return fail(h, FEM_ERR_UNSUPPORTED, "more than 2^30 reads in one batch");
   Slot &s = h->slot[slot];
@@ -1610,6 +1638,7 @@ int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n
 int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_len) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!s.h_bases || !s.h_off) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
   if (n_reads > s.acq_reads) return fail(h, FEM_ERR_INVALID, "more reads than the staging buffers were acquired for");
@@ -1634,6 +1663,7 @@ int fem_dev_commit_stage(fem_dev *h, int slot, uint64_t n_reads, uint32_t max_le
 int fem_dev_commit_stage_uniform(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!s.h_bases) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
   if (read_len > kMaxReadLen)
@@ -1670,6 +1700,7 @@ int fem_dev_packed_layout(uint64_t n_reads, uint32_t read_len, uint32_t *bytes_p
 int fem_dev_commit_stage_packed(fem_dev *h, int slot, uint64_t n_reads, uint32_t read_len, uint64_t n_exceptions) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!s.h_bases) return fail(h, FEM_ERR_STATE, "acquire the slot's staging buffers first");
   if (read_len == 0 && n_reads) return fail(h, FEM_ERR_INVALID, "packed batches hold reads of one non-zero length");
@@ -1768,7 +1799,10 @@ int fem_dev_stage_reads(fem_dev *h, int slot, const fem_read_batch *reads) {
       uint8_t *hc = (uint8_t *)(he + n_exc);
       for (const auto &v : exc)
         for (uint64_t x : v) *he++ = (uint32_t)(x >> 8), *hc++ = (uint8_t)x;
-      if ((rc = enqueue_packed(h, s, n, len, n_exc))) return rc;
+      {
+        FEM_LOCK(h);
+        if ((rc = enqueue_packed(h, s, n, len, n_exc))) return rc;
+      }
       s.staged_by_copy = true;
       return FEM_OK;
     }
@@ -1797,8 +1831,9 @@ int fem_dev_stage_info(fem_dev *h, int slot, uint64_t *h2d_bytes, int32_t *packe
 int fem_dev_map_staged(fem_dev *h, int slot, const fem_params *p) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   if (!params_ok(p)) return fail(h, FEM_ERR_INVALID, "parameters out of range (k 1..16, step 1..16, e 0..7, a 0..2)");
-  if (!h->d_lookup || !h->d_ref_raw) return fail(h, FEM_ERR_STATE, "index and reference must be uploaded first");
+  if (!h->d_lookup || !h->d_ref_raw || !h->d_planes) return fail(h, FEM_ERR_STATE, "index and reference must be uploaded first");
   if (p->k != h->k) return fail(h, FEM_ERR_INVALID, "k differs from the uploaded index");
   Slot &s = h->slot[slot];
   if (!s.staged) return fail(h, FEM_ERR_STATE, "no reads staged in this slot");
@@ -1816,7 +1851,8 @@ int fem_dev_sync(fem_dev *h, int slot) {
   HIP_TRY(h, hipSetDevice(h->device));  // the callers (fetch, fetch_records) allocate and launch on this device
   if (s.synced) return FEM_OK;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));  // (without the handle's lock: other slots' calls go on meanwhile)
+    FEM_LOCK(h);
     drain_timing(h, s);
     const uint32_t *ctr = (const uint32_t *)s.h_ctl;
     const uint64_t *arena_ctr = (const uint64_t *)(s.h_ctl + 4 * sizeof(uint32_t));
@@ -2032,6 +2068,7 @@ int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint6
                                char **names, uint64_t **name_off) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   if (!quals || !names || !name_off) return fail(h, FEM_ERR_INVALID, "null output pointer");
   Slot &s = h->slot[slot];
   HIP_TRY(h, hipSetDevice(h->device));
@@ -2047,6 +2084,7 @@ int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint6
 int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   HIP_TRY(h, hipSetDevice(h->device));
   if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
@@ -2064,6 +2102,7 @@ int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_base
 int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!s.staged) return fail(h, FEM_ERR_STATE, "commit the reads of the batch first");
   if (!s.h_quals || !s.h_names || !s.h_name_off) return fail(h, FEM_ERR_STATE, "acquire the slot's text staging buffers first");
@@ -2123,6 +2162,7 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait);
   if (rc) return fail(h, rc, err);
   if (h->timing) {
+    FEM_LOCK(h);
     for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;
     if (wait) h->t_ms[7] += ms_text, h->t_n[7] += 1;  // (without the wait no elapsed time is read: nothing to count)
   }
@@ -2139,6 +2179,27 @@ int fem_dev_map_batch_submit(fem_dev *h, int slot, const fem_params *p, const fe
 }
 
 int fem_dev_map_batch_wait(fem_dev *h, int slot, fem_batch_result *out) { return fem_dev_fetch(h, slot, out); }
+
+int fem_dev_index_info(const fem_dev *h, char *buf, uint64_t cap) {
+  if (!h || !buf || cap == 0) return FEM_ERR_INVALID;
+  const uint64_t n_buckets = h->n_lookup ? h->n_lookup - 1 : 0;
+  std::string s;
+  if (!h->d_lookup) {
+    s = "no index";
+  } else if (h->d_occ32 && h->d_freq11) {
+    s = "dense: 32-bit occurrence table, ";
+    s += h->list_shift ? "strided with pads (" + std::to_string(((n_buckets + femk::kDensePadBuckets) << h->list_shift) * 4 >> 20) + " MiB)"
+                       : "compact (" + std::to_string(h->n_occ * 4 >> 20) + " MiB)";
+    s += ", " + std::to_string(h->n_banks) + (h->n_banks == 1 ? " bank" : " banks") + ", freq11 64 MiB";
+  } else if (h->d_summary) {
+    s = "sparse: bucket summaries";
+  } else {
+    s = "64-bit occurrence table only";
+  }
+  s += "; " + std::to_string(h->n_occ) + " entries in " + std::to_string(n_buckets) + " buckets";
+  snprintf(buf, (size_t)cap, "%s", s.c_str());
+  return FEM_OK;
+}
 
 const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p) {
   if (!h || !params_ok(p)) return "";

@@ -610,7 +610,10 @@ __device__ uint32_t strand_lists_big(const SeedParams &p, const Picked *picked, 
       }
     }
     wave_sync_global();
-    // ---- the greedy pass by chains; the keep flags are bytes over F (dead by now: 8 (fcap) >= 3 fcap >= nM bytes) ----
+    // ---- the greedy pass by chains; the keep flags are bytes over F (dead by now: 8 fcap bytes; nM <= 3 fcap at step <= 8 —
+    //      beyond that, step 9..16, a strand may merge more than F holds as bytes: such a strand is declined like one that
+    //      outgrows the arena, and the batch runs again with larger buffers) ----
+    if (nM > 8u * b.fcap) return 0xFFFFFFFFu;
     uint8_t *keep = (uint8_t *)b.F;
     for (uint32_t k0 = 0; k0 < nM; k0 += kWave) {
       const uint32_t k = k0 + ln;

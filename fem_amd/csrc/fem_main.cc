@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -220,6 +222,7 @@ struct Growable {  // a reusable host array: only ever grows
 };
 
 struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pair
+  uint64_t seq = 0;  // submission number on its GPU: results are handed on in this order
   int gpu = 0, slot = 0;
   char *bases = nullptr;      // pinned staging lent by the device library (fem_dev_acquire_stage)
   uint64_t *off = nullptr;
@@ -571,44 +574,62 @@ int map_main(int argc, char **argv) {
         if (!acquire(b, reads_cap0, bases_cap0)) b->bases = nullptr;  // (allocated during the setup: this only hands them out)
         free_q.push(b);  // (without buffers when the acquisition failed: the reader stops on it instead of waiting for ever)
       }
-      std::deque<BatchBuf *> flight;
-      // Below max_flight batches in flight the thread lingers a moment for the reader's next batch before it blocks in a
-      // fetch: a batch submitted just before a fetch has its copy and kernels run behind that fetch instead of in front
-      // of the next one (FEM_LINGER_US).
-      double linger = 300e-6;
-      if (const char *lg = getenv("FEM_LINGER_US")) linger = std::max(0, atoi(lg)) * 1e-6;
-      size_t max_flight = 3;  // (2 until round 4; with 1 M-read batches a third in flight is worth 1-2 %)
-      if (const char *fl = getenv("FEM_FLIGHT")) max_flight = (size_t)std::max(1, std::min(n_slots - 1, atoi(fl)));
-      auto retire = [&] {
-        BatchBuf *b = flight.front();
-        flight.pop_front();
+      // Round 5: the thread that submits does not retire.  A batch's way home has host round trips in it (the mapping's
+      // counters, the records counted, the text sized: fem_dev_fetch_sam), each of which can wait behind another batch's
+      // kernels on the device; with one thread per GPU doing both, those waits came one after the other and the GPU idled
+      // (16 M reads of C3 to /dev/null: 91 Mreads/s with 9.4 ms of "device wait" per 1 M-read batch, of which 5 were
+      // kernels).  Now every batch in flight is retired by a thread of its own (the library takes calls on different
+      // slots of a handle from different threads), and a sequencer hands the results on in submission order.
+      std::mutex seq_mu;
+      uint64_t seq_next = 0, seq_submit = 0;
+      std::map<uint64_t, std::function<void()>> seq_held;
+      auto deliver = [&](uint64_t seq, std::function<void()> fn) {
+        std::lock_guard<std::mutex> l(seq_mu);
+        seq_held.emplace(seq, std::move(fn));
+        for (auto it = seq_held.find(seq_next); it != seq_held.end(); it = seq_held.find(seq_next)) {
+          it->second();
+          seq_held.erase(it);
+          ++seq_next;
+        }
+      };
+      Channel<BatchBuf *> retire_q;
+      auto retire = [&](BatchBuf *b) {
         double t0 = real_time();
         int rc = host_tail     ? fem_dev_map_batch_wait(h, b->slot, &b->res)
                  : device_text ? fem_dev_fetch_sam_nowait(h, b->slot, &b->sam)  // (the writer waits for the text itself)
                                : fem_dev_fetch_records(h, b->slot, &b->rec);
-        busy_wait[(size_t)g] += real_time() - t0;
-        if (rc) {
-          if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "mapping", rc);
-          work_q[(size_t)g].push(Msg{kRecycle, b});
-          return;
-        }
-        const uint64_t *st = host_tail ? b->res.stats : device_text ? b->sam.stats : b->rec.stats;
-        for (int i = 0; i < 5; ++i) per_gpu[(size_t)g * 5 + (size_t)i] += st[i];
-        if (device_text) {
-          n_asserted += b->sam.n_asserted;
-          write_q.push(WriteItem{nullptr, b});
-        } else {
-          text_q.push(b);
-        }
+        const double waited = real_time() - t0;
+        deliver(b->seq, [&, b, rc, waited] {
+          busy_wait[(size_t)g] += waited;
+          if (rc) {
+            if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "mapping", rc);
+            work_q[(size_t)g].push(Msg{kRecycle, b});
+            return;
+          }
+          const uint64_t *st = host_tail ? b->res.stats : device_text ? b->sam.stats : b->rec.stats;
+          for (int i = 0; i < 5; ++i) per_gpu[(size_t)g * 5 + (size_t)i] += st[i];
+          if (device_text) {
+            n_asserted += b->sam.n_asserted;
+            write_q.push(WriteItem{nullptr, b});
+          } else {
+            text_q.push(b);
+          }
+        });
       };
+      int n_retire = std::max(1, n_slots - 1);
+      if (const char *fl = getenv("FEM_FLIGHT")) n_retire = std::max(1, std::min(n_slots, atoi(fl)));
+      std::vector<std::thread> retirers;
+      for (int r = 0; r < n_retire; ++r)
+        retirers.emplace_back([&] {
+          if (n_gpus > 1 && !share_gpu) (void)fem_bind_thread_near_device(g);
+          for (;;) {
+            BatchBuf *b = retire_q.pop();
+            if (!b) break;
+            retire(b);
+          }
+        });
       for (;;) {
-        Msg m;
-        if (flight.empty()) {
-          m = work_q[(size_t)g].pop();
-        } else if (!(flight.size() < max_flight ? work_q[(size_t)g].try_pop_for(m, linger) : work_q[(size_t)g].try_pop(m))) {
-          retire();  // nothing new to start: finish the oldest batch in flight
-          continue;
-        }
+        Msg m = work_q[(size_t)g].pop();
         if (m.kind == kStop) break;
         if (m.kind == kRecycle) {
           const double t0 = real_time();
@@ -637,10 +658,11 @@ int map_main(int argc, char **argv) {
           continue;
         }
         busy_submit[(size_t)g] += real_time() - b->t_submit;
-        flight.push_back(b);
-        while (flight.size() > max_flight) retire();  // batches in flight per GPU (FEM_FLIGHT, default 2)
+        b->seq = seq_submit++;
+        retire_q.push(b);
       }
-      while (!flight.empty()) retire();
+      for (int r = 0; r < n_retire; ++r) retire_q.push(nullptr);
+      for (auto &t : retirers) t.join();
     });
 
   // ---- reader (src/input_queue.c:53-79): this thread ----

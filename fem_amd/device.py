@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "fem_dev_upload_index", "fem_dev_upload_reference", "fem_dev_build_index", "fem_dev_fetch_index",
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch", "fem_dev_fetch_packed",
-    "fem_dev_fetch_records", "fem_dev_seed_kernel",
+    "fem_dev_fetch_records", "fem_dev_seed_kernel", "fem_dev_index_info",
     "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
@@ -99,6 +99,7 @@ def load_hip():
     L.fem_dev_fetch.argtypes = [vp, C.c_int, C.POINTER(_BatchResult)]
     L.fem_dev_fetch_packed.argtypes = [vp, C.c_int, C.POINTER(_BatchPacked)]
     L.fem_dev_fetch_records.argtypes = [vp, C.c_int, C.POINTER(_BatchRecords)]
+    L.fem_dev_index_info.argtypes = [vp, C.c_char_p, u64]
     L.fem_dev_seed_kernel.restype = C.c_char_p
     L.fem_dev_seed_kernel.argtypes = [vp, C.POINTER(Params)]
     L.fem_dev_set_timing.argtypes = [vp, C.c_int]
@@ -388,6 +389,12 @@ class Device:
     def seed_kernel(self, e=3, a=1, k=12, step=3):
         p = Params(k, step, e, a)
         return self._L.fem_dev_seed_kernel(self._h, C.byref(p)).decode()
+
+    def index_info(self):
+        """fem_dev_index_info: which derived tables the resident index has."""
+        buf = C.create_string_buffer(512)
+        self._check(self._L.fem_dev_index_info(self._h, buf, 512))
+        return buf.value.decode()
 
     def fetch_records(self, slot=0):
         """The device mapping tail: sorted records with CIGAR and MD (fem_dev_fetch_records)."""

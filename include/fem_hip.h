@@ -251,6 +251,11 @@ int fem_dev_sam_wait(fem_dev *h, int slot);
  * need more than one 32-bit coordinate space —, "seed_fast_kernel<hash>", "seed_fast_kernel<lean>" or
  * "seed_filter_kernel"); the generic seed_filter_kernel always follows for whatever those queue.  Static string. */
 const char *fem_dev_seed_kernel(const fem_dev *h, const fem_params *p);
+/* Which derived tables the resident index has (one line of text, NUL-terminated, cut at cap): "dense: 32-bit occurrence
+ * table, strided with pads (8192 MiB), 1 bank, ..." / "... compact ..." / "sparse: bucket summaries" — so that a
+ * measurement can say what it ran on (the strided table is taken from 16 entries per bucket on, and may be declined when
+ * memory is short). */
+int fem_dev_index_info(const fem_dev *h, char *buf, uint64_t cap);
 
 /* ---- measurement ---- */
 /* With timing on, every kernel launch is bracketed by HIP events on the stream
