@@ -50,7 +50,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r04"   # profiles/<round>_<workload>_hbm_traffic.json: the committed PMC passes `roofline.traffic` comes from
+PROFILE_ROUND = "r05"   # profiles/<round>_<workload>_hbm_traffic.json: the committed PMC passes `roofline.traffic` comes from
 
 
 def kernel_sources_sha16():
@@ -79,7 +79,25 @@ WORKLOADS = {
                name="C3: synthetic 100 bp reads, e=3, 24x125 Mbp random reference, k=12 step=3"),
     "c5": dict(seed=5, seq_lens=[125_000_000] * 24, L=150, e=7,
                name="C5: synthetic 150 bp reads, e=7, 24x125 Mbp random reference, k=12 step=3"),
+    # not a BASELINE configuration: C3's reads on a reference with a real genome's kind of k-mer spectrum — 5 % of it 500
+    # units of 300 bp in 1 000 copies each (lists of a thousand entries: the generic kernel's share)
+    "c3r": dict(seed=3, seq_lens=[125_000_000] * 24, L=100, e=3, repeats=dict(units=500, copies=1000, unit_len=300, rng=5),
+                name="C3 reads on a repeat-rich 3 Gbp reference (5 % in 500 units of 300 bp x 1000 copies), k=12 step=3"),
 }
+
+
+def plant_repeats(text, off, lens, units, copies, unit_len, rng):
+    """Overwrites `copies` places per unit with the unit (scratch/cliff_probe.py's reference): in place."""
+    import numpy as np
+    g = np.random.default_rng(rng)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for _ in range(units):
+        unit = acgt[g.integers(0, 4, unit_len)]
+        seq = g.integers(0, len(lens), copies)
+        at = g.integers(2000, int(lens[0]) - 2000 - unit_len, copies)
+        for s_, a_ in zip(seq, at):
+            p_ = int(off[s_]) + int(a_)
+            text[p_:p_ + unit_len] = unit
 KERNEL_IDS = {"seed": 0, "verify_kernel": 1, "seed_filter_kernel": 2, "seed_select_kernel": 8}
 
 
@@ -666,7 +684,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3, help="timed runs of exactly --steps steps of the headline workload (value = the first; spread = all)")
     ap.add_argument("--batch", type=int, default=2_500_000, help="reads per step and GPU")
     ap.add_argument("--extra", default="auto", help="comma list of further workloads measured on rank 0 when N = 1 "
-                                                    "(auto = c5,c2 next to c3; none)")
+                                                    "(auto = c5,c3r,c2 next to c3; none)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
     ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
@@ -685,6 +703,10 @@ def main():
         sys.exit("bench.py: --steps >= 1, --warmup >= 0, --batch >= 1")
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    if args.profile_replay > 0:
+        # the profiled replay launches every batch whole: a batch that meets an idle device is mapped in two parts otherwise
+        # (fem_hip.hip launch_batch), and a profile's "average duration per launch" would mix halves with wholes
+        os.environ["FEM_TESTING"], os.environ["FEM_NO_PARTS"] = "1", "1"
 
     rk = Rank()
     if rk.world != args.gpus:
@@ -727,7 +749,7 @@ def main():
 
     extras = []
     if rk.world == 1 and args.extra != "none":
-        extras = [x for x in (["c5", "c2"] if args.extra == "auto" else args.extra.split(",")) if x in WORKLOADS and x != args.workload]
+        extras = [x for x in (["c5", "c3r", "c2"] if args.extra == "auto" else args.extra.split(",")) if x in WORKLOADS and x != args.workload]
         if args.extra == "auto" and args.workload != "c3":
             extras = []
 
@@ -740,7 +762,7 @@ def main():
     def cpu_c3_now():
         """The headline configuration on the host cores, while the 3 Gbp reference is at hand (host text + device)."""
         w3 = WORKLOADS["c3"]
-        ref_key3 = (3, tuple(w3["seq_lens"]))
+        ref_key3 = (3, tuple(w3["seq_lens"]), False)
         if cpu_c3[0] is None and not args.no_cpu and rk.world == 1 and "c3" in results and args.cpu_sample_c3 > 0 and ref_key3 in data_cache:
             cpu_c3[0] = cpu_baseline(w3, data_cache[ref_key3][:3], args.cpu_sample_c3, dev, threads, label="C3",
                                      pipe_check=results["c3"]["pipeline_check"],
@@ -756,7 +778,7 @@ def main():
 
     for key in [args.workload] + extras:
         w = WORKLOADS[key]
-        ref_key = (w["seed"] if key == "c2" else 3, tuple(w["seq_lens"]))  # c3 and c5 share one reference (seed 3)
+        ref_key = (w["seed"] if key == "c2" else 3, tuple(w["seq_lens"]), "repeats" in w)  # c3 and c5 share one reference (seed 3)
         if ref_key not in data_cache:
             cpu_c3_now()
             t0 = time.time()
@@ -764,6 +786,8 @@ def main():
             if dev is not None:
                 dev.close()
             text, off, lens = host.synth_reference(ref_key[0], w["seq_lens"], threads=gen_threads)
+            if "repeats" in w:
+                plant_repeats(text, off, lens, **w["repeats"])
             dev = Device(local_rank)
             dev.upload_reference([text[int(o):int(o) + int(l)] for o, l in zip(off, lens)])
             n_occ, _, _ = dev.build_index(12, 3, fetch=False)
@@ -774,12 +798,15 @@ def main():
                 bw = {"device_copy_gbs": round(dev.copy_bandwidth(1 << 30, 10), 1), "pinned_h2d_gbs": round(dev.h2d_bandwidth(1 << 28, 8), 1)}
         text, off, lens, n_occ = data_cache[ref_key]
         steps, warmup = (args.steps, args.warmup) if key == args.workload else (args.extra_steps, N_SLOTS + 1)  # (every slot warm)
+        if "repeats" in w and key != args.workload:
+            steps = min(steps, 8)  # (a step of c3r is ~60 ms and sends 1.1 GB of candidates home)
         if args.profile_replay > 0:
             print(json.dumps(profile_replay(key, dev, (text, off, lens), args.profile_replay, args.batch, torch, gen_threads)), flush=True)
             dev.close()
             return
         res = run_workload(key, dev, (text, off, lens), rk, steps, warmup, args.batch, torch, dist, red_dev, gen_threads,
-                           reps=args.reps, compare_forms=("all" if rk.world == 1 else "stage_reads") if not args.no_compare else None)
+                           reps=1 if "repeats" in w else args.reps,
+                           compare_forms=None if args.no_compare or "repeats" in w else ("all" if rk.world == 1 else "stage_reads"))
         res["index_entries"] = n_occ
         results[key] = res
         log("rank %d %s: pipeline %.1f Mreads/s, kernels only %.1f, %s" % (rk.rank, key, res["value"], res["kernel_only_mreads"], res["kernel_ms_per_launch"]))
@@ -822,8 +849,8 @@ def main():
     c2_data = None
     if (not args.no_cpu or not args.no_e2e) and rk.world == 1:
         w2 = WORKLOADS["c2"]
-        if (w2["seed"], tuple(w2["seq_lens"])) in data_cache:
-            c2_data = data_cache[(w2["seed"], tuple(w2["seq_lens"]))][:3]
+        if (w2["seed"], tuple(w2["seq_lens"]), False) in data_cache:
+            c2_data = data_cache[(w2["seed"], tuple(w2["seq_lens"]), False)][:3]
         else:
             dev.close()
             t2 = host.synth_reference(w2["seed"], w2["seq_lens"], threads=gen_threads)

@@ -474,7 +474,7 @@ femk::SeedLayout make_layout_select(const fem_params &p, uint32_t max_len) {
 
 // LDS of one wave of seed_join_kernel: the strands' candidates, flagged values per phase group, scatter, the block's
 // begin/count entries, the sequence table, the join's bitmap
-femk::SeedLayout make_layout_join(const fem_params &p, bool banked) {
+femk::SeedLayout make_layout_join(const fem_params &p, bool banked, bool padded = false) {
   femk::SeedLayout l{};
   const uint32_t R = (uint32_t)(p.e + 1 + p.a);
   uint32_t o = 0;
@@ -487,7 +487,7 @@ femk::SeedLayout make_layout_join(const fem_params &p, bool banked) {
   l.X = take(64u * 4u);
   l.A = take(3u * (femk::dense_flag_cap((int)R) + 1u) * 4u);
   l.B = take(2u * femk::kReadBlock * 8u);
-  l.F = take(femk::join_bitmap_words((int)R) * 4u);
+  l.F = take(femk::join_bitmap_words((int)R, padded) * 4u);
   if (banked) l.gq = take(2u * 64u * 8u);  // a strand's candidates of bank after bank (seed_join_body<R, true>)
   l.wave_bytes = o;
   l.picked = 0;  // the block's sequence table: set by the launcher (behind the waves' regions)
@@ -518,9 +518,9 @@ JoinKernel join_kernel(int R, int which) {
       {femk::seed_join_banked_kernel_r1, femk::seed_join_banked_kernel_r2, femk::seed_join_banked_kernel_r3, femk::seed_join_banked_kernel_r4,
        femk::seed_join_banked_kernel_r5, femk::seed_join_banked_kernel_r6, femk::seed_join_banked_kernel_r7, femk::seed_join_banked_kernel_r8,
        femk::seed_join_banked_kernel_r9, femk::seed_join_banked_kernel_r10},
-      {femk::seed_join_padded_kernel_r1, femk::seed_join_padded_kernel_r2, femk::seed_join_padded_kernel_r3, femk::seed_join_padded_kernel_r4,
-       femk::seed_join_padded_kernel_r5, femk::seed_join_padded_kernel_r6, femk::seed_join_padded_kernel_r7, femk::seed_join_padded_kernel_r8,
-       femk::seed_join_padded_kernel_r9, femk::seed_join_padded_kernel_r10}};
+      {femk::seed_join_kernel_padded_r1, femk::seed_join_kernel_padded_r2, femk::seed_join_kernel_padded_r3, femk::seed_join_kernel_padded_r4,
+       femk::seed_join_kernel_padded_r5, femk::seed_join_kernel_padded_r6, femk::seed_join_kernel_padded_r7, femk::seed_join_kernel_padded_r8,
+       femk::seed_join_kernel_padded_r9, femk::seed_join_kernel_padded_r10}};
   return k[which][std::min(std::max(R, 1), femk::kMaxR) - 1];
 }
 
@@ -954,7 +954,7 @@ int launch_batch(fem_dev *h, Slot &s) {
       fp.lay = make_layout_select(p, max_len);
       if (fp.lay.wave_bytes > 64u * 1024u) return fail(h, FEM_ERR_UNSUPPORTED, "read too long for the device path");
       const femk::SeedLayout lay_select = fp.lay;
-      femk::SeedLayout lay_join = make_layout_join(p, banked);
+      femk::SeedLayout lay_join = make_layout_join(p, banked, !banked && h->list_shift != 0);
       const uint32_t wpb_s = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (64u * 1024u) / lay_select.wave_bytes));
       const uint32_t wpb_j = std::min<uint32_t>(4u, std::max<uint32_t>(1u, (60u * 1024u) / lay_join.wave_bytes));
       lay_join.picked = wpb_j * lay_join.wave_bytes;

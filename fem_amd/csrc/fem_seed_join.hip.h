@@ -50,7 +50,10 @@ namespace femk {
 #ifndef FEM_JOIN_ABL
 #define FEM_JOIN_ABL 0
 #endif
-constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768u; }
+#ifndef FEM_JOIN_SLOTS_LO
+#define FEM_JOIN_SLOTS_LO 32768u
+#endif
+constexpr uint32_t join_slots(int R, bool padded = false) { return R >= 7 ? FEM_JOIN_SLOTS_HI : padded ? FEM_JOIN_SLOTS_LO : 32768u; }
 // Chunks whose LDS steps are issued together at R >= 7 (see join_read).  Round 3: one — with the 80 registers of six waves per
 // SIMD five blocks of the join fit a CU beside the selection (C5: 120 -> 140 Mreads/s; three chunks at a time 134).  Round 4,
 // after the diet freed registers: three fit the same 80 (C5 join, ms per 2.5 M reads: 1: 13.66, 2: 13.63, 3: 13.44, 4: 13.45,
@@ -59,7 +62,7 @@ constexpr uint32_t join_slots(int R) { return R >= 7 ? FEM_JOIN_SLOTS_HI : 32768
 #define FEM_JOIN_BATCH_HI 3
 #endif
 
-constexpr uint32_t join_bitmap_words(int R) { return join_slots(R) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
+constexpr uint32_t join_bitmap_words(int R, bool padded = false) { return join_slots(R, padded) / 32u + 4u; }  // + the guard word (all ones), 16-byte padded
 
 __device__ __forceinline__ void lds_or(uint32_t *w, uint32_t bits) {
   (void)__hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -79,8 +82,9 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
                           uint32_t *flg /* LDS [3][dense_flag_cap + 1] */, uint32_t *scatter /* LDS [64] */,
                           uint32_t *cand_lds, uint32_t &kept0, uint32_t &kept1, uint32_t seq_base = 0u /* first sequence of the bank */) {
   const uint32_t ln = lane_id();
-  constexpr uint32_t kSlots = join_slots(R);
-  constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : 15u;
+  constexpr uint32_t kSlots = join_slots(R, PADDED);
+  constexpr uint32_t kSlotBits = kSlots == 65536u ? 16u : kSlots == 32768u ? 15u : 14u;
+  static_assert(kSlots == (1u << kSlotBits), "a power of two of slots: 16, 32 or 64 Ki");
   constexpr uint32_t kWordBits = kSlotBits - 5u;     // words of 32 slots
   constexpr uint32_t kWords = kSlots / 32u;          // the guard word sits at bitmap[kWords]
   constexpr uint32_t kPeriodBits = kSlotBits + 3u;   // values this many bits apart share a slot
@@ -115,7 +119,7 @@ __device__ bool join_read(const SeedParams &p, uint32_t s_start, uint32_t s_lo, 
   // run sent_b (256 apart = one word, beyond the first family's range of 64 x 2304).  All of them are >= kDenseVLimit and
   // more than e from each other.
   const uint32_t sent_a = 0xF0000000u + ln * 2304u, sent_b = 0xF0000000u + 149504u + (ln << 8);
-  static_assert(64u * 2304u + 2048u == 149504u && 149504u + 64u * 256u + 2048u < (1u << kPeriodBits), "sentinel families inside one period");
+  static_assert(PADDED || (64u * 2304u + 2048u == 149504u && 149504u + 64u * 256u + 2048u < (1u << kPeriodBits)), "sentinel families inside one period");
   // all-pairs filter: which of four ballots holds lane i's row (i >> 2), and where in it (16 (i & 3))
   const uint64_t q_is1 = __builtin_amdgcn_ballot_w64((ln >> 2) == 1u), q_is2 = __builtin_amdgcn_ballot_w64((ln >> 2) == 2u),
                  q_is3 = __builtin_amdgcn_ballot_w64((ln >> 2) == 3u);
@@ -624,7 +628,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
   const bool small_ref = p.n_seq <= (uint32_t)kWave;
   if (wave_in_block == 0) seqtab[ln] = ln < p.n_seq ? make_uint2(p.goff[ln], p.seq_len[ln]) : make_uint2(0xFFFFFFFFu, 0u);
   __syncthreads();
-  for (uint32_t i = ln; i < join_bitmap_words(R); i += kWave) bitmap[i] = i < join_slots(R) / 32u ? 0u : 0xFFFFFFFFu;  // (guard word)
+  for (uint32_t i = ln; i < join_bitmap_words(R, PADDED); i += kWave) bitmap[i] = i < join_slots(R, PADDED) / 32u ? 0u : 0xFFFFFFFFu;  // (guard word)
   wave_sync_lds();
   unsigned long long pre_sum = 0, cand_sum = 0;
   SlotChunk chunk, qchunk;
@@ -846,7 +850,7 @@ __device__ __forceinline__ void seed_join_body(const SeedParams &p, uint8_t *sme
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R, true>(p, smem);                                                                                            \
   }                                                                                                                              \
-  __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) seed_join_padded_kernel_r##R(SeedParams p) { /* the strided table with pads */ \
+  __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) seed_join_kernel_padded_r##R(SeedParams p) { /* the strided table with pads */ \
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                                                               \
     seed_join_body<R, false, true>(p, smem);                                                                                     \
   }

@@ -1,7 +1,7 @@
 """Regenerates the rocprofv3 summaries under profiles/ (run on the GPU box, from the repo root):
 
-    python3 profiles/make_profiles.py calib       # -> profiles/r04_fetch_calibration.json
-    python3 profiles/make_profiles.py c3          # -> profiles/r04_c3_kernel_stats.csv, r04_c3_kernel_times.json, r04_c3_hbm_traffic.json
+    python3 profiles/make_profiles.py calib       # -> profiles/r05_fetch_calibration.json
+    python3 profiles/make_profiles.py c3          # -> profiles/r05_c3_kernel_stats.csv, r05_c3_kernel_times.json, r05_c3_hbm_traffic.json
 
 Every file carries `git_head` and `kernel_sources_sha16` (bench.kernel_sources_sha16: a hash of fem_amd/csrc/*.hip*): bench.py
 takes `roofline.traffic` from a profile only if the hash is that of the sources it runs on.
@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("FEM_PROFILE_ROUND", "r04")
+ROUND = os.environ.get("FEM_PROFILE_ROUND", "r05")
 PMC_GROUPS = [  # the derived TCC counters each fill the hardware's counter slots: one per pass
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
