@@ -207,6 +207,7 @@ struct fem_seqfile {
   size_t zlen = 0, zpos = 0;
   int threads = 1;  // host threads the caller of the current batch call allows
   bool fast_ok = true;        // 4-line FASTQ so far: the multi-threaded parser may be used
+  bool read_again = false;    // the mapping's pages are read a second time (the spliced formatter): no longer advised as sequential
   int last_char = 0;  // header character already consumed by the previous record
   std::string name, comment, seq, qual;
   // one record; returns sequence length, -1 end of file, -2 truncated quality, -3 stream error
@@ -988,7 +989,7 @@ int fem_seqfile_fill(fem_seqfile *f, fem_batch_plan *pl, int n_threads, char *ba
 // min_len == max_len == read_len).  Returns 1 — and leaves the plan alive for fem_seqfile_fill — when the batch holds more
 // non-ACGT characters than exc_cap.
 static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
-                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, const fem_read_refs *refs);
+                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, fem_read_refs *refs);
 
 int fem_seqfile_fill_packed(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
                             uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off) {
@@ -1004,11 +1005,17 @@ int fem_seqfile_fill_packed_refs(fem_seqfile *f, fem_batch_plan *pl, int n_threa
                                  uint64_t *n_exc_out, fem_read_refs *refs) {
   if (!f || !pl || !refs || !refs->name || !refs->name_len || !refs->seq || !refs->qual) return -1;
   if (!pl->fast || !f->map || pl->m != f->map) return 2;
+  if (!f->read_again) {
+    // the formatter comes back to these records long after the parser's pass: under MADV_SEQUENTIAL (fem_seqfile_open) the
+    // pages behind the parser are the first to go, and a file larger than the page cache would be read from disk twice
+    (void)madvise((void *)f->map, f->map_len, MADV_NORMAL);
+    f->read_again = true;
+  }
   return fill_packed_impl(f, pl, n_threads, read_len, codes, exc_cap, n_exc_out, nullptr, nullptr, nullptr, refs);
 }
 
 static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
-                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, const fem_read_refs *refs) {
+                            uint64_t *n_exc_out, char *quals, char *names, uint64_t *name_off, fem_read_refs *refs) {
   if (!f || !pl || !codes || !n_exc_out || read_len == 0) return -1;
   if (n_threads < 1) n_threads = 1;
   const uint32_t bpr = fempack::bytes_per_read(read_len);
@@ -1048,8 +1055,8 @@ static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, u
         if (rec.len == 0) continue;
         fempack::pack_bases((const uint8_t *)rec.seq, read_len, codes + r * bpr, r * (uint64_t)read_len, exc[(size_t)t]);
         if (refs) {  // nothing else is copied: the formatter takes the fields from the mapping
-          ((const char **)refs->name)[r] = rec.name, ((uint32_t *)refs->name_len)[r] = (uint32_t)rec.name_len;
-          ((const char **)refs->seq)[r] = rec.seq, ((const char **)refs->qual)[r] = rec.qual;
+          refs->name[r] = rec.name, refs->name_len[r] = (uint32_t)rec.name_len;
+          refs->seq[r] = rec.seq, refs->qual[r] = rec.qual;
         } else {
           name_off[r] = nm;
           if (quals) memcpy(quals + r * (uint64_t)read_len, rec.qual, rec.len);
@@ -1072,7 +1079,7 @@ static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, u
   for (const auto &v : exc)
     for (uint64_t x : v) *exc_pos++ = (uint32_t)(x >> 8), *exc_chr++ = (uint8_t)x;
   *n_exc_out = n_exc;
-  if (refs) ((fem_read_refs *)refs)->n = n_total, ((fem_read_refs *)refs)->read_len = read_len;
+  if (refs) refs->n = n_total, refs->read_len = read_len;
   fem_batch_plan_free(pl);
   return 0;
 }

@@ -65,6 +65,7 @@ def lib():
         L.fem_seqfile_plan.argtypes = [vp, u64, C.c_int, C.POINTER(vp), C.POINTER(BatchShape)]
         L.fem_seqfile_fill.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
         L.fem_seqfile_fill_packed.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, u64, C.POINTER(u64), vp, vp, vp]
+        L.fem_seqfile_fill_packed_refs.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, u64, C.POINTER(u64), vp]
         L.fem_batch_plan_free.argtypes = [vp]
         L.fem_records_sam.argtypes = [C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(RecordView), C.c_int, C.POINTER(vp),
                                       C.POINTER(u64)]
@@ -257,6 +258,68 @@ class PackedBatch:
         pos = self.codes[exc_off:exc_off + 4 * self.n_exc].view(np.uint32)
         out[pos] = self.codes[exc_off + 4 * self.n_exc:exc_off + 5 * self.n_exc]
         return out
+
+
+class _ReadRefs(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("read_len", C.c_uint32), ("name", C.c_void_p), ("name_len", C.c_void_p), ("seq", C.c_void_p),
+                ("qual", C.c_void_p)]
+
+
+def read_refs_batches(path, approx_bytes, threads=4, exc_cap=None):
+    """The splice form of the command line (fem_seqfile_fill_packed_refs): per batch (rc, records) where rc is what the call
+    returned — 0: the fields were read through the pointers it filled (into the file's mapping) and the bases also unpacked
+    from the codes; 1 (too many characters outside ACGT) / 2 (the records do not sit in a mapping that stays): the plan was
+    left alone and fem_seqfile_fill took the batch.  records = list of (name, seq, qual), seq twice where rc == 0."""
+    L = lib()
+    f = L.fem_seqfile_open(path.encode())
+    if not f:
+        raise FileNotFoundError(path)
+    out = []
+    try:
+        while True:
+            plan, shape = C.c_void_p(), BatchShape()
+            rc = L.fem_seqfile_plan(f, approx_bytes, threads, C.byref(plan), C.byref(shape))
+            if rc != 0:
+                if plan:
+                    L.fem_batch_plan_free(plan)
+                raise ValueError("malformed sequence file %s (rc=%d)" % (path, rc))
+            if shape.n_reads == 0:
+                L.fem_batch_plan_free(plan)
+                break
+            n, nb = int(shape.n_reads), int(shape.n_bases)
+            rc = 1
+            if shape.min_len == shape.max_len:
+                rl = int(shape.max_len)
+                bpr = (rl + 3) // 4
+                exc_off = (n * bpr + 7) & ~7
+                cap = min((nb + 64 - min(exc_off, nb + 64)) // 5, nb // 16) if exc_cap is None else exc_cap
+                codes = np.zeros(nb + 64, np.uint8)
+                name, seq, qual = (np.zeros(n, np.uint64) for _ in range(3))
+                name_len = np.zeros(n, np.uint32)
+                refs = _ReadRefs(0, 0, name.ctypes.data, name_len.ctypes.data, seq.ctypes.data, qual.ctypes.data)
+                n_exc = C.c_uint64()
+                rc = L.fem_seqfile_fill_packed_refs(f, plan, threads, rl, codes.ctypes.data, cap, C.byref(n_exc), C.byref(refs))
+                if rc == 0:
+                    assert refs.n == n and refs.read_len == rl
+                    unpacked = PackedBatch(shape, codes, n_exc.value, None, None, None).unpack().tobytes()
+                    recs = [(C.string_at(int(name[i]), int(name_len[i])), C.string_at(int(seq[i]), rl), C.string_at(int(qual[i]), rl),
+                             unpacked[i * rl:(i + 1) * rl]) for i in range(n)]
+                    out.append((0, recs))
+                    continue
+                if rc not in (1, 2):
+                    raise ValueError("fem_seqfile_fill_packed_refs failed (%d)" % rc)
+            bases, off = np.zeros(nb + 64, np.uint8), np.zeros(n + 1, np.uint64)
+            quals = np.zeros(nb + 1, np.uint8)
+            names = np.zeros(int(shape.n_name_bytes) + 1, np.uint8)
+            name_off = np.zeros(n + 1, np.uint64)
+            if L.fem_seqfile_fill(f, plan, threads, bases.ctypes.data, off.ctypes.data, quals.ctypes.data, names.ctypes.data, name_off.ctypes.data) != 0:
+                raise ValueError("fem_seqfile_fill failed")
+            b = PlannedBatch(shape, bases, off, quals, names, name_off)
+            as_bytes = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+            out.append((rc, [(as_bytes(b.name(i)), as_bytes(b.seq(i)), as_bytes(b.qual(i))) for i in range(n)]))
+    finally:
+        L.fem_seqfile_close(f)
+    return out
 
 
 def read_planned_batches(path, approx_bytes, threads=4, alloc=None, packed=False):

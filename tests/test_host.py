@@ -497,3 +497,36 @@ def test_packed_generator_equals_the_character_generator():
         q = np.stack([(c >> (2 * j)) & 3 for j in range(4)], axis=2).reshape(n, bpr * 4)
         assert np.array_equal(util.ACGT[q[:, :L]].reshape(-1), bases[:n * L])
         assert not q[:, L:].any() and not out[n * bpr:(n * bpr + 7) & ~7].any() and out[-1] == 0xAA
+
+
+def test_reads_taken_by_reference_from_the_files_mapping(tmp_path):
+    # fem_seqfile_fill_packed_refs (what `FEM map` runs with FEM_HOST_FORMAT=1): name, bases and qualities of every read are
+    # where the pointers say, in the file's mapping; the codes unpack to the same bases.  Where that cannot be — a gzip file
+    # (2), more characters outside ACGT than the batch may carry (1) — the plan is left alone and fem_seqfile_fill takes it.
+    rng = np.random.default_rng(303)
+    L, n = 75, 4000
+    recs = []
+    for i in range(n):
+        seq = bytearray(util.rand_seq(rng, L))
+        if i % 9 == 0:
+            seq[int(rng.integers(0, L))] = ord("N")
+        qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8))
+        recs.append((b"r%d/1 x" % i, bytes(seq), qual))
+    fq = tmp_path / "refs.fq"
+    fq.write_bytes(b"".join(b"@" + nm + b"\n" + sq + b"\n+\n" + ql + b"\n" for nm, sq, ql in recs))
+    want = [(nm.split(b" ")[0], sq, ql) for nm, sq, ql in recs]
+    for approx, threads in ((0, 3), (100_000, 4)):
+        got = host.read_refs_batches(str(fq), approx, threads=threads)
+        assert all(rc == 0 for rc, _ in got)
+        flat = [r for _, rs in got for r in rs]
+        assert [(nm, sq, ql) for nm, sq, ql, _ in flat] == want
+        assert all(sq == un for _, sq, _, un in flat)  # the 2-bit codes + exceptions rebuild the same bases
+    # 1: no room for the batch's N's — the same plan goes through fem_seqfile_fill
+    got = host.read_refs_batches(str(fq), 0, threads=2, exc_cap=3)
+    assert [rc for rc, _ in got] == [1] and [r[:3] for r in got[0][1]] == want
+    # 2: a gzip file's windows are reused: no pointers into them
+    gzp = tmp_path / "refs.fq.gz"
+    with gzip.open(str(gzp), "wb", compresslevel=1) as f:
+        f.write(fq.read_bytes())
+    got = host.read_refs_batches(str(gzp), 1 << 18, threads=3)
+    assert all(rc == 2 for rc, _ in got) and [r[:3] for _, rs in got for r in rs] == want
