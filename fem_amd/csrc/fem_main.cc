@@ -403,7 +403,9 @@ int map_main(int argc, char **argv) {
   }
   std::atomic<int> exit_code{0};
   // The SAM text of a batch is a handful of stretches (one per formatter thread), written one after the other.  (Side
-  // by side with pwrite from four threads was tried: 2.8 GB/s on tmpfs against 5.5 GB/s from one thread.)
+  // by side with pwrite from four threads was tried twice: round 3 on tmpfs, 2.8 GB/s against 5.5 from one thread; round 5 on
+  // the GPU box's /tmp, where four writers into four FILES take 56-61 GB/s against 16.5 from one: into ONE file 10.4 GB/s with
+  // one, four or eight writers — buffered writes to a file take its inode's lock.)
   auto write_all = [&](const char *p, uint64_t n) -> bool {
     while (n) {
       ssize_t w = write(out_fd, p, n);
