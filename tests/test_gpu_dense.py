@@ -245,3 +245,45 @@ def test_overlapped_pipeline_on_a_forced_dense_index(banked):
         _run_overlapped(dev, items[:10], False, form="packed_commit")
     finally:
         dev.close()
+
+
+def test_a_batch_that_meets_an_idle_device_is_mapped_in_parts_with_the_same_result(dense):
+    """launch_batch (fem_hip.hip): a batch committed to an idle device is copied, selected and joined in two parts (the
+    pipeline's fill).  Same batch, same slot: in parts (idle device, the default), whole (FEM_NO_PARTS handle), in four
+    parts (FEM_PARTS=4) — candidates, verification and counters must be identical; the dense index says what it runs on."""
+    from fem_amd import Device, host
+    d = dense
+    assert "dense: 32-bit occurrence table, compact" in d["dev"].index_info() and "1 bank" in d["dev"].index_info()
+    n, L, e = 300_000, 100, 3
+    bases, offsets = host.synth_reads(991, d["text"], d["off"], d["lens"], n, L, e, threads=8)
+    hb, _ = d["dev"].acquire_stage(n, n * L, slot=2)
+    host.synth_reads_packed(991, d["text"], d["off"], d["lens"], n, L, e, hb, first_read=0, threads=8)
+    d["dev"].commit_stage_packed(n, L, 0, slot=2)  # nothing in flight on this handle: in parts
+    d["dev"].map_staged(e=e, a=1, slot=2)
+    in_parts = d["dev"].fetch(slot=2)
+    got = d["dev"].map_batch(bases, offsets, e=e, a=1, slot=1)  # (characters through fem_dev_stage_reads: the same reads)
+    for x, y in zip(in_parts.per_strand(), got.per_strand()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(in_parts.stats, got.stats)
+    seqs = [d["text"][int(o):int(o) + int(l)] for o, l in zip(d["off"], d["lens"])]
+    for env in ({"FEM_NO_PARTS": "1"}, {"FEM_PARTS": "4", "FEM_FORCE_DENSE": "1"}):  # (the second: the padded strided table)
+        os.environ.update(env)
+        try:
+            other = Device(0)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        try:
+            other.upload_reference(seqs)
+            other.build_index(12, 3, fetch=False)
+            assert ("strided with pads" in other.index_info()) == ("FEM_FORCE_DENSE" in env), other.index_info()
+            hb2, _ = other.acquire_stage(n, n * L, slot=0)
+            hb2[:len(hb)] = hb
+            other.commit_stage_packed(n, L, 0, slot=0)
+            other.map_staged(e=e, a=1, slot=0)
+            r = other.fetch(slot=0)
+            for x, y in zip(in_parts.per_strand(), r.per_strand()):
+                assert np.array_equal(x, y), env
+            assert np.array_equal(in_parts.stats, r.stats), env
+        finally:
+            other.close()
