@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -74,6 +75,10 @@ struct Slot {
   uint64_t *d_name_off = nullptr;
   size_t d_quals_cap = 0, d_names_cap = 0, d_name_off_cap = 0;
   bool text_staged = false;
+  hipStream_t text_stream = nullptr;   // qualities and names go to the device beside the batch's kernels, not in front of them
+  hipEvent_t ev_text_staged = nullptr; // ... and have arrived (the SAM text's kernels wait for it)
+  hipEvent_t ev_text_order = nullptr;  // the slot's last SAM text has been rendered (its kernels read the same arrays)
+  bool have_text_order = false;
   uint8_t *d_packed = nullptr;            // packed transfer (fem_dev_stage_reads): 2-bit codes + positions of other characters
   size_t packed_cap = 0;
   uint32_t *d_exc_bits = nullptr;         // ... bit r: read r has such a character (the device tail reads the others' bases from d_packed)
@@ -219,6 +224,7 @@ struct fem_dev {
   // a thread each, so that one batch's host round trips — records counted, text sized — do not hold up the next one's): what
   // the slots share (the kernels' chaining events, the event pool, the timing sums, the error string) is touched under this
   // lock; a thread waiting for the device does not hold it.
+  femt::TextGate text_gate;  // one SAM text on its way to the host at a time (fem_tail.hip.h)
   std::recursive_mutex mu;
   int device = 0;
   StagePool *stage_pool = nullptr;  // host threads of fem_dev_stage_reads
@@ -728,7 +734,9 @@ int grow_candidates(fem_dev *h, Slot &s, uint64_t want) {
 
 // The link is handed from one batch's copy to the next: call before and after a slot's H2D copies.
 int h2d_begin(fem_dev *h, Slot &s) {
-  if (h->have_h2d_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_h2d_done, 0));
+  // (nothing to wait for once the previous copy is through: a wait on an event of another slot's stream is not free in this
+  //  runtime even then)
+  if (h->have_h2d_done && hipEventQuery(h->ev_h2d_done) != hipSuccess) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_h2d_done, 0));
   return FEM_OK;
 }
 int h2d_end(fem_dev *h, Slot &s) {
@@ -1359,6 +1367,12 @@ const char *fem_strerror(int rc) {
 
 const char *fem_dev_last_error(const fem_dev *h) { return h ? h->err.c_str() : "null handle"; }
 
+static std::atomic<int> g_blocking_waits{0};
+int fem_set_blocking_waits(int on) {
+  g_blocking_waits.store(on ? 1 : 0);
+  return FEM_OK;
+}
+
 int fem_dev_open(int device, fem_dev **out) {
   if (!out) return FEM_ERR_INVALID;
   *out = nullptr;
@@ -1372,6 +1386,9 @@ int fem_dev_open(int device, fem_dev **out) {
     delete h;
     return FEM_ERR_HIP;
   }
+  // Threads that wait for the device sleep instead of spinning (fem_set_blocking_waits): FEM map has a thread per batch in
+  // flight waiting most of the time, on hosts where the parser wants every core (16 M reads: 15.6 -> 13.9 cores busy).
+  if (g_blocking_waits.load() || testing_switch("FEM_BLOCKING_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
   for (int i = 0; i < kSlots; ++i) {
@@ -1441,6 +1458,9 @@ int fem_dev_close(fem_dev *h) {
                     (void *)s.h_count8, (void *)s.h_seg, (void *)s.h_pcand, (void *)s.h_ped, (void *)s.h_pend, (void *)s.h_big})
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.text_stream) (void)hipStreamDestroy(s.text_stream);
+    if (s.ev_text_staged) (void)hipEventDestroy(s.ev_text_staged);
+    if (s.ev_text_order) (void)hipEventDestroy(s.ev_text_order);
     delete s.tail;
     s.tail = nullptr;
   }
@@ -2073,6 +2093,7 @@ int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint6
   Slot &s = h->slot[slot];
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(s.stream));  // the previous batch's copies out of these buffers are done
+  if (s.text_stream) HIP_TRY(h, hipStreamSynchronize(s.text_stream));
   if ((rc = pinned_realloc(h, &s.h_quals, &s.h_quals_cap, (size_t)n_bases_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_names, &s.h_names_cap, (size_t)n_name_bytes_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_name_off, &s.h_name_off_cap, (size_t)n_reads_cap + 1))) return rc;
@@ -2099,6 +2120,57 @@ int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_base
   return FEM_OK;
 }
 
+int fem_dev_reserve_batch(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_records, uint32_t max_len, const fem_params *p) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  FEM_LOCK(h);
+  if (!params_ok(p)) return fail(h, FEM_ERR_INVALID, "parameters out of range (k 1..16, step 1..16, e 0..7, a 0..2)");
+  if (!h->d_lookup) return fail(h, FEM_ERR_STATE, "the index must be uploaded first (what a batch needs depends on it)");
+  if (n_reads == 0 || n_reads > 0x7FFFFFF0ull || n_records > 0xFFFFFFF0ull || max_len == 0 || max_len > kMaxReadLen)
+    return fail(h, FEM_ERR_INVALID, "batch shape out of range");
+  Slot &s = h->slot[slot];
+  if (s.mapped && !s.synced) return fail(h, FEM_ERR_STATE, "a batch is in flight in this slot");
+  HIP_TRY(h, hipSetDevice(h->device));
+  // the mapping's own arrays: per read, per candidate (ensure_outputs sizes them by the slot's read count), the packed form's
+  const uint64_t n_was = s.n_reads;
+  s.n_reads = n_reads;
+  rc = ensure_outputs(h, s);
+  s.n_reads = n_was;
+  if (rc) return rc;
+  const uint64_t n_bases = n_reads * (uint64_t)max_len;
+  if ((rc = dev_realloc(h, &s.d_packed, &s.packed_cap, (size_t)fempack::code_bytes(n_reads, max_len) + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_bases_alloc, &s.bases_cap, kFrontPad + (size_t)n_bases + 64))) return rc;
+  if ((rc = dev_realloc(h, &s.d_off, &s.off_cap, (size_t)n_reads + 1))) return rc;
+  if ((rc = dev_realloc(h, &s.d_exc_bits, &s.exc_bits_cap, (size_t)n_reads / 32 + 2))) return rc;
+  if (h->d_occ32 && h->d_freq11 && p->k == 12 && p->step == 3) {  // dense index: the selection's hand-over to the join
+    const size_t R = (size_t)(p->e + 1 + p->a);
+    if ((rc = dev_realloc(h, &s.d_sel, &s.sel_cap, (size_t)n_reads * 6u * R * h->n_banks))) return rc;
+    if ((rc = dev_realloc(h, &s.d_sel_hdr, &s.sel_hdr_cap, (size_t)n_reads))) return rc;
+  }
+  // the mapping tail and the SAM text's bookkeeping
+  if (!s.tail) s.tail = new (std::nothrow) femt::Tail();
+  if (!s.tail) return fail(h, FEM_ERR_NOMEM, "out of host memory");
+  std::string err;
+  if ((rc = s.tail->reserve((uint32_t)n_reads, (uint32_t)n_records, max_len, p->e, h->tiny_buffers, &err))) return fail(h, rc, err);
+  // first uses: the slot's streams (a stream's queue is made by its first command) and the tail's code object
+  if (!s.text_stream) HIP_TRY(h, hipStreamCreateWithFlags(&s.text_stream, hipStreamNonBlocking));
+  HIP_TRY(h, hipMemsetAsync(s.d_sel_hdr ? (void *)s.d_sel_hdr : (void *)s.d_off, 0, 8, s.text_stream));
+  HIP_TRY(h, hipStreamSynchronize(s.text_stream));
+  HIP_TRY(h, hipMemsetAsync(s.d_off, 0, 8, h->side_stream));
+  HIP_TRY(h, hipStreamSynchronize(h->side_stream));
+  // ... and the copy paths a batch takes, in both directions, from and to the buffers it will use
+  const size_t probe = 1u << 20;
+  if (s.h_bases && s.h_bases_cap >= probe && s.bases_cap >= kFrontPad + probe)
+    HIP_TRY(h, hipMemcpyAsync(s.d_bases_alloc + kFrontPad, s.h_bases, probe, hipMemcpyHostToDevice, s.stream));
+  if (s.h_quals && s.d_quals && s.h_quals_cap >= probe && s.d_quals_cap >= probe)
+    HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, probe, hipMemcpyHostToDevice, s.text_stream));
+  HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(h, hipStreamSynchronize(s.text_stream));
+  HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if ((rc = s.tail->warm(s.stream, &err))) return fail(h, rc, err);
+  return FEM_OK;
+}
+
 int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
@@ -2115,9 +2187,16 @@ int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n
   if ((rc = dev_realloc(h, &s.d_quals, &s.d_quals_cap, (size_t)s.n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_names, &s.d_names_cap, (size_t)n_name_bytes + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_name_off, &s.d_name_off_cap, (size_t)n_reads + 1))) return rc;
-  if (s.n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, s.n_bases, hipMemcpyHostToDevice, s.stream));
-  if (n_name_bytes) HIP_TRY(h, hipMemcpyAsync(s.d_names, s.h_names, n_name_bytes, hipMemcpyHostToDevice, s.stream));
-  HIP_TRY(h, hipMemcpyAsync(s.d_name_off, s.h_name_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  // On a stream of their own: nothing before the SAM text reads them, and on the slot's stream these copies (1.25 times the
+  // characters of the reads: 2.5 ms per million 100-bp reads) stood between the batch's reads and its first kernel.
+  if (!s.text_stream) HIP_TRY(h, hipStreamCreateWithFlags(&s.text_stream, hipStreamNonBlocking));
+  if (!s.ev_text_staged) HIP_TRY(h, hipEventCreateWithFlags(&s.ev_text_staged, hipEventDisableTiming));
+  // (the slot's previous batch may still be rendering its text out of the same arrays)
+  if (s.have_text_order) HIP_TRY(h, hipStreamWaitEvent(s.text_stream, s.ev_text_order, 0));
+  if (s.n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, s.n_bases, hipMemcpyHostToDevice, s.text_stream));
+  if (n_name_bytes) HIP_TRY(h, hipMemcpyAsync(s.d_names, s.h_names, n_name_bytes, hipMemcpyHostToDevice, s.text_stream));
+  HIP_TRY(h, hipMemcpyAsync(s.d_name_off, s.h_name_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.text_stream));
+  HIP_TRY(h, hipEventRecord(s.ev_text_staged, s.text_stream));
   s.text_staged = true;
   return FEM_OK;
 }
@@ -2134,8 +2213,12 @@ int fem_dev_sam_wait(fem_dev *h, int slot) {
 }
 
 static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
+  static const bool trace_host = testing_switch("FEM_FETCH_TIMES");  // host time of the call's three stretches, on stderr
+  const auto t_in = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   int rc = fem_dev_sync(h, slot);
   if (rc) return rc;
+  const double ms_sync = since(t_in);
   if (!out) return fail(h, FEM_ERR_INVALID, "null result");
   Slot &s = h->slot[slot];
   if (!s.text_staged) return fail(h, FEM_ERR_STATE, "qualities and names of this batch were not committed (fem_dev_commit_text_stage)");
@@ -2155,12 +2238,18 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   std::string err;
   rc = s.tail->run(in, s.stream, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr, false);
   if (rc) return fail(h, rc, err);
+  const double ms_run = since(t_in);
   femt::SamInput names{};
   names.quals = s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
   names.ref_names = h->d_ref_names, names.ref_name_off = h->d_ref_name_off;
   femt::SamOutput text{};
-  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait);
+  HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_text_staged, 0));  // qualities and names came on the slot's text stream
+  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait, &h->text_gate);
   if (rc) return fail(h, rc, err);
+  if (!s.ev_text_order) HIP_TRY(h, hipEventCreateWithFlags(&s.ev_text_order, hipEventDisableTiming));
+  HIP_TRY(h, hipEventRecord(s.ev_text_order, s.stream));
+  s.have_text_order = true;
+  if (trace_host) fprintf(stderr, "[fetch_sam] slot %d: mapping synced after %.2f ms, records %.2f, text sized and queued %.2f\n", slot, ms_sync, ms_run, since(t_in));
   if (h->timing) {
     FEM_LOCK(h);
     for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;

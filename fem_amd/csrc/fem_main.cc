@@ -242,6 +242,7 @@ struct BatchBuf {  // everything about the batch that sits in one (GPU, slot) pa
   fem_batch_records rec{};                  // device tail's records (default path)
   fem_batch_result res{};                   // per-candidate outcome (FEM_HOST_TAIL=1)
   double t_submit = 0;
+  double t_slot = 0, t_filled = 0, t_submitted = 0, t_retired = 0, t_text = 0;  // FEM_STAGE_TIMES=2: the batch's way through the stages
 };
 
 struct TextOut {  // one batch of SAM text: parts[i] of buf, in order
@@ -366,6 +367,23 @@ int map_main(int argc, char **argv) {
   std::vector<fem_dev *> devs((size_t)n_gpus, nullptr);
   // FEM_TEST_SHARE_GPU=1 (test hook for one-GPU boxes): all `--gpus N` workers open GPU 0, each with its own handle, and
   // the counters are summed on the host (RCCL refuses two ranks on one device)
+  // What a batch will look like, from the input's first records: the device library then makes a batch's allocations during
+  // the setup (fem_dev_reserve_batch) instead of between the first batches' kernels.
+  uint64_t res_reads = 0;
+  uint32_t res_len = 0;
+  if (device_text) {
+    if (fem_seqfile *f0 = fem_seqfile_open(read_path)) {
+      fem_batch_plan *pl = nullptr;
+      fem_batch_shape sh{};
+      if (fem_seqfile_plan(f0, 1u << 18, 1, &pl, &sh) == 0 && pl && sh.n_reads > 0) {
+        const uint64_t per_record = (2 * sh.n_bases + sh.n_name_bytes) / sh.n_reads + 6;
+        res_reads = batch_bytes / per_record + batch_bytes / per_record / 8 + 1024, res_len = sh.max_len;
+      }
+      fem_batch_plan_free(pl);
+      fem_seqfile_close(f0);
+    }
+  }
+  (void)fem_set_blocking_waits(1);  // (a thread per batch in flight waits for the device; the parser needs the cores)
   const double t_dev = real_time();
   {  // one thread per GPU uploads the replicated reference + index (src/FEM_map.c:135-143)
     std::vector<int> up_rc((size_t)n_gpus, 0);
@@ -386,6 +404,7 @@ int map_main(int argc, char **argv) {
           rc = fem_dev_acquire_stage(devs[(size_t)g], sl, reads_cap0, bases_cap0, &pb, &po);
           if (!rc && device_text) rc = fem_dev_acquire_text_stage(devs[(size_t)g], sl, reads_cap0, bases_cap0, names_cap0, &pq, &pn, &pno);
           if (!rc && device_text) rc = fem_dev_reserve_text(devs[(size_t)g], sl, reads_cap0, bases_cap0, names_cap0, batch_bytes + batch_bytes / 4);
+          if (!rc && device_text && res_reads) rc = fem_dev_reserve_batch(devs[(size_t)g], sl, res_reads, res_reads + res_reads / 8, res_len, &params);
         }
         up_rc[(size_t)g] = rc;
       });
@@ -433,6 +452,13 @@ int map_main(int argc, char **argv) {
     }
 
   double t_start = real_time();
+  auto cpu_seconds = [](double *user, double *sys) {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    *user = ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, *sys = ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
+  };
+  double cpu_u0 = 0, cpu_s0 = 0;
+  cpu_seconds(&cpu_u0, &cpu_s0);
   // -t threads are shared by the two host stages that run side by side (FEM_SPLIT_THREADS=0: each gets all of them)
   const char *sp_env = getenv("FEM_SPLIT_THREADS");
   const bool split = !(sp_env && sp_env[0] == '0') && n_threads >= 4;
@@ -444,7 +470,8 @@ int map_main(int argc, char **argv) {
   (void)fem_dev_limits(devs[0], nullptr, &n_slots);
   // FEM_STAGE_TIMES=1: busy seconds of each pipeline stage on stderr at the end
   const char *st_env = getenv("FEM_STAGE_TIMES");
-  const bool stage_times = st_env && st_env[0] == '1';
+  const bool stage_times = st_env && (st_env[0] == '1' || st_env[0] == '2');
+  const bool batch_times = st_env && st_env[0] == '2';  // ... =2: and every batch's way through them
   double busy_read = 0, busy_text = 0, busy_write = 0;
   double wait_slot = 0, wait_records = 0, wait_text_buf = 0;  // reader waiting for a free slot, formatter for records / a text buffer
   std::vector<double> busy_submit((size_t)n_gpus, 0.0), busy_recycle((size_t)n_gpus, 0.0);
@@ -475,10 +502,16 @@ int map_main(int argc, char **argv) {
         // (this thread must not read the handle's error string, which the GPU's worker thread may be writing: the code says enough)
         if (wrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] SAM text failed: %s\n", fem_strerror(wrc));
         double t0 = real_time();
+        it.b->t_text = t0;
         bool ok = wrc != 0 || it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
         if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
         busy_write += real_time() - t0;
         fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - it.b->t_submit);
+        if (batch_times)
+          fprintf(stderr, "[FEM] batch %lu gpu %d slot %d (ms): slot %.2f filled %.2f submit %.2f..%.2f retired %.2f text home %.2f written %.2f\n",
+                  (unsigned long)it.b->seq, it.b->gpu, it.b->slot, 1e3 * (it.b->t_slot - t_start), 1e3 * (it.b->t_filled - t_start),
+                  1e3 * (it.b->t_submit - t_start), 1e3 * (it.b->t_submitted - t_start), 1e3 * (it.b->t_retired - t_start),
+                  1e3 * (it.b->t_text - t_start), 1e3 * (real_time() - t_start));
         free_q.push(it.b);  // written: the slot's buffers may be refilled
         continue;
       }
@@ -601,6 +634,7 @@ int map_main(int argc, char **argv) {
                  : device_text ? fem_dev_fetch_sam_nowait(h, b->slot, &b->sam)  // (the writer waits for the text itself)
                                : fem_dev_fetch_records(h, b->slot, &b->rec);
         const double waited = real_time() - t0;
+        b->t_retired = t0 + waited;
         deliver(b->seq, [&, b, rc, waited] {
           busy_wait[(size_t)g] += waited;
           if (rc) {
@@ -652,14 +686,22 @@ int map_main(int argc, char **argv) {
                  : b->shape.min_len == b->shape.max_len  // reads of one length: the offsets need not cross the link
                      ? fem_dev_commit_stage_uniform(h, b->slot, b->shape.n_reads, b->shape.max_len)
                      : fem_dev_commit_stage(h, b->slot, b->shape.n_reads, b->shape.max_len);
-        if (!rc && device_text) rc = fem_dev_commit_text_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes);
+        const double t_c1 = real_time();
         if (!rc) rc = fem_dev_map_staged(h, b->slot, &params);
+        const double t_c2 = real_time();
+        // (qualities and names behind the mapping's launches: the call that hands the link 140 MB can wait for room in the copy
+        //  engine's queue, 8-10 ms now and then, and the kernels need none of it)
+        if (!rc && device_text) rc = fem_dev_commit_text_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes);
+        if (batch_times && real_time() - b->t_submit > 1e-3)
+          fprintf(stderr, "[FEM] slow submit (ms): reads committed %.2f, mapping queued %.2f, text committed %.2f\n", 1e3 * (t_c1 - b->t_submit),
+                  1e3 * (t_c2 - t_c1), 1e3 * (real_time() - t_c2));
         if (rc) {
           if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "batch submit", rc);
           work_q[(size_t)g].push(Msg{kRecycle, b});
           continue;
         }
-        busy_submit[(size_t)g] += real_time() - b->t_submit;
+        b->t_submitted = real_time();
+        busy_submit[(size_t)g] += b->t_submitted - b->t_submit;
         b->seq = seq_submit++;
         retire_q.push(b);
       }
@@ -681,6 +723,7 @@ int map_main(int argc, char **argv) {
       if (!b->bases) break;  // its GPU could not provide staging buffers (reported by the worker)
       double t0 = real_time();
       wait_slot += t0 - t_pop;
+      b->t_slot = t0;
       if (t_first_slot == 0) t_first_slot = t0;
       fem_batch_plan *plan = nullptr;
       int rc = fem_seqfile_plan(f, batch_bytes, rd_threads, &plan, &b->shape);
@@ -750,7 +793,8 @@ int map_main(int argc, char **argv) {
         exit_code = EXIT_FAILURE;
         break;
       }
-      if (t_first_filled == 0) t_first_filled = real_time();
+      b->t_filled = real_time();
+      if (t_first_filled == 0) t_first_filled = b->t_filled;
       work_q[(size_t)b->gpu].push(Msg{kFilled, b});
     }
     // (the file stays open until the mapping phase is over: unmapping 4 GB of faulted-in pages takes 0.08 s, which the GPUs
@@ -774,6 +818,10 @@ int map_main(int argc, char **argv) {
             busy_text, busy_write);
     fprintf(stderr, "[FEM] waiting seconds: reader for a free slot %.3f, formatter for records %.3f and for a text buffer %.3f; "
                     "GPU threads: submit %.3f, slot recycling %.3f\n", wait_slot, wait_records, wait_text_buf, bs, br);
+    double cpu_u1 = 0, cpu_s1 = 0;
+    cpu_seconds(&cpu_u1, &cpu_s1);
+    fprintf(stderr, "[FEM] host CPU in the mapping phase: %.3f s user + %.3f s system = %.1f cores on average\n", cpu_u1 - cpu_u0, cpu_s1 - cpu_s0,
+            (cpu_u1 - cpu_u0 + cpu_s1 - cpu_s0) / std::max(1e-9, real_time() - t_start));
     fprintf(stderr, "[FEM] timeline (s after the mapping phase began): first staging slot %.3f, first batch parsed %.3f, input read %.3f, "
                     "devices done %.3f, output written %.3f\n", t_first_slot - t_start, t_first_filled - t_start, t_reader_done - t_start,
             t_workers_done - t_start, real_time() - t_start);

@@ -1189,116 +1189,160 @@ __global__ void __launch_bounds__(256) sam_len_kernel(SamParams p) {
   }
 }
 
-// One wave per record: the long fields by all lanes, the numbers by lane 0.  The kernel is bound by memory latency (a
-// dozen small loads per record, then the fields' bytes), so everything that does not depend on something else is
-// requested together: the record's numbers, then the table entries they point to, then two bytes per lane of every
-// field at once (fields over 128 bytes finish in a loop).
+// One wave per 64 consecutive records.  First every lane takes a record of its own: its numbers (two levels of small loads —
+// 64 records' worth in flight where one record per wave had one, which made the kernel wait for memory 1.4 ms per million
+// records), where each field of its line starts, and the short fields (numbers, separators, tags), written by the lane itself.
+// Then the wave goes through its records two at a time, the long fields (QNAME, RNAME, SEQ, QUAL, MD) a byte per lane, every
+// load of a pair requested before the first store; what a lane knows of record i reaches the others by v_readlane.
 __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = kSamSeqLut[threadIdx.x];
+  __syncthreads();
   const uint32_t ln = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t j = wave; j < p.n_records; j += n_waves) {
-    // level 1
-    const uint32_t r = p.s_read[j];
-    const uint32_t t = p.tid[j];
-    const uint32_t flag = p.flag[j] & 0x7FFFu, pos1 = p.pos0[j] + 1u, nm = p.nm[j];
-    const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1], m0 = p.md_off[j], md_len = p.md_off[j + 1] - m0;
-    const unsigned long long at = p.line_off[j];
-    // level 2
-    const bool primary = p.rec_begin[r] == j;
-    const uint64_t ro = p.read_off[r];
-    const uint32_t L = (uint32_t)(p.read_off[r + 1] - ro);
-    const uint64_t no = p.name_off[r];
-    const uint32_t name_len = (uint32_t)(p.name_off[r + 1] - no);
-    const uint32_t rn0 = p.ref_name_off[t], rname_len = p.ref_name_off[t + 1] - rn0;
-    uint32_t op_a = 0, op_b = 0, op_c = 0;  // the first CIGAR operations (most records have one to three)
-    const uint32_t n_ops = c1 - c0;
-    if (n_ops > 0) op_a = p.cigar[c0];
-    if (n_ops > 1) op_b = p.cigar[c0 + 1];
-    if (n_ops > 2) op_c = p.cigar[c0 + 2];
-    const bool seq = primary && L > 0;
-    // level 3: two bytes per lane of every field
-    const uint32_t k1 = ln + 64u;
-    uint8_t nA = 0, nB = 0, rA = 0, mA = 0, mB = 0, sA = 0, sB = 0, qA = 0, qB = 0;
-    if (ln < name_len) nA = p.names[no + ln];
-    if (k1 < name_len) nB = p.names[no + k1];
-    if (ln < rname_len) rA = p.ref_names[rn0 + ln];
-    if (ln < md_len) mA = p.md[m0 + ln];
-    if (k1 < md_len) mB = p.md[m0 + k1];
-    if (seq) {
-      if (ln < L) sA = p.bases[ro + ln];
-      if (k1 < L) sB = p.bases[ro + k1];
-      if (p.quals) {
-        if (ln < L) qA = p.quals[ro + ln];
-        if (k1 < L) qB = p.quals[ro + k1];
-      }
-    }
-    uint32_t cig = 0;
-    if (n_ops <= 3u) {
-      if (n_ops > 0) cig += dec_digits(op_a >> 4) + 1u;
-      if (n_ops > 1) cig += dec_digits(op_b >> 4) + 1u;
-      if (n_ops > 2) cig += dec_digits(op_c >> 4) + 1u;
-    } else {
-      for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
-    }
-    if (n_ops == 0) cig = 1;
+  const uint32_t j0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64u;
+  if (j0 >= p.n_records) return;
+  const uint32_t n_here = p.n_records - j0 < 64u ? p.n_records - j0 : 64u;
+  const bool mine = ln < n_here;
+  const uint32_t j = j0 + (mine ? ln : n_here - 1u);  // (lanes behind the last record repeat its loads and write nothing)
+  // level 1
+  const uint32_t r = p.s_read[j];
+  const uint32_t t = p.tid[j];
+  const uint32_t flag = p.flag[j] & 0x7FFFu, pos1 = p.pos0[j] + 1u, nm = p.nm[j];
+  const uint32_t c0 = p.cigar_off[j], c1 = p.cigar_off[j + 1], m0 = p.md_off[j], md_len = p.md_off[j + 1] - m0;
+  const unsigned long long at = p.line_off[j];
+  // level 2
+  const bool primary = p.rec_begin[r] == j;
+  const uint64_t ro = p.read_off[r];
+  const uint32_t L = (uint32_t)(p.read_off[r + 1] - ro);
+  const uint64_t no = p.name_off[r];
+  const uint32_t name_len = (uint32_t)(p.name_off[r + 1] - no);
+  const uint32_t rn0 = p.ref_name_off[t], rname_len = p.ref_name_off[t + 1] - rn0;
+  uint32_t op_a = 0, op_b = 0, op_c = 0;  // the first CIGAR operations (most records have one to three)
+  const uint32_t n_ops = c1 - c0;
+  if (n_ops > 0) op_a = p.cigar[c0];
+  if (n_ops > 1) op_b = p.cigar[c0 + 1];
+  if (n_ops > 2) op_c = p.cigar[c0 + 2];
+  const bool seq = primary && L > 0;
+  uint32_t cig = 0;
+  if (n_ops <= 3u) {
+    if (n_ops > 0) cig += dec_digits(op_a >> 4) + 1u;
+    if (n_ops > 1) cig += dec_digits(op_b >> 4) + 1u;
+    if (n_ops > 2) cig += dec_digits(op_c >> 4) + 1u;
+  } else {
+    for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
+  }
+  if (n_ops == 0) cig = 1;
+  // where the line's fields start (offsets from its first byte)
+  const uint32_t o_flag = name_len + 1u;
+  const uint32_t o_rname = o_flag + dec_digits(flag) + 1u;
+  const uint32_t o_pos = o_rname + rname_len + 1u;
+  const uint32_t o_cig = o_pos + dec_digits(pos1) + 5u;
+  const uint32_t o_seq = o_cig + cig + 7u;
+  const uint32_t o_nm = o_seq + (seq ? L + 1u + (p.quals ? L : 1u) : 3u) + 6u;
+  const uint32_t o_md = o_nm + dec_digits(nm) + 6u;
+  if (mine) {  // the short fields of the lane's own record
     uint8_t *w = p.text + at;
-    uint8_t *w_flag = w + name_len + 1u;
-    uint8_t *w_rname = w_flag + dec_digits(flag) + 1u;
-    uint8_t *w_pos = w_rname + rname_len + 1u;
-    uint8_t *w_cig = w_pos + dec_digits(pos1) + 5u;
-    uint8_t *w_seq = w_cig + cig + 7u;
-    uint8_t *w_nm = w_seq + (seq ? L + 1u + (p.quals ? L : 1u) : 3u) + 6u;
-    uint8_t *w_md = w_nm + dec_digits(nm) + 6u;
-    if (ln < name_len) w[ln] = nA;
-    if (k1 < name_len) w[k1] = nB;
-    for (uint32_t k = ln + 128u; k < name_len; k += 64u) w[k] = p.names[no + k];
-    if (ln < rname_len) w_rname[ln] = rA;
-    for (uint32_t k = k1; k < rname_len; k += 64u) w_rname[k] = p.ref_names[rn0 + k];
-    if (ln < md_len) w_md[ln] = mA;
-    if (k1 < md_len) w_md[k1] = mB;
-    for (uint32_t k = ln + 128u; k < md_len; k += 64u) w_md[k] = p.md[m0 + k];
+    w[name_len] = '\t';
+    put_dec(w + o_flag, flag)[0] = '\t';
+    w[o_rname + rname_len] = '\t';
+    uint8_t *q = put_dec(w + o_pos, pos1);
+    q[0] = '\t', q[1] = '2', q[2] = '5', q[3] = '5', q[4] = '\t';
+    q = w + o_cig;
+    if (n_ops == 0) *q++ = '*';
+    if (n_ops <= 3u) {
+      if (n_ops > 0) q = put_dec(q, op_a >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_a & 0xFu];
+      if (n_ops > 1) q = put_dec(q, op_b >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_b & 0xFu];
+      if (n_ops > 2) q = put_dec(q, op_c >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_c & 0xFu];
+    } else {
+      for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t op = p.cigar[c];
+        q = put_dec(q, op >> 4);
+        *q++ = (uint8_t)"MIDNSHP=XB"[op & 0xFu];
+      }
+    }
+    q[0] = '\t', q[1] = '*', q[2] = '\t', q[3] = '0', q[4] = '\t', q[5] = '0', q[6] = '\t';
+    uint8_t *w_seq = w + o_seq;
     if (seq) {
-      if (ln < L) w_seq[ln] = kSamSeqLut[sA];
-      if (k1 < L) w_seq[k1] = kSamSeqLut[sB];
-      for (uint32_t k = ln + 128u; k < L; k += 64u) w_seq[k] = kSamSeqLut[p.bases[ro + k]];
-      if (p.quals) {
-        if (ln < L) w_seq[L + 1u + ln] = qA;
-        if (k1 < L) w_seq[L + 1u + k1] = qB;
-        for (uint32_t k = ln + 128u; k < L; k += 64u) w_seq[L + 1u + k] = p.quals[ro + k];
-      }
+      w_seq[L] = '\t';
+      if (!p.quals) w_seq[L + 1u] = '*';
+    } else {
+      w_seq[0] = '*', w_seq[1] = '\t', w_seq[2] = '*';
     }
-    if (ln == 0) {
-      w[name_len] = '\t';
-      put_dec(w_flag, flag)[0] = '\t';
-      w_rname[rname_len] = '\t';
-      uint8_t *q = put_dec(w_pos, pos1);
-      q[0] = '\t', q[1] = '2', q[2] = '5', q[3] = '5', q[4] = '\t';
-      q = w_cig;
-      if (n_ops == 0) *q++ = '*';
-      if (n_ops <= 3u) {
-        if (n_ops > 0) q = put_dec(q, op_a >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_a & 0xFu];
-        if (n_ops > 1) q = put_dec(q, op_b >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_b & 0xFu];
-        if (n_ops > 2) q = put_dec(q, op_c >> 4), *q++ = (uint8_t)"MIDNSHP=XB"[op_c & 0xFu];
-      } else {
-        for (uint32_t c = c0; c < c1; ++c) {
-          const uint32_t op = p.cigar[c];
-          q = put_dec(q, op >> 4);
-          *q++ = (uint8_t)"MIDNSHP=XB"[op & 0xFu];
-        }
-      }
-      q[0] = '\t', q[1] = '*', q[2] = '\t', q[3] = '0', q[4] = '\t', q[5] = '0', q[6] = '\t';
-      if (seq) {
-        w_seq[L] = '\t';
-        if (!p.quals) w_seq[L + 1u] = '*';
-      } else {
-        w_seq[0] = '*', w_seq[1] = '\t', w_seq[2] = '*';
-      }
-      q = w_nm - 6u;
-      q[0] = '\t', q[1] = 'N', q[2] = 'M', q[3] = ':', q[4] = 'i', q[5] = ':';
-      q = put_dec(w_nm, nm);
-      q[0] = '\t', q[1] = 'M', q[2] = 'D', q[3] = ':', q[4] = 'Z', q[5] = ':';
-      w_md[md_len] = '\n';
+    q = w + o_nm - 6u;
+    q[0] = '\t', q[1] = 'N', q[2] = 'M', q[3] = ':', q[4] = 'i', q[5] = ':';
+    q = put_dec(w + o_nm, nm);
+    q[0] = '\t', q[1] = 'M', q[2] = 'D', q[3] = ':', q[4] = 'Z', q[5] = ':';
+    w[o_md + md_len] = '\n';
+  }
+  // ---- the long fields, record by record, all lanes ----
+  const uint32_t at_lo = (uint32_t)at, at_hi = (uint32_t)(at >> 32), no_lo = (uint32_t)no, no_hi = (uint32_t)(no >> 32);
+  const uint32_t ro_lo = (uint32_t)ro, ro_hi = (uint32_t)(ro >> 32);
+  const uint32_t L_seq = seq ? L : 0u;  // (no SEQ / QUAL bytes on a read's further records)
+  struct Rec {
+    uint8_t *w;
+    const uint8_t *name, *rname, *md, *bases, *quals;
+    uint32_t name_len, rname_len, md_len, L, o_rname, o_md, o_seq;
+  };
+  auto rl = [](uint32_t v, uint32_t i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); };
+  auto record = [&](uint32_t i) -> Rec {
+    Rec x;
+    x.w = p.text + ((uint64_t)rl(at_lo, i) | (uint64_t)rl(at_hi, i) << 32);
+    x.name = p.names + ((uint64_t)rl(no_lo, i) | (uint64_t)rl(no_hi, i) << 32);
+    const uint64_t ro_i = (uint64_t)rl(ro_lo, i) | (uint64_t)rl(ro_hi, i) << 32;
+    x.bases = p.bases + ro_i, x.quals = p.quals ? p.quals + ro_i : nullptr;
+    x.rname = p.ref_names + rl(rn0, i), x.md = p.md + rl(m0, i);
+    x.name_len = rl(name_len, i), x.rname_len = rl(rname_len, i), x.md_len = rl(md_len, i), x.L = rl(L_seq, i);
+    x.o_rname = rl(o_rname, i), x.o_md = rl(o_md, i), x.o_seq = rl(o_seq, i);
+    return x;
+  };
+  struct Bytes {
+    uint8_t n, rn, m, sA, sB, qA, qB;
+  };
+  const uint32_t k1 = ln + 64u;
+  auto load = [&](const Rec &x) -> Bytes {
+    Bytes b{};
+    if (ln < x.name_len) b.n = x.name[ln];
+    if (ln < x.rname_len) b.rn = x.rname[ln];
+    if (ln < x.md_len) b.m = x.md[ln];
+    if (ln < x.L) b.sA = x.bases[ln];
+    if (k1 < x.L) b.sB = x.bases[k1];
+    if (x.quals) {
+      if (ln < x.L) b.qA = x.quals[ln];
+      if (k1 < x.L) b.qB = x.quals[k1];
     }
+    return b;
+  };
+  auto store = [&](const Rec &x, const Bytes &b) {
+    uint8_t *w_seq = x.w + x.o_seq, *w_rname = x.w + x.o_rname, *w_md = x.w + x.o_md;
+    if (ln < x.name_len) x.w[ln] = b.n;
+    if (ln < x.rname_len) w_rname[ln] = b.rn;
+    if (ln < x.md_len) w_md[ln] = b.m;
+    if (ln < x.L) w_seq[ln] = lut[b.sA];
+    if (k1 < x.L) w_seq[k1] = lut[b.sB];
+    if (x.quals) {
+      if (ln < x.L) w_seq[x.L + 1u + ln] = b.qA;
+      if (k1 < x.L) w_seq[x.L + 1u + k1] = b.qB;
+    }
+    // fields beyond what a lane holds (wave-uniform conditions): names and reference names over 64 characters, MD strings
+    // over 64, reads over 128
+    for (uint32_t k = k1; k < x.name_len; k += 64u) x.w[k] = x.name[k];
+    for (uint32_t k = k1; k < x.rname_len; k += 64u) w_rname[k] = x.rname[k];
+    for (uint32_t k = k1; k < x.md_len; k += 64u) w_md[k] = x.md[k];
+    for (uint32_t k = ln + 128u; k < x.L; k += 64u) {
+      w_seq[k] = lut[x.bases[k]];
+      if (x.quals) w_seq[x.L + 1u + k] = x.quals[k];
+    }
+  };
+  uint32_t i = 0;
+  for (; i + 1u < n_here; i += 2u) {
+    const Rec xa = record(i), xb = record(i + 1u);
+    const Bytes ba = load(xa), bb = load(xb);
+    store(xa, ba);
+    store(xb, bb);
+  }
+  if (i < n_here) {
+    const Rec xa = record(i);
+    store(xa, load(xa));
   }
 }
 
@@ -1335,6 +1379,97 @@ Tail::~Tail() { delete impl_; }
     }                                                                              \
   } while (0)
 
+// Everything run() and sam() allocate for a batch of n reads with nr records (device arrays sized by the records, the scans'
+// scratch).  run() calls it with the batch's own numbers; a caller that knows what is coming (fem_dev_reserve_batch) calls it
+// during its setup: thirty allocations per slot otherwise fall into the first batches' way home.
+int Tail::reserve(uint32_t n, uint32_t nr, uint32_t max_len_in, int e, bool tiny, std::string *err) {
+  if (!impl_) impl_ = new (std::nothrow) Impl();
+  if (!impl_) return FEM_ERR_NOMEM;
+  Impl &m = *impl_;
+  const uint32_t fast_ops = std::min<uint32_t>(kOpsCap, 2u * (uint32_t)e + 2u);
+  const uint32_t ops_cap = tiny ? 1u : std::max<uint32_t>(8u, fast_ops), md_cap = tiny ? 2u : kMdCap;
+  (void)max_len_in;
+  TAIL_TRY(m.rec_begin.need(((size_t)n + 1) * 4));
+  TAIL_TRY(m.queue.need(std::max<size_t>(n, 1) * 4));
+  TAIL_TRY(m.ctl.need(16));
+  TAIL_TRY(m.h_ctl.need(32));
+  const size_t r1 = (size_t)nr + 1;
+  TAIL_TRY(m.u_cand.need(r1 * 8));
+  TAIL_TRY(m.u_misc.need(r1 * 4));
+  TAIL_TRY(m.s_cand.need(r1 * 8));
+  TAIL_TRY(m.s_misc.need(r1 * 4));
+  TAIL_TRY(m.s_read.need(r1 * 4));
+  TAIL_TRY(m.t_ops.need(r1 * ops_cap * 4));
+  TAIL_TRY(m.t_md.need(r1 * std::max<uint32_t>(md_cap, 12)));  // doubles as the ordering scratch (8 + 4 bytes per hit)
+  TAIL_TRY(m.ovf.need(r1 * 4));
+  TAIL_TRY(m.rec_list.need(r1 * 4));
+  TAIL_TRY(m.src_slot.need(r1 * 4));
+  TAIL_TRY(m.n_ops.need(r1 * 4));
+  TAIL_TRY(m.n_md.need(r1 * 4));
+  TAIL_TRY(m.flag.need(r1 * 2));
+  TAIL_TRY(m.tid.need(r1 * 4));
+  TAIL_TRY(m.pos0.need(r1 * 4));
+  TAIL_TRY(m.nm.need(r1));
+  TAIL_TRY(m.cigar_off.need(r1 * 4));
+  TAIL_TRY(m.md_off.need(r1 * 4));
+  TAIL_TRY(m.cigar.need(std::max<size_t>((size_t)nr * ops_cap, 1) * 4));
+  TAIL_TRY(m.md.need(std::max<size_t>((size_t)nr * md_cap, 1)));
+  TAIL_TRY(m.line_len.need(r1 * 8));
+  TAIL_TRY(m.line_off.need(r1 * 8));
+  size_t tmp_a = 0, tmp_b = 0, tmp_c = 0;
+  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_a, (const uint32_t *)nullptr, m.rec_begin.as<uint32_t>(), 0u, (size_t)n,
+                                   rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
+  {
+    auto lens = rocprim::make_zip_iterator(rocprim::make_tuple(m.n_ops.as<uint32_t>(), m.n_md.as<uint32_t>()));
+    auto offs = rocprim::make_zip_iterator(rocprim::make_tuple(m.cigar_off.as<uint32_t>(), m.md_off.as<uint32_t>()));
+    TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_b, lens, offs, rocprim::make_tuple(0u, 0u), r1, PairPlus(), (hipStream_t) nullptr));
+  }
+  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_c, m.line_len.as<unsigned long long>(), m.line_off.as<unsigned long long>(), 0ull, r1,
+                                   rocprim::plus<unsigned long long>(), (hipStream_t) nullptr));
+  TAIL_TRY(m.scan_tmp.need(std::max<size_t>(std::max(tmp_a, std::max(tmp_b, tmp_c)), 16)));
+  for (hipEvent_t &ev : m.ev)
+    if (!ev) TAIL_TRY(hipEventCreate(&ev));
+  if (!m.ev_text) TAIL_TRY(hipEventCreateWithFlags(&m.ev_text, hipEventDisableTiming));
+  return FEM_OK;
+}
+
+// The first launch of a kernel loads its code object (this file's: 12-17 ms of host time in front of the first batch's
+// ordering kernels, 7 more in front of its text) and the first use of a stream creates its queue: both belong to the setup.
+// Asks for every kernel's attributes (which loads the code object) and runs the three scans over one element on `stream`.
+int Tail::warm(hipStream_t stream, std::string *err) {
+  if (!impl_) return FEM_ERR_STATE;
+  Impl &m = *impl_;
+  hipFuncAttributes a;
+  const void *kernels[] = {(const void *)gather_kernel, (const void *)sort_kernel, (const void *)trace_ident_kernel,
+                           (const void *)trace_fast_kernel<uint8_t, NoPlane>, (const void *)trace_fast_kernel<uint16_t, NoPlane>,
+                           (const void *)trace_fast_kernel<uint16_t, uint8_t>, (const void *)trace_fast_kernel<uint32_t, NoPlane>,
+                           (const void *)trace_fast_kernel<uint32_t, uint8_t>, (const void *)trace_fast_kernel<uint32_t, uint16_t>,
+                           (const void *)trace_kernel, (const void *)compact_kernel, (const void *)sam_len_kernel,
+                           (const void *)sam_write_kernel};
+  for (const void *k : kernels) TAIL_TRY(hipFuncGetAttributes(&a, k));
+  if (!m.scan_tmp.p || !m.rec_begin.p || !m.n_ops.p || !m.line_len.p) return FEM_OK;  // (nothing reserved: the scans load with the first batch)
+  size_t tmp = m.scan_tmp.cap;
+  TAIL_TRY(hipMemsetAsync(m.n_ops.p, 0, 4, stream));
+  TAIL_TRY(hipMemsetAsync(m.n_md.p, 0, 4, stream));
+  TAIL_TRY(hipMemsetAsync(m.line_len.p, 0, 8, stream));
+  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp, (const uint32_t *)m.n_ops.as<uint32_t>(), m.rec_begin.as<uint32_t>(), 0u, (size_t)1,
+                                   rocprim::plus<uint32_t>(), stream));
+  {
+    auto lens = rocprim::make_zip_iterator(rocprim::make_tuple(m.n_ops.as<uint32_t>(), m.n_md.as<uint32_t>()));
+    auto offs = rocprim::make_zip_iterator(rocprim::make_tuple(m.cigar_off.as<uint32_t>(), m.md_off.as<uint32_t>()));
+    tmp = m.scan_tmp.cap;
+    TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp, lens, offs, rocprim::make_tuple(0u, 0u), (size_t)1, PairPlus(), stream));
+  }
+  tmp = m.scan_tmp.cap;
+  TAIL_TRY(rocprim::exclusive_scan(m.scan_tmp.p, tmp, m.line_len.as<unsigned long long>(), m.line_off.as<unsigned long long>(), 0ull, (size_t)1,
+                                   rocprim::plus<unsigned long long>(), stream));
+  if (m.text.p && m.h_text.p && m.text.cap >= (1u << 20) && m.h_text.cap >= (1u << 20))
+    TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, 1u << 20, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipMemcpyAsync(m.h_ctl.p, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
+  TAIL_TRY(hipStreamSynchronize(stream));
+  return FEM_OK;
+}
+
 int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, TailOutput *out, std::string *err, double *ms,
               bool copy_records) {
   if (!impl_) impl_ = new (std::nothrow) Impl();
@@ -1369,41 +1504,16 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
   // longest possible walk: every step opens a run; the MD of a run never exceeds two characters per column
   const uint32_t o_ops_cap = 2 * max_len + 2 * (uint32_t)in.e + 8, o_md_cap = 8 * max_len + 128;
 
-  TAIL_TRY(m.rec_begin.need(((size_t)n + 1) * 4));
-  TAIL_TRY(m.queue.need(std::max<size_t>(n, 1) * 4));
-  TAIL_TRY(m.ctl.need(16));
-  TAIL_TRY(m.h_ctl.need(32));
-  const size_t r1 = (size_t)nr + 1;
-  TAIL_TRY(m.u_cand.need(r1 * 8));
-  TAIL_TRY(m.u_misc.need(r1 * 4));
-  TAIL_TRY(m.s_cand.need(r1 * 8));
-  TAIL_TRY(m.s_misc.need(r1 * 4));
-  TAIL_TRY(m.s_read.need(r1 * 4));
-  TAIL_TRY(m.t_ops.need(r1 * ops_cap * 4));
-  TAIL_TRY(m.t_md.need(r1 * std::max<uint32_t>(md_cap, 12)));  // doubles as the ordering scratch (8 + 4 bytes per hit)
-  TAIL_TRY(m.ovf.need(r1 * 4));
-  TAIL_TRY(m.rec_list.need(r1 * 4));
-  TAIL_TRY(m.src_slot.need(r1 * 4));
-  TAIL_TRY(m.n_ops.need(r1 * 4));
-  TAIL_TRY(m.n_md.need(r1 * 4));
-  TAIL_TRY(m.flag.need(r1 * 2));
-  TAIL_TRY(m.tid.need(r1 * 4));
-  TAIL_TRY(m.pos0.need(r1 * 4));
-  TAIL_TRY(m.nm.need(r1));
-  TAIL_TRY(m.cigar_off.need(r1 * 4));
-  TAIL_TRY(m.md_off.need(r1 * 4));
-
-  size_t tmp_a = 0, tmp_b = 0;
-  TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_a, (const uint32_t *)in.n_map, m.rec_begin.as<uint32_t>(), 0u, (size_t)n,
-                                   rocprim::plus<uint32_t>(), stream));
+  static const bool trace_host = getenv("FEM_TESTING") && getenv("FEM_FETCH_TIMES");
+  const auto t_in = std::chrono::steady_clock::now();
+  auto since_in = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
   {
-    auto lens = rocprim::make_zip_iterator(rocprim::make_tuple(m.n_ops.as<uint32_t>(), m.n_md.as<uint32_t>()));
-    auto offs = rocprim::make_zip_iterator(rocprim::make_tuple(m.cigar_off.as<uint32_t>(), m.md_off.as<uint32_t>()));
-    TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_b, lens, offs, rocprim::make_tuple(0u, 0u), r1, PairPlus(), stream));
+    const int rrc = reserve(n, nr, max_len, in.e, tiny, err);
+    if (rrc) return rrc;
   }
-  size_t tmp_bytes = std::max(tmp_a, tmp_b);
-  TAIL_TRY(m.scan_tmp.need(std::max<size_t>(tmp_bytes, 16)));
-  tmp_bytes = m.scan_tmp.cap;
+  const double ms_reserved = since_in();
+  const size_t r1 = (size_t)nr + 1;
+  size_t tmp_bytes = m.scan_tmp.cap;
 
   Params p{};
   p.bases = in.bases, p.read_off = in.read_off, p.n_reads = n;
@@ -1454,7 +1564,9 @@ int Tail::run(const TailInput &in, hipStream_t stream, int n_cu, bool tiny, Tail
     }
     TAIL_TRY(hipGetLastError());
     TAIL_TRY(hipMemcpyAsync(h_ctl, m.ctl.p, 16, hipMemcpyDeviceToHost, stream));
+    const double ms_queued = since_in();
     TAIL_TRY(hipStreamSynchronize(stream));
+    if (trace_host) fprintf(stderr, "[tail] allocations %.2f ms, kernels queued %.2f, walked %.2f\n", ms_reserved, ms_queued, since_in());
     n_overflow = h_ctl[1];
     if (getenv("FEM_TESTING") && getenv("FEM_TAIL_DEBUG"))
       fprintf(stderr, "[tail] records %u, queued for ordering %u, walked %u, overflow pass %u, lanes %u/%u\n", nr, h_ctl[0], h_ctl[3], n_overflow, fast_lanes, lanes);
@@ -1574,7 +1686,7 @@ int Tail::wait_text() {
 }
 
 int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms,
-              bool wait) {
+              bool wait, TextGate *gate) {
   if (!impl_ || !out) return FEM_ERR_STATE;
   Impl &m = *impl_;
   const uint32_t nr = m.last_nr;
@@ -1610,14 +1722,25 @@ int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, in
   TAIL_TRY(m.h_text.need(std::max<size_t>((size_t)total + total / 8, 1u << 20)));
   if (nr) {
     p.text = m.text.as<uint8_t>();
-    const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((nr + 3u) / 4u, (uint32_t)n_cu * 32u));
+    const uint32_t blocks = (nr + 255u) / 256u;  // a wave per 64 records
     hipLaunchKernelGGL(sam_write_kernel, dim3(blocks), dim3(256), 0, stream, p);
     TAIL_TRY(hipGetLastError());
   }
   TAIL_TRY(hipEventRecord(m.ev[1], stream));
-  if (total) TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, (size_t)total, hipMemcpyDeviceToHost, stream));
   if (!m.ev_text) TAIL_TRY(hipEventCreateWithFlags(&m.ev_text, hipEventDisableTiming));
-  TAIL_TRY(hipEventRecord(m.ev_text, stream));
+  static const bool no_gate = getenv("FEM_TESTING") && getenv("FEM_TEXT_NO_GATE");  // (A/B)
+  {
+    std::unique_lock<std::mutex> turn;
+    if (gate && !no_gate) {
+      turn = std::unique_lock<std::mutex>(gate->mu);
+      if (gate->last && gate->last != m.ev_text) TAIL_TRY(hipEventSynchronize(gate->last));  // (this slot's own last text is home: its stream is in order)
+    }
+    // (by the copy engine.  The shader cores' stores into the pinned buffer — no engine to queue in — bring a text home in 7-9.5
+    //  ms where the engine takes 5.4, and FEM map from 130 to 117 Mreads/s.)
+    if (total) TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, (size_t)total, hipMemcpyDeviceToHost, stream));
+    TAIL_TRY(hipEventRecord(m.ev_text, stream));
+    if (gate) gate->last = m.ev_text;
+  }
   if (wait) TAIL_TRY(hipStreamSynchronize(stream));
   if (ms && wait) {
     float t = 0.f;

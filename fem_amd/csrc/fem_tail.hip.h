@@ -5,6 +5,7 @@
 // Input: the per-candidate verification outcome the mapping kernels left in HBM.  Output: records in the reference's
 // order (FLAG, reference id, POS, NM, BAM-encoded CIGAR, MD), compacted on the device, copied to pinned host memory.
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +66,16 @@ struct SamOutput {  // pinned host memory owned by the Tail object, valid until 
   uint64_t n_asserted;  // records on which the reference would have tripped an assertion (written with CIGAR *)
 };
 
+// One text on its way home at a time (per GPU).  Two device-to-host copies queued in the copy engines take both of them, and
+// the next batch's reads wait for their copy in until every queued text is home (scratch/sdma_probe.hip: a 30 MB copy in
+// behind ONE 300 MB copy out is done after 0.6 ms, behind four after all four, 22 ms); FEM map's device then alternated
+// between four batches' kernels and four batches' texts going home.  The thread that queues a text's copy waits here for
+// the previous text to have arrived.
+struct TextGate {
+  std::mutex mu;
+  hipEvent_t last = nullptr;  // the latest text's arrival (an event of some slot's Tail; never destroyed before the handle's tails are)
+};
+
 class Tail {
  public:
   Tail() = default;
@@ -79,11 +90,15 @@ class Tail {
   // Makes room for `bytes` of SAM text ahead of time (pinning host memory costs ~0.25 ms per MB: better spent before
   // the first batch than inside it).
   int reserve_text(uint64_t bytes, std::string *err);
+  // ... and for everything else run() and sam() allocate for a batch of n_reads reads with n_records records.
+  int reserve(uint32_t n_reads, uint32_t n_records, uint32_t max_len, int e, bool tiny, std::string *err);
+  // ... and loads the kernels (a code object is loaded by its first launch otherwise) and wakes `stream`.
+  int warm(hipStream_t stream, std::string *err);
   // The records of the last run() as SAM lines, in record order.  ms (optional) receives the device time.
   // wait = false: returns once the copy of the text to the host has been queued; wait_text() (which may be called from
   // another thread) returns when it has arrived.
   int sam(const TailInput &in, const SamInput &names, hipStream_t stream, int n_cu, SamOutput *out, std::string *err, double *ms,
-          bool wait = true);
+          bool wait = true, TextGate *gate = nullptr);
   int wait_text();
 
  private:

@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch", "fem_dev_fetch_packed",
     "fem_dev_fetch_records", "fem_dev_seed_kernel", "fem_dev_index_info",
-    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
+    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_reserve_batch", "fem_set_blocking_waits", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
     "fem_device_numa", "fem_bind_thread_near_device",
@@ -112,6 +112,7 @@ def load_hip():
     L.fem_dev_acquire_text_stage.argtypes = [vp, C.c_int, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
     L.fem_dev_reserve_text.argtypes = [vp, C.c_int, u64, u64, u64, u64]
+    L.fem_dev_reserve_batch.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, C.POINTER(Params)]
     L.fem_dev_fetch_sam.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_fetch_sam_nowait.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_sam_wait.argtypes = [vp, C.c_int]
@@ -395,6 +396,11 @@ class Device:
         buf = C.create_string_buffer(512)
         self._check(self._L.fem_dev_index_info(self._h, buf, 512))
         return buf.value.decode()
+
+    def reserve_batch(self, n_reads, n_records, max_len, e=3, a=1, k=12, step=3, slot=0):
+        """fem_dev_reserve_batch: the slot's allocations for batches of this shape, made now."""
+        p = Params(k, step, e, a)
+        self._check(self._L.fem_dev_reserve_batch(self._h, slot, n_reads, n_records, max_len, C.byref(p)))
 
     def fetch_records(self, slot=0):
         """The device mapping tail: sorted records with CIGAR and MD (fem_dev_fetch_records)."""

@@ -133,6 +133,12 @@ typedef struct {
 
 typedef struct fem_dev fem_dev;
 
+/* Process-wide, before fem_dev_open: handles opened afterwards make their threads SLEEP while they wait for the device
+ * (hipDeviceScheduleBlockingSync) instead of spinning.  For callers that keep several threads waiting on one handle while
+ * other threads need the cores (FEM map: a thread per batch in flight beside the FASTQ parser); a caller with one thread
+ * that waits rarely (bench.py's pipeline) is better off with the default. */
+int fem_set_blocking_waits(int on);
+
 /* ---- lifetime ---- */
 int fem_dev_open(int device, fem_dev **out);
 int fem_dev_close(fem_dev *h);
@@ -230,7 +236,8 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out);
  * upload_reference_names: the @SQ names (first token of every FASTA header), once, next to the reference.
  * acquire_text_stage / commit_text_stage: pinned staging for the batch's quality strings (same offsets as the bases)
  *   and read names (name i = names[name_off[i] .. name_off[i+1])), filled by the parser like the bases; commit after
- *   fem_dev_commit_stage* of the same batch, asynchronous.
+ *   fem_dev_commit_stage* of the same batch (before or after its fem_dev_map_staged: the copies run on a stream of
+ *   the slot's own, beside the batch's kernels, and only the SAM text waits for them), asynchronous.
  * fetch_sam: sync + mapping tail + text, all on the device; one D2H copy of the finished lines. */
 int fem_dev_upload_reference_names(fem_dev *h, uint32_t n_seq, const char *names, const uint64_t *name_off);
 int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, uint64_t n_name_bytes_cap,
@@ -239,6 +246,12 @@ int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n
 /* Optional: device and pinned buffers of the slot for batches of this shape and `text_bytes` of SAM text, allocated now
  * (pinning host memory costs ~0.25 ms per MB; otherwise the first batch of every slot pays for it). */
 int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes);
+/* Optional, after the index is resident: everything else a batch of up to n_reads reads of up to max_len characters with up
+ * to n_records mappings allocates in this slot on its way through fem_dev_map_staged and fem_dev_fetch_records /
+ * fem_dev_fetch_sam (per-read and per-candidate arrays, the selection's hand-over, the mapping tail's thirty arrays) —
+ * otherwise the first batch of every slot makes these allocations between its kernels (FEM map, 16 M reads: 20 of the job's
+ * 145 ms).  Larger batches still grow what they need. */
+int fem_dev_reserve_batch(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_records, uint32_t max_len, const fem_params *p);
 int fem_dev_fetch_sam(fem_dev *h, int slot, fem_batch_sam *out);
 /* The same, returning as soon as the copy of the text to the host is queued: out->text must not be read before
  * fem_dev_sam_wait(h, slot) has returned — the one call that may be made from another thread than the one driving

@@ -20,13 +20,14 @@ def _case(seed, e, L, n_reads, repeats, odd):
         seqs.append(util.rand_seq(rng, 120_000))
     else:
         seqs = [util.rand_seq(rng, 200_000), util.rand_seq(rng, 50_000)]
-    names = ["chr%d_%s" % (i, "x" * (i * 7)) for i in range(len(seqs))]
+    long_fields = L > 200  # names, reference names and MD strings beyond one and two bytes per lane of sam_write_kernel
+    names = ["chr%d_%s" % (i, "x" * (i * (70 if long_fields else 7))) for i in range(len(seqs))]
     reads = util.make_reads(rng, seqs, n_reads, L, e, n_rate=0.003)
     if odd:
         reads[3] = reads[3].lower()
         reads[5] = reads[5][:L // 2] + b"RYKM=.-*"[:min(8, L - L // 2)] + reads[5][L // 2 + 8:]
         reads[7] = reads[7][:L - 17]  # a different length
-    rnames = ["read_%d/%s" % (i, "n" * (i % 40)) for i in range(len(reads))]
+    rnames = ["read_%d/%s" % (i, "n" * (i % (150 if long_fields else 40))) for i in range(len(reads))]
     quals = ["".join(chr(33 + (11 * i + j) % 60) for j in range(len(r))) for i, r in enumerate(reads)]
     ref = fo.Reference(seqs)
     idx = fo.OracleIndex(ref)
@@ -38,13 +39,15 @@ def _case(seed, e, L, n_reads, repeats, odd):
 
 
 @pytest.mark.parametrize("seed,e,L,n,repeats,odd", [(1, 3, 100, 1500, False, True), (2, 7, 150, 800, True, True),
-                                                     (3, 2, 64, 3000, True, False), (4, 0, 36, 500, False, False)])
+                                                     (3, 2, 64, 3000, True, False), (4, 0, 36, 500, False, False),
+                                                     (5, 7, 260, 700, False, True)])
 def test_device_sam_text_equals_host_text_and_oracle_text(seed, e, L, n, repeats, odd):
     dev, ref, idx, seqs, names, reads, rnames, quals = _case(seed, e, L, n, repeats, odd)
     try:
         batch = fo.ReadBatch(reads)
         want = fo.map_reads(ref, idx, batch, e=e)
         q = np.frombuffer("".join(quals).encode(), np.uint8)
+        dev.reserve_batch(len(reads), 2 * len(reads), L, e=e, slot=2)  # (slot 2 with its allocations made ahead, slot 0 as they come)
         for slot in (0, 2):
             dev.stage_reads(batch.bases, batch.off, slot=slot)
             dev.stage_text(q, rnames, slot=slot)
