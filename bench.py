@@ -618,6 +618,7 @@ def e2e_cli(w, data, n_reads, threads, label="C2"):
             return {"error": "FEM index failed: " + r.stderr[-300:]}
         env = dict(os.environ, FEM_STAGE_TIMES="1")
         load = [None]
+        cores = [None]  # host cores busy on average during the mapping phase (user + system time / its wall time)
 
         def run_map(out_path):
             t0 = time.perf_counter()
@@ -630,11 +631,14 @@ def e2e_cli(w, data, n_reads, threads, label="C2"):
             st = re.search(r"stage busy seconds: (.*)", r.stderr)
             ld = re.search(r"resident on \d+ GPUs? in ([0-9.]+)s", r.stderr)
             load[0] = float(ld.group(1)) if ld else None
+            cpu = re.search(r"host CPU in the mapping phase: .* = ([0-9.]+) cores", r.stderr)
+            cores[0] = float(cpu.group(1)) if cpu else None
             return (float(m.group(1)) if m else None), wall, (st.group(1) if st else None)
 
         secs, wall, busy = run_map(sam)
         if secs is None:
             return {"error": busy}
+        file_cores = cores[0]
         sam_bytes = os.path.getsize(sam)
         os.unlink(sam)
         # what the output directory's file system takes from plain write() calls — one writer (what FEM map has, like the
@@ -665,14 +669,18 @@ def e2e_cli(w, data, n_reads, threads, label="C2"):
                           "buffered writes take the inode's lock), four into four files; as_mreads = one writer at this run's SAM bytes per read")
         # the same run with the SAM text discarded: what the host stages do when no file system is in the way
         null_secs, _, null_busy = run_map("/dev/null")
+        null_cores = cores[0]
+        null_again, _, _ = run_map("/dev/null")
         return {"value": round(n_reads / secs / 1e6, 3), "unit": "Mreads/s",
                 "what": "FEM map mapping phase (its own 'Time:' line, src/FEM_map.c:172,219): FASTQ parse -> device -> SAM text -> file, "
                         "%d reads of %s, -t %d, inputs in %s, SAM file in %s" % (n_reads, label, threads, base or "tmp", d_out),
                 "seconds": secs, "wall_seconds_incl_load": round(wall, 3), "sam_bytes": sam_bytes, "stage_busy": busy,
                 "fem_index_wall_seconds": round(t_ix, 2), "reference_and_index_resident_seconds": load[0],
                 "file_system_write_ceiling": fs_gbs,
+                "host_cores_busy": file_cores,
                 "to_dev_null": {"value": round(n_reads / null_secs / 1e6, 3) if null_secs else None, "seconds": null_secs,
-                                "stage_busy": null_busy}}
+                                "stage_busy": null_busy, "host_cores_busy": null_cores,
+                                "second_run": round(n_reads / null_again / 1e6, 3) if null_again else None}}
     finally:
         shutil.rmtree(d, ignore_errors=True)
         shutil.rmtree(d_out, ignore_errors=True)
@@ -692,9 +700,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads of the C2 workload timed on the host cores")
     ap.add_argument("--cpu-sample-c3", type=int, default=2_000_000, help="reads of the C3 workload timed on the host cores (0 = skip; "
                                                                          "the oracle's 3 Gbp index takes ~30 s to build)")
-    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FEM map run on C2 (0 = skip)")
-    ap.add_argument("--e2e-reads-c3", type=int, default=16_000_000, help="reads of the end-to-end FEM map run on the headline configuration "
-                                                                        "(3 GB FASTA + 8 GB index file + 4 GB FASTQ in /dev/shm; 0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=32_000_000, help="reads of the end-to-end FEM map run on C2 (0 = skip)")
+    ap.add_argument("--e2e-reads-c3", type=int, default=32_000_000, help="reads of the end-to-end FEM map run on the headline configuration "
+                                                                        "(3 GB FASTA + 8 GB index file + 7 GB FASTQ in /dev/shm; 0 = skip)")
     ap.add_argument("--profile-replay", type=int, default=0, help="profiling aid: only the resident replay of --workload (kernels on batches "
                                                                      "already in HBM, slots in rotation, no copies in flight), this many steps; "
                                                                      "prints the HIP-event means of exactly those launches")

@@ -76,6 +76,7 @@ struct Slot {
   size_t d_quals_cap = 0, d_names_cap = 0, d_name_off_cap = 0;
   bool text_staged = false;
   hipStream_t text_stream = nullptr;   // qualities and names go to the device beside the batch's kernels, not in front of them
+  hipStream_t out_stream = nullptr;    // the batch's way out (mapping tail, SAM text, its copy home): HIGH priority, see out_stream_of
   hipEvent_t ev_text_staged = nullptr; // ... and have arrived (the SAM text's kernels wait for it)
   hipEvent_t ev_text_order = nullptr;  // the slot's last SAM text has been rendered (its kernels read the same arrays)
   bool have_text_order = false;
@@ -1459,6 +1460,7 @@ int fem_dev_close(fem_dev *h) {
       if (p) (void)hipHostFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.text_stream) (void)hipStreamDestroy(s.text_stream);
+    if (s.out_stream) (void)hipStreamDestroy(s.out_stream);
     if (s.ev_text_staged) (void)hipEventDestroy(s.ev_text_staged);
     if (s.ev_text_order) (void)hipEventDestroy(s.ev_text_order);
     delete s.tail;
@@ -1646,6 +1648,7 @@ int fem_dev_acquire_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n
   Slot &s = h->slot[slot];
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(s.stream));  // the previous batch's copy out of these buffers is done
+  if (s.out_stream) HIP_TRY(h, hipStreamSynchronize(s.out_stream));  // ... and its records and text (they read the slot's device arrays)
   drain_timing(h, s);
   if ((rc = pinned_realloc(h, &s.h_bases, &s.h_bases_cap, (size_t)n_bases_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_off, &s.h_off_cap, (size_t)n_reads_cap + 1))) return rc;
@@ -2053,6 +2056,7 @@ int fem_dev_fetch_records(fem_dev *h, int slot, fem_batch_records *out) {
   femt::TailOutput t{};
   double ms[3] = {0, 0, 0};
   std::string err;
+  if (s.out_stream) HIP_TRY(h, hipStreamSynchronize(s.out_stream));  // (a SAM text of this slot still being made reads the tail's arrays)
   rc = s.tail->run(in, s.stream, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr);
   if (rc) return fail(h, rc, err);
   if (h->timing)
@@ -2094,6 +2098,7 @@ int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint6
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(s.stream));  // the previous batch's copies out of these buffers are done
   if (s.text_stream) HIP_TRY(h, hipStreamSynchronize(s.text_stream));
+  if (s.out_stream) HIP_TRY(h, hipStreamSynchronize(s.out_stream));
   if ((rc = pinned_realloc(h, &s.h_quals, &s.h_quals_cap, (size_t)n_bases_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_names, &s.h_names_cap, (size_t)n_name_bytes_cap + 64))) return rc;
   if ((rc = pinned_realloc(h, &s.h_name_off, &s.h_name_off_cap, (size_t)n_reads_cap + 1))) return rc;
@@ -2118,6 +2123,24 @@ int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_base
   std::string err;
   if ((rc = s.tail->reserve_text(text_bytes, &err))) return fail(h, rc, err);
   return FEM_OK;
+}
+
+// The stream a batch's records and text are made on.  The mapping has been waited for by then (fem_dev_sync), so nothing ties
+// this work to the slot's own stream — and on that stream, at the same priority as every other slot's, the small kernels of a
+// batch on its way OUT queue behind the joins of the batches coming IN (a join's persistent blocks fill the chip): with more
+// batches in flight each took longer, finished out of order and kept its slot (FEM map, 8 slots: a batch's records 56 ms after
+// its submission).  At high priority the oldest batch's kernels take the first resources that come free.
+static hipStream_t out_stream_of(fem_dev *h, Slot &s) {
+  static const bool plain = testing_switch("FEM_NO_OUT_PRIORITY");  // (A/B)
+  if (plain) return s.stream;
+  if (!s.out_stream) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&s.out_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+      s.out_stream = nullptr;
+  }
+  (void)h;
+  return s.out_stream ? s.out_stream : s.stream;
 }
 
 int fem_dev_reserve_batch(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_records, uint32_t max_len, const fem_params *p) {
@@ -2167,7 +2190,7 @@ int fem_dev_reserve_batch(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_rec
   HIP_TRY(h, hipMemcpyAsync(s.h_ctl, s.d_ctl, kCtlBytes, hipMemcpyDeviceToHost, s.stream));
   HIP_TRY(h, hipStreamSynchronize(s.text_stream));
   HIP_TRY(h, hipStreamSynchronize(s.stream));
-  if ((rc = s.tail->warm(s.stream, &err))) return fail(h, rc, err);
+  if ((rc = s.tail->warm(out_stream_of(h, s), &err))) return fail(h, rc, err);
   return FEM_OK;
 }
 
@@ -2236,18 +2259,19 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   femt::TailOutput t{};
   double ms[3] = {0, 0, 0}, ms_text = 0;
   std::string err;
-  rc = s.tail->run(in, s.stream, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr, false);
+  hipStream_t os = out_stream_of(h, s);
+  rc = s.tail->run(in, os, h->n_cu, h->tiny_buffers, &t, &err, h->timing ? ms : nullptr, false);
   if (rc) return fail(h, rc, err);
   const double ms_run = since(t_in);
   femt::SamInput names{};
   names.quals = s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
   names.ref_names = h->d_ref_names, names.ref_name_off = h->d_ref_name_off;
   femt::SamOutput text{};
-  HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev_text_staged, 0));  // qualities and names came on the slot's text stream
-  rc = s.tail->sam(in, names, s.stream, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait, &h->text_gate);
+  HIP_TRY(h, hipStreamWaitEvent(os, s.ev_text_staged, 0));  // qualities and names came on the slot's text stream
+  rc = s.tail->sam(in, names, os, h->n_cu, &text, &err, h->timing ? &ms_text : nullptr, wait, &h->text_gate);
   if (rc) return fail(h, rc, err);
   if (!s.ev_text_order) HIP_TRY(h, hipEventCreateWithFlags(&s.ev_text_order, hipEventDisableTiming));
-  HIP_TRY(h, hipEventRecord(s.ev_text_order, s.stream));
+  HIP_TRY(h, hipEventRecord(s.ev_text_order, os));
   s.have_text_order = true;
   if (trace_host) fprintf(stderr, "[fetch_sam] slot %d: mapping synced after %.2f ms, records %.2f, text sized and queued %.2f\n", slot, ms_sync, ms_run, since(t_in));
   if (h->timing) {
