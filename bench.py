@@ -268,10 +268,11 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         fence()
         host_s[0] = host_s[1] = 0.0
         t_start = time.perf_counter()
-        job_r, last_r = pipeline(steps, traced=os.environ.get("FEM_BENCH_TRACE") == "1" and rep == 0)
+        job_r, last_r = pipeline(steps, traced=(os.environ.get("FEM_BENCH_TRACE") == "1" and rep == 0) or os.environ.get("FEM_BENCH_TRACE") == "2")
         if trace:
             t_ret = [t - t_start for w_, _, t in trace if w_ == "retire"]
             log("%s trace: retire times (ms) %s" % (key, " ".join("%.2f" % (1e3 * t) for t in t_ret)))
+            log("%s trace: submit times (ms) %s" % (key, " ".join("%.2f" % (1e3 * (t - t_start)) for w_, _, t in trace if w_ == "submit")))
             log("%s trace: steady step %.3f ms (retires %d..%d)" % (key, 1e3 * (t_ret[-DEPTH - 1] - t_ret[DEPTH]) / max(1, len(t_ret) - 2 * DEPTH - 1), DEPTH, len(t_ret) - DEPTH - 1))
             trace.clear()
         if rk.dist:  # MappingStats reduction (src/FEM_map.c:200-212): the path's one exchange, 40 bytes over RCCL
@@ -283,6 +284,16 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         runs.append((elapsed, {name: dev.kernel_time(kid) for name, kid in KERNEL_IDS.items()}))
+        if reps > 1 and rk.rank == 0:  # (a repetition that falls out of line: was it the kernels or the host?)
+            kt_r = runs[-1][1]
+            try:  # (... or the job's CPU quota: periods in which the cgroup was stopped for having used it up)
+                thr = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+                log("%s rep %d: cgroup cpu.stat nr_throttled %s throttled_usec %s usage_usec %s" % (key, rep, thr.get("nr_throttled"), thr.get("throttled_usec"), thr.get("usage_usec")))
+            except Exception:
+                pass
+            log("%s rep %d: %.2f ms per step; host stage %.3f + fetch %.3f ms per step; kernels %s" % (
+                key, rep, 1e3 * elapsed / steps, host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps,
+                " ".join("%s %.3f" % (n_[5:9], t_[0] / max(1, t_[1])) for n_, t_ in kt_r.items() if t_[1])))
         if rep == 0:
             job, last_stats = job_r, last_r
             host_first = (host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps)

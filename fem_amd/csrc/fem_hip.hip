@@ -735,9 +735,7 @@ int grow_candidates(fem_dev *h, Slot &s, uint64_t want) {
 
 // The link is handed from one batch's copy to the next: call before and after a slot's H2D copies.
 int h2d_begin(fem_dev *h, Slot &s) {
-  // (nothing to wait for once the previous copy is through: a wait on an event of another slot's stream is not free in this
-  //  runtime even then)
-  if (h->have_h2d_done && hipEventQuery(h->ev_h2d_done) != hipSuccess) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_h2d_done, 0));
+  if (h->have_h2d_done) HIP_TRY(h, hipStreamWaitEvent(s.stream, h->ev_h2d_done, 0));
   return FEM_OK;
 }
 int h2d_end(fem_dev *h, Slot &s) {

@@ -112,7 +112,8 @@ def load_hip():
     L.fem_dev_acquire_text_stage.argtypes = [vp, C.c_int, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
     L.fem_dev_reserve_text.argtypes = [vp, C.c_int, u64, u64, u64, u64]
-    L.fem_dev_reserve_batch.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, C.POINTER(Params)]
+    if hasattr(L, "fem_dev_reserve_batch"):  # (FEM_HIP_LIBRARY may name an older build of the library: measurement only)
+        L.fem_dev_reserve_batch.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, C.POINTER(Params)]
     L.fem_dev_fetch_sam.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_fetch_sam_nowait.argtypes = [vp, C.c_int, C.POINTER(_BatchSam)]
     L.fem_dev_sam_wait.argtypes = [vp, C.c_int]
