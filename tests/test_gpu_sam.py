@@ -82,6 +82,21 @@ def test_fetch_sam_needs_its_inputs():
         q = np.frombuffer("".join(quals).encode(), np.uint8)
         with pytest.raises(FemError):
             dev.stage_text(q, rnames[:-1])  # one name short
+        # fem_dev_reserve_batch: shapes and parameters out of range are refused, and a handle without an index
+        for bad in (dict(n_reads=0, n_records=1, max_len=100), dict(n_reads=10, n_records=10, max_len=0),
+                    dict(n_reads=10, n_records=10, max_len=100_000), dict(n_reads=1 << 40, n_records=10, max_len=100)):
+            with pytest.raises(FemError):
+                dev.reserve_batch(slot=3, **bad)
+        with pytest.raises(FemError):
+            dev.reserve_batch(50, 50, 100, e=9, slot=3)  # parameters out of range
+        dev.reserve_batch(50, 100, 100, e=3, slot=3)
+        from fem_amd import Device
+        bare = Device(0)
+        try:
+            with pytest.raises(FemError):
+                bare.reserve_batch(50, 50, 100)
+        finally:
+            bare.close()
         empty = fo.ReadBatch([])
         dev.stage_reads(empty.bases, empty.off, slot=1)
         dev.stage_text(np.zeros(0, np.uint8), [], slot=1)
