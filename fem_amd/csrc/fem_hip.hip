@@ -75,6 +75,8 @@ struct Slot {
   uint64_t *d_name_off = nullptr;
   size_t d_quals_cap = 0, d_names_cap = 0, d_name_off_cap = 0;
   bool text_staged = false;
+  bool host_quals = false;             // the batch's qualities stayed on the host (fem_dev_commit_names_stage): the text leaves their field open
+  const uint64_t *qual_at = nullptr;   // ... and where each read's field starts in the slot's last text (pinned, the tail's)
   hipStream_t text_stream = nullptr;   // qualities and names go to the device beside the batch's kernels, not in front of them
   hipStream_t out_stream = nullptr;    // the batch's way out (mapping tail, SAM text, its copy home): HIGH priority, see out_stream_of
   hipEvent_t ev_text_staged = nullptr; // ... and have arrived (the SAM text's kernels wait for it)
@@ -2192,20 +2194,20 @@ int fem_dev_reserve_batch(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_rec
   return FEM_OK;
 }
 
-int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) {
+static int commit_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes, bool with_quals) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
   FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!s.staged) return fail(h, FEM_ERR_STATE, "commit the reads of the batch first");
-  if (!s.h_quals || !s.h_names || !s.h_name_off) return fail(h, FEM_ERR_STATE, "acquire the slot's text staging buffers first");
+  if ((with_quals && !s.h_quals) || !s.h_names || !s.h_name_off) return fail(h, FEM_ERR_STATE, "acquire the slot's text staging buffers first");
   if (n_reads != s.n_reads) return fail(h, FEM_ERR_INVALID, "as many names as reads, please");
-  if (s.n_bases + 64 > s.h_quals_cap || n_name_bytes + 64 > s.h_names_cap || n_reads + 1 > s.h_name_off_cap)
+  if ((with_quals && s.n_bases + 64 > s.h_quals_cap) || n_name_bytes + 64 > s.h_names_cap || n_reads + 1 > s.h_name_off_cap)
     return fail(h, FEM_ERR_INVALID, "more qualities or names than the text staging buffers were acquired for");
   if (n_reads && (s.h_name_off[0] != 0 || s.h_name_off[n_reads] != n_name_bytes))
     return fail(h, FEM_ERR_INVALID, "name offsets must start at 0 and end at the number of name bytes");
   HIP_TRY(h, hipSetDevice(h->device));
-  if ((rc = dev_realloc(h, &s.d_quals, &s.d_quals_cap, (size_t)s.n_bases + 64))) return rc;
+  if (with_quals && (rc = dev_realloc(h, &s.d_quals, &s.d_quals_cap, (size_t)s.n_bases + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_names, &s.d_names_cap, (size_t)n_name_bytes + 64))) return rc;
   if ((rc = dev_realloc(h, &s.d_name_off, &s.d_name_off_cap, (size_t)n_reads + 1))) return rc;
   // On a stream of their own: nothing before the SAM text reads them, and on the slot's stream these copies (1.25 times the
@@ -2214,11 +2216,28 @@ int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n
   if (!s.ev_text_staged) HIP_TRY(h, hipEventCreateWithFlags(&s.ev_text_staged, hipEventDisableTiming));
   // (the slot's previous batch may still be rendering its text out of the same arrays)
   if (s.have_text_order) HIP_TRY(h, hipStreamWaitEvent(s.text_stream, s.ev_text_order, 0));
-  if (s.n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, s.n_bases, hipMemcpyHostToDevice, s.text_stream));
+  if (with_quals && s.n_bases) HIP_TRY(h, hipMemcpyAsync(s.d_quals, s.h_quals, s.n_bases, hipMemcpyHostToDevice, s.text_stream));
   if (n_name_bytes) HIP_TRY(h, hipMemcpyAsync(s.d_names, s.h_names, n_name_bytes, hipMemcpyHostToDevice, s.text_stream));
   HIP_TRY(h, hipMemcpyAsync(s.d_name_off, s.h_name_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.text_stream));
   HIP_TRY(h, hipEventRecord(s.ev_text_staged, s.text_stream));
-  s.text_staged = true;
+  s.text_staged = true, s.host_quals = !with_quals, s.qual_at = nullptr;
+  return FEM_OK;
+}
+
+int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) { return commit_text(h, slot, n_reads, n_name_bytes, true); }
+// Names only: the qualities stay where the caller has them (228 of the 473 bytes per read that cross the link with the device's
+// SAM text are the qualities going up and coming back unchanged).  The text then leaves the QUAL field of every read's first
+// record unwritten, and fem_dev_sam_quals says where each read's field is.
+int fem_dev_commit_names_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes) { return commit_text(h, slot, n_reads, n_name_bytes, false); }
+
+int fem_dev_sam_quals(fem_dev *h, int slot, const uint64_t **qual_at, uint64_t *n_reads) {
+  int rc = check_slot(h, slot);
+  if (rc) return rc;
+  Slot &s = h->slot[slot];
+  if (!qual_at) return fail(h, FEM_ERR_INVALID, "null output pointer");
+  if (!s.host_quals || !s.qual_at) return fail(h, FEM_ERR_STATE, "the slot's last SAM text was rendered with its qualities (or there is none)");
+  *qual_at = s.qual_at;
+  if (n_reads) *n_reads = s.n_reads;
   return FEM_OK;
 }
 
@@ -2262,7 +2281,8 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
   if (rc) return fail(h, rc, err);
   const double ms_run = since(t_in);
   femt::SamInput names{};
-  names.quals = s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
+  names.quals = s.host_quals ? nullptr : s.d_quals, names.names = s.d_names, names.name_off = s.d_name_off;
+  names.qual_hole = s.host_quals;
   names.ref_names = h->d_ref_names, names.ref_name_off = h->d_ref_name_off;
   femt::SamOutput text{};
   HIP_TRY(h, hipStreamWaitEvent(os, s.ev_text_staged, 0));  // qualities and names came on the slot's text stream
@@ -2277,6 +2297,7 @@ static int fetch_sam(fem_dev *h, int slot, fem_batch_sam *out, bool wait) {
     for (int i = 0; i < 3; ++i) h->t_ms[3 + i] += ms[i], h->t_n[3 + i] += 1;
     if (wait) h->t_ms[7] += ms_text, h->t_n[7] += 1;  // (without the wait no elapsed time is read: nothing to count)
   }
+  s.qual_at = text.qual_at;
   out->text = text.text, out->len = text.len, out->n_asserted = text.n_asserted;
   out->n_reads = t.n_reads, out->n_records = t.n_records;
   memcpy(out->stats, s.stats, sizeof s.stats);

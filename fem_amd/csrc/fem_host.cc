@@ -1756,6 +1756,30 @@ void fem_records_free(fem_records *r) {
   memset(r, 0, sizeof *r);
 }
 
+int fem_sam_fill_quals(char *text, uint64_t text_len, const uint64_t *qual_at, uint64_t n_reads, const char *quals, const uint64_t *off,
+                       uint32_t read_len, int n_threads) {
+  if (!text || !qual_at || !quals) return -1;
+  static SleepingPool pool;  // (its own: the parser's pool is busy with the next batch meanwhile)
+  const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, n_threads), n_reads / 4096 + 1));
+  std::vector<int> bad((size_t)nt, 0);
+  pool.run(nt, [&](int t) {
+    const uint64_t lo = n_reads * (uint64_t)t / (uint64_t)nt, hi = n_reads * (uint64_t)(t + 1) / (uint64_t)nt;
+    for (uint64_t r = lo; r < hi; ++r) {
+      const uint64_t at = qual_at[r];
+      if (at == ~0ull) continue;
+      const uint64_t from = off ? off[r] : r * (uint64_t)read_len, len = off ? off[r + 1] - off[r] : (uint64_t)read_len;
+      if (at > text_len || len > text_len - at) {
+        bad[(size_t)t] = 1;
+        continue;
+      }
+      memcpy(text + at, quals + from, len);
+    }
+  });
+  for (int b : bad)
+    if (b) return -1;
+  return 0;
+}
+
 int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len) {
   if (!ref || !text || !text_len) return -1;
   std::string s;

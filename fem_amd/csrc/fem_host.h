@@ -170,6 +170,12 @@ int fem_records_sam_refs(const fem_tail_ref *ref, const fem_read_refs *reads, co
                          uint64_t *cap, fem_text_part *parts, uint64_t *n_asserted);
 /* "@SQ\tSN:%s\tLN:%d\n" per sequence (src/output_queue.c:104-108). *text is malloc'd. */
 int fem_sam_header(const fem_tail_ref *ref, char **text, uint64_t *text_len);
+/* The other half of fem_dev_commit_names_stage / fem_dev_sam_quals (include/fem_hip.h): copies read r's quality string
+ * (quals + off[r], off[r + 1] - off[r] characters; off == NULL: reads of one length, quals + r * read_len) to text + qual_at[r]
+ * for every read with qual_at[r] != UINT64_MAX, on up to n_threads threads (they sleep between calls).  Returns 0, or -1 on a
+ * null argument or a field that would end behind text_len. */
+int fem_sam_fill_quals(char *text, uint64_t text_len, const uint64_t *qual_at, uint64_t n_reads, const char *quals, const uint64_t *off,
+                       uint32_t read_len, int n_threads);
 
 /* ---------------- synthetic data ---------------- */
 /* iid uniform A/C/G/T; sequence i is a pure function of (seed, i). */

@@ -350,6 +350,10 @@ int map_main(int argc, char **argv) {
   // option, not the default.  FEM_HOST_TAIL=1: ordering, traceback and text by the host threads from the per-candidate outcome.
   const char *hf = getenv("FEM_HOST_FORMAT"), *spl = getenv("FEM_SPLICE");
   const bool device_text = !host_tail && !(hf && hf[0] == '1');
+  // ... with the qualities kept on the host (fem_dev_commit_names_stage: the device leaves their field open and the writer's
+  // threads fill it in): they are 228 of the 473 bytes per read on the link otherwise.  FEM_DEVICE_QUALS=1: up and down again.
+  const char *dq = getenv("FEM_DEVICE_QUALS");
+  const bool host_quals = device_text && !(dq && dq[0] == '1');
   const bool splice = !host_tail && !device_text && !(spl && spl[0] == '0');
   // With the text on the device the link is what bounds the run: batches of equal-length reads then cross it at two bits per
   // base — the parser writes that form straight into the pinned staging (fem_seqfile_fill_packed ->
@@ -503,9 +507,20 @@ int map_main(int argc, char **argv) {
         if (wrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] SAM text failed: %s\n", fem_strerror(wrc));
         double t0 = real_time();
         it.b->t_text = t0;
+        if (!wrc && host_quals && it.b->sam.len) {  // the qualities never left the host: into the fields the device left open
+          const uint64_t *qual_at = nullptr;
+          uint64_t n_q = 0;
+          int qrc = fem_dev_sam_quals(devs[(size_t)it.b->gpu], it.b->slot, &qual_at, &n_q);
+          if (!qrc)
+            qrc = fem_sam_fill_quals(const_cast<char *>(it.b->sam.text), it.b->sam.len, qual_at, n_q, it.b->q_stage, it.b->packed ? nullptr : it.b->off,
+                                     it.b->shape.max_len, std::max(1, n_threads / 2));
+          if (qrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] qualities could not be placed in the SAM text (%d)\n", qrc);
+          busy_text += real_time() - t0;
+        }
+        const double t_w = real_time();
         bool ok = wrc != 0 || it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
         if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
-        busy_write += real_time() - t0;
+        busy_write += real_time() - t_w;
         fprintf(stderr, "Mapped read batch in %fs.\n", real_time() - it.b->t_submit);
         if (batch_times)
           fprintf(stderr, "[FEM] batch %lu gpu %d slot %d (ms): slot %.2f filled %.2f submit %.2f..%.2f retired %.2f text home %.2f written %.2f\n",
@@ -691,7 +706,9 @@ int map_main(int argc, char **argv) {
         const double t_c2 = real_time();
         // (qualities and names behind the mapping's launches: the call that hands the link 140 MB can wait for room in the copy
         //  engine's queue, 8-10 ms now and then, and the kernels need none of it)
-        if (!rc && device_text) rc = fem_dev_commit_text_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes);
+        if (!rc && device_text)
+          rc = host_quals ? fem_dev_commit_names_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes)
+                          : fem_dev_commit_text_stage(h, b->slot, b->shape.n_reads, b->shape.n_name_bytes);
         if (batch_times && real_time() - b->t_submit > 1e-3)
           fprintf(stderr, "[FEM] slow submit (ms): reads committed %.2f, mapping queued %.2f, text committed %.2f\n", 1e3 * (t_c1 - b->t_submit),
                   1e3 * (t_c2 - t_c1), 1e3 * (real_time() - t_c2));

@@ -1149,6 +1149,8 @@ struct SamParams {
   const unsigned long long *line_off;  // exclusive scan of line_len
   uint8_t *text;
   uint32_t *asserted;
+  unsigned long long *qual_at;  // qual_hole: n_reads entries, set for the reads that have a record
+  uint32_t qual_hole;           // the QUAL field of a primary record is sized but not written (quals == nullptr)
 };
 
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
@@ -1183,7 +1185,7 @@ __global__ void __launch_bounds__(256) sam_len_kernel(SamParams p) {
     for (uint32_t c = c0; c < c1; ++c) cig += dec_digits(p.cigar[c] >> 4) + 1u;
     if (c1 == c0) cig = 1;  // '*'
     const uint32_t md_len = p.md_off[j + 1] - p.md_off[j];
-    const uint32_t seq_qual = primary && L > 0 ? L + 1u + (p.quals ? L : 1u) : 3u;
+    const uint32_t seq_qual = primary && L > 0 ? L + 1u + (p.quals || p.qual_hole ? L : 1u) : 3u;
     p.line_len[j] = (unsigned long long)name_len + 1u + dec_digits(flag & 0x7FFFu) + 1u + rname_len + 1u + dec_digits(p.pos0[j] + 1u) + 5u + cig +
                     7u + seq_qual + 6u + dec_digits(p.nm[j]) + 6u + md_len + 1u;
   }
@@ -1238,7 +1240,7 @@ __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
   const uint32_t o_pos = o_rname + rname_len + 1u;
   const uint32_t o_cig = o_pos + dec_digits(pos1) + 5u;
   const uint32_t o_seq = o_cig + cig + 7u;
-  const uint32_t o_nm = o_seq + (seq ? L + 1u + (p.quals ? L : 1u) : 3u) + 6u;
+  const uint32_t o_nm = o_seq + (seq ? L + 1u + (p.quals || p.qual_hole ? L : 1u) : 3u) + 6u;
   const uint32_t o_md = o_nm + dec_digits(nm) + 6u;
   if (mine) {  // the short fields of the lane's own record
     uint8_t *w = p.text + at;
@@ -1264,7 +1266,8 @@ __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
     uint8_t *w_seq = w + o_seq;
     if (seq) {
       w_seq[L] = '\t';
-      if (!p.quals) w_seq[L + 1u] = '*';
+      if (p.qual_hole) p.qual_at[r] = at + o_seq + L + 1u;  // (the caller has the qualities: it writes them here)
+      else if (!p.quals) w_seq[L + 1u] = '*';
     } else {
       w_seq[0] = '*', w_seq[1] = '\t', w_seq[2] = '*';
     }
@@ -1351,17 +1354,17 @@ __global__ void __launch_bounds__(256) sam_write_kernel(SamParams p) {
 struct Tail::Impl {
   DevBuf rec_begin, queue, ctl, u_cand, u_misc, s_cand, s_misc, s_read, t_ops, t_md, o_ops, o_md, ovf, rec_list, src_slot, n_ops, n_md,
       flag, tid, pos0, nm, cigar_off, md_off, cigar, md, scan_tmp;
-  DevBuf line_len, line_off, text;
-  PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md, h_text;
+  DevBuf line_len, line_off, text, qual_at;
+  PinBuf h_ctl, h_rec_begin, h_flag, h_tid, h_pos0, h_nm, h_cigar_off, h_md_off, h_cigar, h_md, h_text, h_qual_at;
   uint32_t last_n = 0, last_nr = 0;  // what the last run() left on the device
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_text = nullptr;  // the SAM text has arrived in h_text
   ~Impl() {
     if (ev_text) (void)hipEventDestroy(ev_text);
     for (DevBuf *b : {&rec_begin, &queue, &ctl, &u_cand, &u_misc, &s_cand, &s_misc, &s_read, &t_ops, &t_md, &o_ops, &o_md, &ovf, &rec_list,
-                      &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp, &line_len, &line_off, &text})
+                      &src_slot, &n_ops, &n_md, &flag, &tid, &pos0, &nm, &cigar_off, &md_off, &cigar, &md, &scan_tmp, &line_len, &line_off, &text, &qual_at})
       b->release();
-    for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md, &h_text})
+    for (PinBuf *b : {&h_ctl, &h_rec_begin, &h_flag, &h_tid, &h_pos0, &h_nm, &h_cigar_off, &h_md_off, &h_cigar, &h_md, &h_text, &h_qual_at})
       b->release();
     for (hipEvent_t e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -1416,6 +1419,8 @@ int Tail::reserve(uint32_t n, uint32_t nr, uint32_t max_len_in, int e, bool tiny
   TAIL_TRY(m.md.need(std::max<size_t>((size_t)nr * md_cap, 1)));
   TAIL_TRY(m.line_len.need(r1 * 8));
   TAIL_TRY(m.line_off.need(r1 * 8));
+  TAIL_TRY(m.qual_at.need(((size_t)n + 1) * 8));
+  TAIL_TRY(m.h_qual_at.need(((size_t)n + 1) * 8));
   size_t tmp_a = 0, tmp_b = 0, tmp_c = 0;
   TAIL_TRY(rocprim::exclusive_scan(nullptr, tmp_a, (const uint32_t *)nullptr, m.rec_begin.as<uint32_t>(), 0u, (size_t)n,
                                    rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
@@ -1706,6 +1711,14 @@ int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, in
   p.cigar_off = m.cigar_off.as<uint32_t>(), p.cigar = m.cigar.as<uint32_t>(), p.md_off = m.md_off.as<uint32_t>(), p.md = m.md.as<uint8_t>();
   p.bases = in.bases, p.read_off = in.read_off;
   p.quals = names.quals, p.names = names.names, p.name_off = names.name_off, p.ref_names = names.ref_names, p.ref_name_off = names.ref_name_off;
+  const bool hole = names.qual_hole && !names.quals;
+  const size_t n_reads1 = (size_t)m.last_n + 1;
+  if (hole) {  // where each read's QUAL field starts (all ones: the read has no record)
+    TAIL_TRY(m.qual_at.need(n_reads1 * 8));
+    TAIL_TRY(m.h_qual_at.need(n_reads1 * 8));
+    TAIL_TRY(hipMemsetAsync(m.qual_at.p, 0xFF, n_reads1 * 8, stream));
+    p.qual_at = m.qual_at.as<unsigned long long>(), p.qual_hole = 1u;
+  }
   p.line_len = m.line_len.as<unsigned long long>(), p.line_off = m.line_off.as<unsigned long long>();
   p.asserted = m.ctl.as<uint32_t>() + 2;  // (ctl[2] is zero after a successful run())
   unsigned long long *h_total = (unsigned long long *)(m.h_ctl.as<uint32_t>() + 6);
@@ -1738,6 +1751,7 @@ int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, in
     // (by the copy engine.  The shader cores' stores into the pinned buffer — no engine to queue in — bring a text home in 7-9.5
     //  ms where the engine takes 5.4, and FEM map from 130 to 117 Mreads/s.)
     if (total) TAIL_TRY(hipMemcpyAsync(m.h_text.p, m.text.p, (size_t)total, hipMemcpyDeviceToHost, stream));
+    if (hole) TAIL_TRY(hipMemcpyAsync(m.h_qual_at.p, m.qual_at.p, n_reads1 * 8, hipMemcpyDeviceToHost, stream));
     TAIL_TRY(hipEventRecord(m.ev_text, stream));
     if (gate) gate->last = m.ev_text;
   }
@@ -1747,6 +1761,7 @@ int Tail::sam(const TailInput &in, const SamInput &names, hipStream_t stream, in
     if (hipEventElapsedTime(&t, m.ev[0], m.ev[1]) == hipSuccess) *ms += t;
   }
   out->text = m.h_text.as<char>(), out->len = total, out->n_asserted = m.h_ctl.as<uint32_t>()[2];
+  out->qual_at = hole ? m.h_qual_at.as<uint64_t>() : nullptr;
   return FEM_OK;
 }
 

@@ -59,11 +59,13 @@ struct SamInput {  // device pointers
   const uint64_t *name_off;      // n_reads + 1
   const uint8_t *ref_names;      // reference sequence names, concatenated
   const uint32_t *ref_name_off;  // n_seq + 1
+  bool qual_hole;                // quals == nullptr and the QUAL field of a primary record is LEFT UNWRITTEN (the caller fills it: SamOutput::qual_at)
 };
 struct SamOutput {  // pinned host memory owned by the Tail object, valid until its next sam()
   const char *text;
   uint64_t len;
   uint64_t n_asserted;  // records on which the reference would have tripped an assertion (written with CIGAR *)
+  const uint64_t *qual_at;  // qual_hole: per READ, where in `text` its QUAL field starts (~0: the read has no record); else nullptr
 };
 
 // One text on its way home at a time (per GPU).  Two device-to-host copies queued in the copy engines take both of them, and

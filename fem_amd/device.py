@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "fem_dev_map_batch_submit", "fem_dev_map_batch_wait",
     "fem_dev_stage_reads", "fem_dev_stage_info", "fem_dev_acquire_stage", "fem_dev_commit_stage", "fem_dev_commit_stage_uniform", "fem_dev_packed_layout", "fem_dev_commit_stage_packed", "fem_dev_map_staged", "fem_dev_sync", "fem_dev_fetch_stats", "fem_dev_fetch", "fem_dev_fetch_packed",
     "fem_dev_fetch_records", "fem_dev_seed_kernel", "fem_dev_index_info",
-    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_reserve_text", "fem_dev_reserve_batch", "fem_set_blocking_waits", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
+    "fem_dev_upload_reference_names", "fem_dev_acquire_text_stage", "fem_dev_commit_text_stage", "fem_dev_commit_names_stage", "fem_dev_sam_quals", "fem_dev_reserve_text", "fem_dev_reserve_batch", "fem_set_blocking_waits", "fem_dev_fetch_sam", "fem_dev_fetch_sam_nowait", "fem_dev_sam_wait",
     "fem_dev_set_timing", "fem_dev_reset_timing", "fem_dev_kernel_time", "fem_dev_copy_bandwidth",
     "fem_dev_h2d_bandwidth",
     "fem_device_numa", "fem_bind_thread_near_device",
@@ -111,6 +111,9 @@ def load_hip():
     L.fem_dev_upload_reference_names.argtypes = [vp, C.c_uint32, C.c_char_p, vp]
     L.fem_dev_acquire_text_stage.argtypes = [vp, C.c_int, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.fem_dev_commit_text_stage.argtypes = [vp, C.c_int, u64, u64]
+    if hasattr(L, "fem_dev_commit_names_stage"):
+        L.fem_dev_commit_names_stage.argtypes = [vp, C.c_int, u64, u64]
+        L.fem_dev_sam_quals.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(u64)]
     L.fem_dev_reserve_text.argtypes = [vp, C.c_int, u64, u64, u64, u64]
     if hasattr(L, "fem_dev_reserve_batch"):  # (FEM_HIP_LIBRARY may name an older build of the library: measurement only)
         L.fem_dev_reserve_batch.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, C.POINTER(Params)]
@@ -416,8 +419,10 @@ class Device:
         off[1:] = np.cumsum([len(n) for n in raw])
         self._check(self._L.fem_dev_upload_reference_names(self._h, len(raw), b"".join(raw), off.ctypes.data))
 
-    def stage_text(self, quals, names, slot=0):
-        """Qualities (uint8 array / bytes, same offsets as the staged bases) and read names (list) of the slot's batch."""
+    def stage_text(self, quals, names, slot=0, quals_on_host=False):
+        """Qualities (uint8 array / bytes, same offsets as the staged bases) and read names (list) of the slot's batch.
+        quals_on_host: fem_dev_commit_names_stage — only the names go to the device, fetch_sam(quals=, offsets=) puts the
+        qualities into the text."""
         raw = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
         q = np.frombuffer(bytes(quals), np.uint8) if not isinstance(quals, np.ndarray) else quals
         nn = sum(len(n) for n in raw)
@@ -430,9 +435,12 @@ class Device:
         off = np.zeros(len(raw) + 1, np.uint64)
         off[1:] = np.cumsum([len(n) for n in raw])
         C.memmove(po.value, off.ctypes.data, 8 * (len(raw) + 1))
-        self._check(self._L.fem_dev_commit_text_stage(self._h, slot, len(raw), nn))
+        if quals_on_host:
+            self._check(self._L.fem_dev_commit_names_stage(self._h, slot, len(raw), nn))
+        else:
+            self._check(self._L.fem_dev_commit_text_stage(self._h, slot, len(raw), nn))
 
-    def fetch_sam(self, slot=0, nowait=False):
+    def fetch_sam(self, slot=0, nowait=False, quals=None, offsets=None):
         """(SAM text of the slot's batch as bytes, n_records, n_asserted, stats) — rendered on the device.
         nowait: through fem_dev_fetch_sam_nowait + fem_dev_sam_wait."""
         r = _BatchSam()
@@ -441,6 +449,15 @@ class Device:
             self._check(self._L.fem_dev_sam_wait(self._h, slot))
         else:
             self._check(self._L.fem_dev_fetch_sam(self._h, slot, C.byref(r)))
+        if quals is not None and r.len:  # the batch went without its qualities: into the fields the device left open
+            from fem_amd import host
+            qa, nq = C.c_void_p(), C.c_uint64()
+            self._check(self._L.fem_dev_sam_quals(self._h, slot, C.byref(qa), C.byref(nq)))
+            q = np.ascontiguousarray(quals, dtype=np.uint8)
+            o = np.ascontiguousarray(offsets, dtype=np.uint64)
+            rc = host.lib().fem_sam_fill_quals(r.text, r.len, qa.value, nq.value, q.ctypes.data, o.ctypes.data, 0, 3)
+            if rc:
+                raise FemError("fem_sam_fill_quals failed (%d)" % rc)
         text = C.string_at(r.text, r.len) if r.len else b""
         return text, int(r.n_records), int(r.n_asserted), np.array(list(r.stats), dtype=np.uint64)
 

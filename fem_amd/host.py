@@ -80,6 +80,7 @@ def lib():
         L.fem_tail_sam.argtypes = [i32, C.POINTER(TailRef), C.POINTER(SeqSet), C.POINTER(TailInput), C.c_int,
                                    C.POINTER(vp), C.POINTER(u64)]
         L.fem_sam_header.argtypes = [C.POINTER(TailRef), C.POINTER(vp), C.POINTER(u64)]
+        L.fem_sam_fill_quals.argtypes = [vp, u64, vp, u64, vp, vp, C.c_uint32, C.c_int]
         L.fem_synth_reference.argtypes = [u64, C.c_uint32, vp, vp, vp, C.c_int]
         L.fem_synth_reads.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, C.c_int]
         L.fem_synth_reads_ex.argtypes = [u64, vp, vp, vp, C.c_uint32, u64, u64, C.c_uint32, i32, vp, vp, C.c_int]

@@ -243,6 +243,15 @@ int fem_dev_upload_reference_names(fem_dev *h, uint32_t n_seq, const char *names
 int fem_dev_acquire_text_stage(fem_dev *h, int slot, uint64_t n_reads_cap, uint64_t n_bases_cap, uint64_t n_name_bytes_cap,
                                char **quals, char **names, uint64_t **name_off);
 int fem_dev_commit_text_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes);
+/* The same without the qualities (the staging's `quals` need not be filled): they stay with the caller.  With the text from
+ * the device 228 of the 473 bytes per 100-bp read on the link are the qualities going to the device and coming back unchanged;
+ * this form sends none up and the SAM text comes back with the QUAL field of every read's first record sized but NOT WRITTEN.
+ * fem_dev_sam_quals (once the text is home: after fem_dev_fetch_sam / fem_dev_sam_wait) gives qual_at[n_reads]: where in the
+ * text read r's field starts, UINT64_MAX for a read without a record; the caller copies each read's quality string there
+ * (libfemhost's fem_sam_fill_quals does it on several threads) before it uses the text.  Pinned memory of the slot, valid until
+ * the slot's next SAM text. */
+int fem_dev_commit_names_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_name_bytes);
+int fem_dev_sam_quals(fem_dev *h, int slot, const uint64_t **qual_at, uint64_t *n_reads);
 /* Optional: device and pinned buffers of the slot for batches of this shape and `text_bytes` of SAM text, allocated now
  * (pinning host memory costs ~0.25 ms per MB; otherwise the first batch of every slot pays for it). */
 int fem_dev_reserve_text(fem_dev *h, int slot, uint64_t n_reads, uint64_t n_bases, uint64_t n_name_bytes, uint64_t text_bytes);

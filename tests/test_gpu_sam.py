@@ -54,6 +54,12 @@ def test_device_sam_text_equals_host_text_and_oracle_text(seed, e, L, n, repeats
             dev.map_staged(e=e, slot=slot)
             text, n_records, n_asserted, stats = dev.fetch_sam(slot=slot, nowait=slot == 2)
             assert np.array_equal(stats, want.stats) and n_records == int(want.rec_off[-1])
+            # the same batch with its qualities kept on the host (fem_dev_commit_names_stage): the device leaves the QUAL field of
+            # every read's first record open, fem_dev_sam_quals says where, fem_sam_fill_quals fills it in — the same bytes
+            dev.stage_text(q, rnames, slot=slot, quals_on_host=True)
+            text_h, n_records_h, _, _ = dev.fetch_sam(slot=slot, nowait=slot == 2, quals=q, offsets=batch.off)
+            assert text_h == text and n_records_h == n_records
+            dev.stage_text(q, rnames, slot=slot)  # (and with them on the device again, for the records below)
             # the host formatter on the records the device tail hands out
             rec = dev.fetch_records(slot=slot)
             tref = host.TailReference(ref.text, ref.off, ref.len, names=names)

@@ -530,3 +530,43 @@ def test_reads_taken_by_reference_from_the_files_mapping(tmp_path):
         f.write(fq.read_bytes())
     got = host.read_refs_batches(str(gzp), 1 << 18, threads=3)
     assert all(rc == 2 for rc, _ in got) and [r[:3] for _, rs in got for r in rs] == want
+
+
+def test_qualities_filled_into_the_text_the_device_left_open():
+    """fem_sam_fill_quals (fem_host.cc): the host half of fem_dev_commit_names_stage — read r's quality string goes to
+    text + qual_at[r]; UINT64_MAX = the read has no record; a field that would end behind the text is refused."""
+    import ctypes as C
+    from fem_amd import host
+    rng = np.random.default_rng(5)
+    n = 20_000
+    lens = rng.integers(1, 120, n).astype(np.uint64)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    quals = rng.integers(33, 100, int(off[-1])).astype(np.uint8)
+    text = np.full(int(off[-1]) * 2 + 64, ord("."), np.uint8)
+    qual_at = np.full(n, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    at = 7
+    want = text.copy()
+    for r in range(n):
+        if r % 5 == 3:
+            continue  # (no record)
+        qual_at[r] = at
+        want[at:at + int(lens[r])] = quals[int(off[r]):int(off[r + 1])]
+        at += int(lens[r]) + int(rng.integers(0, 3))
+    L = host.lib()
+    for threads in (1, 5):
+        got = text.copy()
+        assert L.fem_sam_fill_quals(got.ctypes.data, len(got), qual_at.ctypes.data, n, quals.ctypes.data, off.ctypes.data, 0, threads) == 0
+        assert np.array_equal(got, want)
+    # reads of one length, no offset table
+    n2, L2 = 5000, 36
+    q2 = rng.integers(33, 100, n2 * L2).astype(np.uint8)
+    at2 = (np.arange(n2, dtype=np.uint64) * np.uint64(L2 + 3)) + np.uint64(2)
+    t2 = np.zeros(n2 * (L2 + 3) + 8, np.uint8)
+    assert L.fem_sam_fill_quals(t2.ctypes.data, len(t2), at2.ctypes.data, n2, q2.ctypes.data, None, L2, 4) == 0
+    for r in (0, 1, n2 - 1):
+        assert np.array_equal(t2[int(at2[r]):int(at2[r]) + L2], q2[r * L2:(r + 1) * L2])
+    bad = at2.copy()
+    bad[n2 - 1] = len(t2) - 5  # the field would end behind the text
+    assert L.fem_sam_fill_quals(t2.ctypes.data, len(t2), bad.ctypes.data, n2, q2.ctypes.data, None, L2, 4) == -1
+    assert L.fem_sam_fill_quals(None, 0, bad.ctypes.data, n2, q2.ctypes.data, None, L2, 4) == -1
