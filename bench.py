@@ -19,8 +19,8 @@ five counters, and — at N = 1, where the oracle's index exists — one slot's 
 a 100 k-read prefix, fetched out of the running four-deep pipeline, equal the oracle's.
 `value`, `ms_per_step` and `roofline` all come from the SAME workload, the headline one: C3 (100 bp, e=3, 3 Gbp
 reference: the HBM-resident configuration SURVEY.md 8d calls bandwidth-relevant; 20 steps x 2.5 M = BASELINE's 50 M
-reads).  `value` is the first timed run of exactly K steps; `spread` has min / median / max over that run and
-`--reps - 1` further ones.  C2 (5 Mbp: the index is cache-resident, the pipeline host- and link-balanced) and C5 (150 bp,
+reads).  `value` is the MEDIAN of `--reps` (3) timed runs of exactly K steps each, `ms_per_step` and the kernel times are
+that run's; `spread` has all of them (`value_is_repetition`: which one).  C2 (5 Mbp: the index is cache-resident, the pipeline host- and link-balanced) and C5 (150 bp,
 e=7) are measured next to it at N = 1 (`pipeline_by_workload`, `roofline_by_workload`).
 
 `roofline` is the dominant kernel of the headline workload — seed_join_kernel — with ITS algorithmic bytes (8 P: the
@@ -70,7 +70,13 @@ N_SLOTS = 4  # batch slots of the library
 # the join of the previous — so three in flight left the host one batch short now and then: 225-250 against 248-258 Mreads/s)
 DEPTH = int(os.environ.get("FEM_BENCH_DEPTH", "4"))
 CHECK_READS = 100_000  # prefix of one slot's batch whose full pipeline result is compared with the oracle's (N = 1)
-PRIME_TO = 12          # untimed batches a workload has seen before its timed steps (warm-up included), at least
+PRIME_TO = 12          # untimed batches a workload has seen before its timed steps (warm-up included), at least ...
+# ... and the PROCESS this many before its first timed step: the HIP runtime stalls single calls and waits for 20-50 ms while it
+# grows its pools over a process's first ~80 batches (round 5's last day: with 12, one or two of the first workload's three
+# timed runs carried such a stall — rep by rep 7.73 7.76 8.36 7.72 7.71 / 7.66 7.72 9.74 7.73 7.65 ms per step —, with 100 none:
+# 7.71 7.63 7.66 7.67 7.68 / 7.72 7.64 7.64 7.64 7.66; the later workloads of the same process never showed one)
+PRIME_PROCESS_TO = int(os.environ.get("FEM_BENCH_PRIME", "100"))
+_batches_seen = [0]    # by this process, any workload
 
 WORKLOADS = {
     "c2": dict(seed=2, seq_lens=[5_000_000], L=100, e=3,
@@ -233,6 +239,7 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     trace = []  # FEM_BENCH_TRACE=1: (what, step, seconds) of every submit / retire of the timed region (fill and drain made visible)
 
     def pipeline(n, traced=False):
+        _batches_seen[0] += n
         tot = np.zeros(5, dtype=np.uint64)
         last = None
         for i in range(n):
@@ -255,14 +262,14 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
     # The HIP runtime grows its command / signal pools over the first ~10 batches of a process's life (two enqueue calls
     # of ~8 ms each around the 8th-10th batch, measured): with fewer warm-up steps than that asked for, the difference
     # is run first, untimed and reported as config.priming_steps — it is setup, like the buffer allocations.
-    priming = max(0, PRIME_TO - max(warmup, 1))
+    priming = max(0, max(PRIME_TO, PRIME_PROCESS_TO - _batches_seen[0]) - max(warmup, 1))
     if priming:
         pipeline(priming)
     pipeline(max(warmup, 1))
     h2d_bytes, sent_packed = dev.stage_info(0)
     runs = []  # (elapsed seconds, kernel times) of every timed repetition of exactly `steps` steps; the first is `value`
     job = last_stats = None
-    host_first = None
+    host_reps = []
     for rep in range(max(1, reps)):
         dev.reset_timing()
         fence()
@@ -294,12 +301,18 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
             log("%s rep %d: %.2f ms per step; host stage %.3f + fetch %.3f ms per step; kernels %s" % (
                 key, rep, 1e3 * elapsed / steps, host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps,
                 " ".join("%s %.3f" % (n_[5:9], t_[0] / max(1, t_[1])) for n_, t_ in kt_r.items() if t_[1])))
+        host_reps.append((host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps))
         if rep == 0:
             job, last_stats = job_r, last_r
-            host_first = (host_s[0] * 1e3 / steps, host_s[1] * 1e3 / steps)
             d2h_timed = d2h_bytes[0]  # (of the timed steps' form; the comparison forms below fetch the plain arrays)
     dev.set_timing(False)
-    elapsed, kt = runs[0]
+    # `value` is the MEDIAN of the timed repetitions (each exactly `steps` steps between fences; all of them in spread.values).
+    # Until round 5's last day it was the first one; since then the GPU boxes show one stall of 20-50 ms every half second or so
+    # (a host call or a wait that returns late: kernel times unchanged, no cgroup throttling, the previous day's library shows
+    # it too), and whichever repetition it lands in comes out 8-20 % low.
+    mid = sorted(range(len(runs)), key=lambda i_: runs[i_][0])[len(runs) // 2]
+    elapsed, kt = runs[mid]
+    host_first = host_reps[mid]
 
     # ---- the pipeline checks itself (untimed): the same four-deep pipeline once more round the slots, with a copy of slot
     #      0's full result taken out of it; every repeat of a slot's batch, timed steps included, must have given the same
@@ -458,11 +471,11 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         except Exception as ex:  # a malformed profile file must not break the measurement
             log("could not read %s: %s" % (tpath, ex))
     values = [rk.world * batch * steps / r[0] / 1e6 for r in runs]
-    value = values[0]
+    value = values[mid]
     return {
         "workload": w["name"], "value": round(value, 3), "ms_per_step": round(ms_step, 3), "steps": steps,
         "spread": {"reps": len(values), "min": round(min(values), 3), "median": round(sorted(values)[len(values) // 2], 3),
-                   "max": round(max(values), 3), "values": [round(v, 3) for v in values]},
+                   "max": round(max(values), 3), "values": [round(v, 3) for v in values], "value_is_repetition": mid},
         "reads_per_step_per_gpu": batch, "read_len": L, "e": e, "a": a, "k": k, "step": step,
         "kernel_only_mreads": round(kernel_only, 3), "seed_kernel": seed_name, "index_tables": dev.index_info(),
         "h2d_bytes_per_step": int(h2d_bytes), "h2d_packed": bool(sent_packed), "d2h_bytes_per_step": d2h_timed,
@@ -703,7 +716,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="the workload `value` is measured on")
-    ap.add_argument("--reps", type=int, default=3, help="timed runs of exactly --steps steps of the headline workload (value = the first; spread = all)")
+    ap.add_argument("--reps", type=int, default=3, help="timed runs of exactly --steps steps each (value = their median; spread = all)")
     ap.add_argument("--batch", type=int, default=2_500_000, help="reads per step and GPU")
     ap.add_argument("--extra", default="auto", help="comma list of further workloads measured on rank 0 when N = 1 "
                                                     "(auto = c5,c3r,c2 next to c3; none)")
@@ -853,7 +866,8 @@ def main():
                                                                          "roofline_by_kernel", "spread")},
                        value_is="device pipeline: the batch at two bits per base in the slot's pinned staging (as the FASTQ parser of FEM map "
                                 "writes it) -> fem_dev_commit_stage_packed (H2D, expansion) -> kernels -> D2H of fem_batch_result, %d batches "
-                                "in flight, a different batch per slot, fresh H2D and D2H every step; no host work per base" % DEPTH,
+                                "in flight, a different batch per slot, fresh H2D and D2H every step; no host work per base; the median of %d timed "
+                                "runs of exactly %d steps each (spread.values)" % (DEPTH, max(1, args.reps), args.steps),
                        parallelism="reads sharded x%d, index replicated" % rk.world, bandwidths=bw),
         "roofline": dict(head["roofline"], workload=args.workload),
         "roofline_step": dict(head["roofline_step"], workload=args.workload),

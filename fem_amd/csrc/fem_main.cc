@@ -350,10 +350,13 @@ int map_main(int argc, char **argv) {
   // option, not the default.  FEM_HOST_TAIL=1: ordering, traceback and text by the host threads from the per-candidate outcome.
   const char *hf = getenv("FEM_HOST_FORMAT"), *spl = getenv("FEM_SPLICE");
   const bool device_text = !host_tail && !(hf && hf[0] == '1');
-  // ... with the qualities kept on the host (fem_dev_commit_names_stage: the device leaves their field open and the writer's
-  // threads fill it in): they are 228 of the 473 bytes per read on the link otherwise.  FEM_DEVICE_QUALS=1: up and down again.
-  const char *dq = getenv("FEM_DEVICE_QUALS");
-  const bool host_quals = device_text && !(dq && dq[0] == '1');
+  // ... with the qualities kept on the host (fem_dev_commit_names_stage: the device leaves their field open and the batch's
+  // retiring thread fills it in): they are 228 of the 473 bytes per read on the link otherwise — and 0.027 core-µs per read on
+  // the host then, next to the parser's 0.078.  With 16 cores per GPU the two forms are within +7 / -16 % of each other from box
+  // to box (the run is bound by the link in one and by the cores in the other); from 24 threads on the qualities stay on the
+  // host.  FEM_HOST_QUALS=1 / FEM_DEVICE_QUALS=1 decide it by hand.
+  const char *dq = getenv("FEM_DEVICE_QUALS"), *hq = getenv("FEM_HOST_QUALS");
+  const bool host_quals = device_text && !(dq && dq[0] == '1') && ((hq && hq[0] == '1') || n_threads >= 24);
   const bool splice = !host_tail && !device_text && !(spl && spl[0] == '0');
   // With the text on the device the link is what bounds the run: batches of equal-length reads then cross it at two bits per
   // base — the parser writes that form straight into the pinned staging (fem_seqfile_fill_packed ->
@@ -477,6 +480,7 @@ int map_main(int argc, char **argv) {
   const bool stage_times = st_env && (st_env[0] == '1' || st_env[0] == '2');
   const bool batch_times = st_env && st_env[0] == '2';  // ... =2: and every batch's way through them
   double busy_read = 0, busy_text = 0, busy_write = 0;
+  std::mutex stat_mu;  // (busy_text: the batches' retiring threads add to it)
   double wait_slot = 0, wait_records = 0, wait_text_buf = 0;  // reader waiting for a free slot, formatter for records / a text buffer
   std::vector<double> busy_submit((size_t)n_gpus, 0.0), busy_recycle((size_t)n_gpus, 0.0);
   double t_first_slot = 0, t_first_filled = 0, t_reader_done = 0, t_workers_done = 0;
@@ -507,16 +511,6 @@ int map_main(int argc, char **argv) {
         if (wrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] SAM text failed: %s\n", fem_strerror(wrc));
         double t0 = real_time();
         it.b->t_text = t0;
-        if (!wrc && host_quals && it.b->sam.len) {  // the qualities never left the host: into the fields the device left open
-          const uint64_t *qual_at = nullptr;
-          uint64_t n_q = 0;
-          int qrc = fem_dev_sam_quals(devs[(size_t)it.b->gpu], it.b->slot, &qual_at, &n_q);
-          if (!qrc)
-            qrc = fem_sam_fill_quals(const_cast<char *>(it.b->sam.text), it.b->sam.len, qual_at, n_q, it.b->q_stage, it.b->packed ? nullptr : it.b->off,
-                                     it.b->shape.max_len, std::max(1, n_threads / 2));
-          if (qrc && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] qualities could not be placed in the SAM text (%d)\n", qrc);
-          busy_text += real_time() - t0;
-        }
         const double t_w = real_time();
         bool ok = wrc != 0 || it.b->sam.len == 0 || write_all(it.b->sam.text, it.b->sam.len);
         if (!ok && !exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] write error on %s\n", out_path);
@@ -650,8 +644,32 @@ int map_main(int argc, char **argv) {
                                : fem_dev_fetch_records(h, b->slot, &b->rec);
         const double waited = real_time() - t0;
         b->t_retired = t0 + waited;
-        deliver(b->seq, [&, b, rc, waited] {
+        double placing = 0;
+        if (!rc && host_quals) {
+          // the qualities never left the host: once the text is home, into the fields the device left open — on this thread
+          // (a batch's own), so that the writer only writes
+          rc = fem_dev_sam_wait(h, b->slot);
+          if (!rc && b->sam.len) {
+            const double t1 = real_time();
+            const uint64_t *qual_at = nullptr;
+            uint64_t n_q = 0;
+            int qrc = fem_dev_sam_quals(h, b->slot, &qual_at, &n_q);
+            if (!qrc)
+              qrc = fem_sam_fill_quals(const_cast<char *>(b->sam.text), b->sam.len, qual_at, n_q, b->q_stage, b->packed ? nullptr : b->off, b->shape.max_len,
+                                       std::max(1, n_threads / 2));
+            if (qrc) {
+              if (!exit_code.exchange(EXIT_FAILURE)) fprintf(stderr, "[FEM] qualities could not be placed in the SAM text (%d)\n", qrc);
+              rc = FEM_ERR_STATE;
+            }
+            placing = real_time() - t1;
+          }
+        }
+        deliver(b->seq, [&, b, rc, waited, placing] {
           busy_wait[(size_t)g] += waited;
+          {
+            std::lock_guard<std::mutex> l(stat_mu);
+            busy_text += placing;
+          }
           if (rc) {
             if (!exit_code.exchange(EXIT_FAILURE)) dev_fail(h, "mapping", rc);
             work_q[(size_t)g].push(Msg{kRecycle, b});
@@ -667,7 +685,7 @@ int map_main(int argc, char **argv) {
           }
         });
       };
-      int n_retire = std::max(1, n_slots - 1);
+      int n_retire = std::max(1, n_slots);  // (one per slot: a batch's thread also waits for its text and places the qualities)
       if (const char *fl = getenv("FEM_FLIGHT")) n_retire = std::max(1, std::min(n_slots, atoi(fl)));
       std::vector<std::thread> retirers;
       for (int r = 0; r < n_retire; ++r)

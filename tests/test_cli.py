@@ -89,7 +89,9 @@ def test_index_and_map_end_to_end(tmp_path, e, L, gz, batch):
     assert open(host_sam).read() == text
     # ... with the records from the device and the text spliced by the host threads between the fields of the input file's
     # mapping (the default renders the text on the device), and with those fields copied by the parser instead of read in place
-    for env in ({"FEM_HOST_FORMAT": "1"}, {"FEM_HOST_FORMAT": "1", "FEM_SPLICE": "0"}, {"FEM_PACK_BASES": "0"}):
+    # ... and with the device's text but the qualities kept on the host (the default from 24 threads on), packed and as characters
+    for env in ({"FEM_HOST_FORMAT": "1"}, {"FEM_HOST_FORMAT": "1", "FEM_SPLICE": "0"}, {"FEM_PACK_BASES": "0"}, {"FEM_HOST_QUALS": "1"},
+                {"FEM_HOST_QUALS": "1", "FEM_PACK_BASES": "0"}):
         r3 = run("map", "-e", str(e), "-t", "3", "--ref", fa, "--index", index_path, "--read1", fq, "-o", host_sam,
                  "--batch", str(batch), env=env)
         assert r3.returncode == 0, r3.stderr.decode()
@@ -204,7 +206,7 @@ def test_map_regrows_its_staging_for_unusual_records(tmp_path):
     ix = str(tmp_path / "r.idx")
     assert run("index", "12", "3", str(fa), ix).returncode == 0
     exp = "@SQ\tSN:chrL\tLN:%d\n" % len(seqs[0]) + expected_sam(["chrL"], reads, rnames, quals, want)
-    for env in (None, {"FEM_HOST_FORMAT": "1"}, {"FEM_HOST_FORMAT": "1", "FEM_SPLICE": "0"}, {"FEM_PACK_BASES": "0"}):
+    for env in (None, {"FEM_HOST_FORMAT": "1"}, {"FEM_HOST_FORMAT": "1", "FEM_SPLICE": "0"}, {"FEM_PACK_BASES": "0"}, {"FEM_HOST_QUALS": "1"}):
         out = str(tmp_path / "o.sam")
         r = run("map", "-e", "1", "-t", "4", "--ref", str(fa), "--index", ix, "--read1", str(fq), "-o", out, "--batch", "200", env=env)
         assert r.returncode == 0, r.stderr.decode()
