@@ -2233,6 +2233,7 @@ int fem_dev_commit_names_stage(fem_dev *h, int slot, uint64_t n_reads, uint64_t 
 int fem_dev_sam_quals(fem_dev *h, int slot, const uint64_t **qual_at, uint64_t *n_reads) {
   int rc = check_slot(h, slot);
   if (rc) return rc;
+  FEM_LOCK(h);
   Slot &s = h->slot[slot];
   if (!qual_at) return fail(h, FEM_ERR_INVALID, "null output pointer");
   if (!s.host_quals || !s.qual_at) return fail(h, FEM_ERR_STATE, "the slot's last SAM text was rendered with its qualities (or there is none)");
