@@ -259,9 +259,10 @@ def run_workload(key, dev, data, rk, steps, warmup, batch, torch, dist, red_dev,
         return tot, last
 
     dev.set_timing(True)  # (on during the warm-up as well: the timed steps then differ from it in nothing)
-    # The HIP runtime grows its command / signal pools over the first ~10 batches of a process's life (two enqueue calls
-    # of ~8 ms each around the 8th-10th batch, measured): with fewer warm-up steps than that asked for, the difference
-    # is run first, untimed and reported as config.priming_steps — it is setup, like the buffer allocations.
+    # The HIP runtime grows its command / signal pools over the first batches of a process's life (two enqueue calls of ~8 ms
+    # each around the 8th-10th batch; single stalls of 20-50 ms up to the ~80th: PRIME_PROCESS_TO above): with fewer warm-up
+    # steps than that asked for, the difference is run first, untimed and reported as config.priming_steps — it is setup, like
+    # the buffer allocations.
     priming = max(0, max(PRIME_TO, PRIME_PROCESS_TO - _batches_seen[0]) - max(warmup, 1))
     if priming:
         pipeline(priming)

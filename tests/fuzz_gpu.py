@@ -64,6 +64,10 @@ def trial(rng, dev, ref, idx, tref, seqs, kind, threads=16, max_reads=15000, log
         text, n_rec, n_assert, st = dev.fetch_sam(slot=slot, nowait=bool(rng.integers(0, 2)))
         host_text, host_assert = host.records_sam(tref, rnames, b.bases, b.off, quals, rec, threads=4, parts=True)
         ok = text.decode("latin-1") == host_text and n_assert == host_assert and n_rec == rec.n_records
+        if ok and rng.integers(0, 2):  # ... and with the qualities kept on the host (the device leaves their field open): the same bytes
+            dev.stage_text(quals, rnames, slot=slot, quals_on_host=True)
+            text_h, n_rec_h, _, _ = dev.fetch_sam(slot=slot, nowait=bool(rng.integers(0, 2)), quals=quals, offsets=b.off)
+            ok = text_h == text and n_rec_h == n_rec
     log(kind, dict(e=e, a=a, L=L, n=n, packed=dev.stage_info(slot)[1], full=full, kernel=dev.seed_kernel(e=e, a=a)), "ok" if ok else "MISMATCH",
         [int(x) for x in got.stats], flush=True)
     return ok
