@@ -93,7 +93,7 @@ WORKLOADS = {
 
 
 def plant_repeats(text, off, lens, units, copies, unit_len, rng):
-    """Overwrites `copies` places per unit with the unit (scratch/cliff_probe.py's reference): in place."""
+    """Overwrites `copies` places per unit with the unit (tools/cliff_probe.py's reference): in place."""
     import numpy as np
     g = np.random.default_rng(rng)
     acgt = np.frombuffer(b"ACGT", np.uint8)
