@@ -99,6 +99,10 @@ SleepingPool &parser_pool() {
   static SleepingPool pool;
   return pool;
 }
+SleepingPool &planner_pool() {  // the plan's pass has threads of its own: the NEXT batch may be planned while this one is filled
+  static SleepingPool pool;
+  return pool;
+}
 }  // namespace
 
 namespace {
@@ -962,7 +966,7 @@ int fem_seqfile_plan(fem_seqfile *f, uint64_t approx_bytes, int n_threads, fem_b
       for (int t = 1; t < nt; ++t) pl->cut[(size_t)t] = std::min(hi, next_fastq_record(m, len, lo + span * (size_t)t / (size_t)nt));
       for (int t = 1; t <= nt; ++t) pl->cut[(size_t)t] = std::max(pl->cut[(size_t)t], pl->cut[(size_t)t - 1]);
       pl->count.assign((size_t)nt, RangeCount());
-      parser_pool().run(nt, [&](int t) {
+      planner_pool().run(nt, [&](int t) {
         RangeCount c;
         size_t p = pl->cut[(size_t)t];
         const size_t h = pl->cut[(size_t)t + 1];
@@ -1160,6 +1164,8 @@ static int fill_packed_impl(fem_seqfile *f, fem_batch_plan *pl, int n_threads, u
   fem_batch_plan_free(pl);
   return 0;
 }
+
+int fem_seqfile_plan_ahead_ok(fem_seqfile *f) { return f && f->map && f->fast_ok ? 1 : 0; }
 
 void fem_batch_plan_free(fem_batch_plan *pl) {
   if (!pl) return;

@@ -86,6 +86,10 @@ typedef struct {
 int fem_seqfile_fill_packed_refs(fem_seqfile *f, fem_batch_plan *plan, int n_threads, uint32_t read_len, uint8_t *codes, uint64_t exc_cap,
                                  uint64_t *n_exc, fem_read_refs *refs);
 void fem_batch_plan_free(fem_batch_plan *plan);
+/* 1 when the NEXT batch may be planned (by another thread) while a plan of this file is still being filled: plain 4-line
+ * FASTQ files read through a mapping (a plan's records then stay where they are).  gzip / BGZF windows and the sequential
+ * reader reuse their buffers: 0, plan and fill alternate. */
+int fem_seqfile_plan_ahead_ok(fem_seqfile *f);
 
 /* ---------------- index files (src/index.c:100-168) ---------------- */
 /* int32 k | int32 step | uint32 lookup[4^k+1] | size_t n | uint64 occ[n] */
